@@ -1,0 +1,582 @@
+/*
+ * TEST INFRASTRUCTURE — CPU oracle for the RWARE step path.  NOT PRODUCT CODE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load this
+ * library, and only as the checker / reported CPU baseline.  The product
+ * (robotic-warehouse_amd/csrc) never links, includes or calls anything in this file.
+ *
+ * What it is: a plain-C restatement of the reference algorithm for the hot path
+ *   /root/reference/rware/warehouse.py  step()  :804-946
+ *                                       reset() :757-802
+ *                                       _get_default_obs() (FLATTENED) :598-674
+ *                                       _recalc_grid() :749-755, Agent.req_location :102-116,
+ *                                       Agent.req_direction :118-125
+ * plus the two third-party pieces the reference calls on that path and that are not under
+ * /root/reference:
+ *   - networkx 3.4.2 (unpinned in setup.py:28): weakly_connected_components, find_cycle,
+ *     dag_longest_path — restated LITERALLY here as a cell graph (union-find components,
+ *     cycle walk, longest-path DP), deliberately NOT in the closed form the HIP kernel uses,
+ *     so the two are independent derivations.
+ *   - numpy 2.2.6 Generator(PCG64) (unpinned in setup.py:25): PCG64 XSL-RR 128/64 with the
+ *     buffered 32-bit half, Lemire bounded draws, Floyd sampling + Fisher-Yates pass of
+ *     Generator.choice(replace=False), SeedSequence -> PCG64 seeding.
+ *
+ * Parity pin: tests/test_oracle_golden.py checks this file bit-for-bit against
+ * the tests/golden/ fixtures (.npz), which tests/golden/generate_golden.py produced by running the
+ * unmodified reference in the build container (oracle/ref_runner.py), and
+ * tests/test_oracle_vs_reference.py re-runs that comparison live when /root/reference
+ * exists.  The RNG pieces are additionally checked against numpy itself.
+ *
+ * Tie-break (see oracle/ref_runner.py): among equal-depth predecessors of a cell the
+ * LOWEST AGENT ID wins.  The reference's own choice is CPython-set-order dependent.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+
+enum { A_NOOP = 0, A_FORWARD = 1, A_LEFT = 2, A_RIGHT = 3, A_TOGGLE = 4 };
+enum { D_UP = 0, D_DOWN = 1, D_LEFT = 2, D_RIGHT = 3 };
+enum { RW_GLOBAL = 0, RW_INDIVIDUAL = 1, RW_TWO_STAGE = 2 };
+
+typedef struct orc_cfg {
+    int32_t H, W, N, Q, R, n_goals;
+    int32_t max_inactivity; /* 0 == None */
+    int32_t max_steps;      /* 0 == None */
+    int32_t reward_type;
+    int32_t normalised;
+    const uint8_t *highways; /* [H*W] */
+    const int32_t *goals;    /* [n_goals*2] (x, y) */
+} orc_cfg;
+
+/* batched SoA state, env-major; identical field meaning to the engine's buffers */
+typedef struct orc_state {
+    int32_t *grid;      /* [B][2][H][W]  layer 0 agents, layer 1 shelves (warehouse.py:11-14) */
+    int32_t *agent_x;   /* [B][N] */
+    int32_t *agent_y;
+    int32_t *agent_dir;
+    int32_t *agent_carry;     /* shelf id or 0 */
+    int32_t *agent_delivered; /* has_delivered */
+    int32_t *queue;     /* [B][Q] shelf ids, slot order */
+    int32_t *steps;     /* [B] _cur_steps */
+    int32_t *inactive;  /* [B] _cur_inactive_steps */
+    uint64_t *rng;      /* [B][6] state_hi,state_lo,inc_hi,inc_lo,has_uint32,uinteger */
+} orc_state;
+
+/* ------------------------------------------------------------------------------------ */
+/* numpy PCG64                                                                           */
+/* ------------------------------------------------------------------------------------ */
+#define PCG_MULT ((((u128)0x2360ED051FC65DA4ULL) << 64) | 0x4385DF649FCCF645ULL)
+
+typedef struct {
+    u128 state, inc;
+    int has_uint32;
+    uint32_t uinteger;
+} pcg64;
+
+static void pcg_load(pcg64 *g, const uint64_t *r) {
+    g->state = (((u128)r[0]) << 64) | r[1];
+    g->inc = (((u128)r[2]) << 64) | r[3];
+    g->has_uint32 = (int)r[4];
+    g->uinteger = (uint32_t)r[5];
+}
+static void pcg_store(const pcg64 *g, uint64_t *r) {
+    r[0] = (uint64_t)(g->state >> 64);
+    r[1] = (uint64_t)g->state;
+    r[2] = (uint64_t)(g->inc >> 64);
+    r[3] = (uint64_t)g->inc;
+    r[4] = (uint64_t)g->has_uint32;
+    r[5] = g->uinteger;
+}
+static uint64_t pcg_next64(pcg64 *g) {
+    g->state = g->state * PCG_MULT + g->inc;
+    uint64_t hi = (uint64_t)(g->state >> 64), lo = (uint64_t)g->state;
+    uint64_t x = hi ^ lo;
+    unsigned rot = (unsigned)(hi >> 58);
+    return (x >> rot) | (x << ((-rot) & 63));
+}
+static uint32_t pcg_next32(pcg64 *g) {
+    if (g->has_uint32) {
+        g->has_uint32 = 0;
+        return g->uinteger;
+    }
+    uint64_t n = pcg_next64(g);
+    g->has_uint32 = 1;
+    g->uinteger = (uint32_t)(n >> 32);
+    return (uint32_t)n;
+}
+/* numpy random_bounded_uint64(off=0, rng, use_masked=0) for rng < 2^32-1: value in [0, rng] */
+static uint32_t bounded(pcg64 *g, uint32_t rng) {
+    if (rng == 0) return 0; /* no draw consumed */
+    const uint32_t rng_excl = rng + 1;
+    uint64_t m = (uint64_t)pcg_next32(g) * rng_excl;
+    uint32_t leftover = (uint32_t)m;
+    if (leftover < rng_excl) {
+        const uint32_t threshold = (UINT32_MAX - rng) % rng_excl;
+        while (leftover < threshold) {
+            m = (uint64_t)pcg_next32(g) * rng_excl;
+            leftover = (uint32_t)m;
+        }
+    }
+    return (uint32_t)(m >> 32);
+}
+/* Generator.choice(pop, size=k, replace=False, shuffle=True) index draw (Floyd + Fisher-Yates) */
+static void choice_no_replace(pcg64 *g, int pop, int k, int32_t *out) {
+    for (int j = pop - k; j < pop; ++j) {
+        int32_t val = (int32_t)bounded(g, (uint32_t)j);
+        int seen = 0;
+        for (int i = 0; i < j - (pop - k); ++i)
+            if (out[i] == val) seen = 1;
+        out[j - (pop - k)] = seen ? j : val;
+    }
+    for (int i = k - 1; i >= 1; --i) {
+        int j = (int)bounded(g, (uint32_t)i);
+        int32_t t = out[j];
+        out[j] = out[i];
+        out[i] = t;
+    }
+}
+
+/* numpy SeedSequence(entropy=seed).generate_state(4, uint64) -> PCG64 state */
+static uint32_t ss_hashmix(uint32_t v, uint32_t *hc) {
+    v ^= *hc;
+    *hc *= 0x931e8875u;
+    v *= *hc;
+    v ^= v >> 16;
+    return v;
+}
+static uint32_t ss_mix(uint32_t x, uint32_t y) {
+    uint32_t r = 0xca01f9ddu * x - 0x4973f715u * y;
+    r ^= r >> 16;
+    return r;
+}
+void orc_seed(uint64_t seed, uint64_t out[6]) {
+    uint32_t ent[2];
+    int n_ent = 1;
+    ent[0] = (uint32_t)seed;
+    ent[1] = (uint32_t)(seed >> 32);
+    if (ent[1]) n_ent = 2;
+    uint32_t pool[4], hc = 0x43b0d7e5u;
+    for (int i = 0; i < 4; ++i) pool[i] = ss_hashmix(i < n_ent ? ent[i] : 0u, &hc);
+    for (int s = 0; s < 4; ++s)
+        for (int d = 0; d < 4; ++d)
+            if (s != d) pool[d] = ss_mix(pool[d], ss_hashmix(pool[s], &hc));
+    uint32_t w[8], hb = 0x8b51f9ddu;
+    for (int i = 0; i < 8; ++i) {
+        uint32_t v = pool[i & 3];
+        v ^= hb;
+        hb *= 0x58f38dedu;
+        v *= hb;
+        v ^= v >> 16;
+        w[i] = v;
+    }
+    uint64_t s64[4];
+    for (int i = 0; i < 4; ++i) s64[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    /* pcg64_set_seed: seed = (s64[0] hi, s64[1] lo), inc = (s64[2] hi, s64[3] lo) */
+    u128 initstate = (((u128)s64[0]) << 64) | s64[1];
+    u128 initseq = (((u128)s64[2]) << 64) | s64[3];
+    pcg64 g;
+    g.state = 0;
+    g.inc = (initseq << 1) | 1u;
+    g.state = g.state * PCG_MULT + g.inc;
+    g.state += initstate;
+    g.state = g.state * PCG_MULT + g.inc;
+    g.has_uint32 = 0;
+    g.uinteger = 0;
+    pcg_store(&g, out);
+}
+
+/* test hooks for the numpy cross-check */
+uint32_t orc_rng_bounded(uint64_t r[6], uint32_t rng) {
+    pcg64 g;
+    pcg_load(&g, r);
+    uint32_t v = bounded(&g, rng);
+    pcg_store(&g, r);
+    return v;
+}
+void orc_rng_choice(uint64_t r[6], int pop, int k, int32_t *out) {
+    pcg64 g;
+    pcg_load(&g, r);
+    choice_no_replace(&g, pop, k, out);
+    pcg_store(&g, r);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* helpers                                                                               */
+/* ------------------------------------------------------------------------------------ */
+int orc_num_shelves(const orc_cfg *c) {
+    int s = 0;
+    for (int i = 0; i < c->H * c->W; ++i) s += c->highways[i] ? 0 : 1;
+    return s;
+}
+int orc_obs_len(const orc_cfg *c) {
+    int win = (2 * c->R + 1) * (2 * c->R + 1);
+    return 8 + win * 5 + win * 2; /* warehouse.py:432-443 with msg_bits = 0 */
+}
+
+typedef struct {
+    int32_t *grid, *ax, *ay, *adir, *acarry, *adeliv, *queue, *steps, *inactive;
+    uint64_t *rng;
+} env_view;
+
+static env_view view(const orc_cfg *c, const orc_state *s, int e) {
+    env_view v;
+    v.grid = s->grid + (size_t)e * 2 * c->H * c->W;
+    v.ax = s->agent_x + (size_t)e * c->N;
+    v.ay = s->agent_y + (size_t)e * c->N;
+    v.adir = s->agent_dir + (size_t)e * c->N;
+    v.acarry = s->agent_carry + (size_t)e * c->N;
+    v.adeliv = s->agent_delivered + (size_t)e * c->N;
+    v.queue = s->queue + (size_t)e * c->Q;
+    v.steps = s->steps + e;
+    v.inactive = s->inactive + e;
+    v.rng = s->rng + (size_t)e * 6;
+    return v;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* reset  (warehouse.py:757-802)                                                         */
+/* ------------------------------------------------------------------------------------ */
+static void reset_one(const orc_cfg *c, env_view v) {
+    const int H = c->H, W = c->W, N = c->N, Q = c->Q, HW = H * W;
+    pcg64 g;
+    pcg_load(&g, v.rng);
+    *v.steps = 0;
+    *v.inactive = 0;
+    memset(v.grid, 0, sizeof(int32_t) * 2 * HW);
+    /* shelves: one per non-highway cell, ids 1..S in row-major (y outer, x inner) order :771-778 */
+    int S = 0;
+    for (int i = 0; i < HW; ++i)
+        if (!c->highways[i]) v.grid[HW + i] = ++S;
+    /* agent cells: choice(arange(H*W), size=N, replace=False) -> unravel_index -> (y, x) :781-786 */
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > Q ? N : Q));
+    choice_no_replace(&g, HW, N, tmp);
+    for (int i = 0; i < N; ++i) {
+        v.ay[i] = tmp[i] / W;
+        v.ax[i] = tmp[i] % W;
+    }
+    /* directions: choice(list(Direction), size=N) == N bounded draws in [0,3] :788 */
+    for (int i = 0; i < N; ++i) v.adir[i] = (int32_t)bounded(&g, 3);
+    for (int i = 0; i < N; ++i) {
+        v.acarry[i] = 0;
+        v.adeliv[i] = 0;
+        v.grid[v.ay[i] * W + v.ax[i]] = i + 1; /* _recalc_grid :754-755 */
+    }
+    /* request queue: choice(shelfs, size=Q, replace=False) :796-800 ; shelfs[k].id == k+1 */
+    choice_no_replace(&g, S, Q, tmp);
+    for (int i = 0; i < Q; ++i) v.queue[i] = tmp[i] + 1;
+    free(tmp);
+    pcg_store(&g, v.rng);
+}
+
+int orc_reset(const orc_cfg *c, int B, orc_state *s, const uint8_t *mask) {
+    for (int e = 0; e < B; ++e)
+        if (!mask || mask[e]) reset_one(c, view(c, s, e));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* step  (warehouse.py:804-946), collision graph restated literally                      */
+/* ------------------------------------------------------------------------------------ */
+#define MAXN 64
+
+static int uf_find(int *p, int a) {
+    while (p[a] != a) {
+        p[a] = p[p[a]];
+        a = p[a];
+    }
+    return a;
+}
+
+static int in_queue(const int32_t *q, int Q, int sid) {
+    for (int i = 0; i < Q; ++i)
+        if (q[i] == sid) return i;
+    return -1;
+}
+
+/* returns 0 ok, -2 invalid action */
+static int step_one(const orc_cfg *c, env_view v, const int32_t *act, float *rew, uint8_t *done) {
+    const int H = c->H, W = c->W, N = c->N, Q = c->Q, HW = H * W;
+    int32_t *gA = v.grid, *gS = v.grid + HW;
+    int req[MAXN], start[MAXN], target[MAXN], commit[MAXN];
+    if (N > MAXN) return -1;
+    for (int i = 0; i < N; ++i) {
+        if (act[i] < 0 || act[i] > 4) return -2; /* Action(action) raises ValueError :814 */
+        req[i] = act[i];
+    }
+    /* intent + shelf-block cancel :825-846 (reads the start-of-step grid) */
+    for (int i = 0; i < N; ++i) {
+        int x = v.ax[i], y = v.ay[i], tx = x, ty = y;
+        if (req[i] == A_FORWARD) { /* req_location :102-112, clamped at walls */
+            if (v.adir[i] == D_UP) ty = y - 1 < 0 ? 0 : y - 1;
+            else if (v.adir[i] == D_DOWN) ty = y + 1 > H - 1 ? H - 1 : y + 1;
+            else if (v.adir[i] == D_LEFT) tx = x - 1 < 0 ? 0 : x - 1;
+            else tx = x + 1 > W - 1 ? W - 1 : x + 1;
+        }
+        start[i] = y * W + x;
+        target[i] = ty * W + tx;
+        if (v.acarry[i] && start[i] != target[i] && gS[target[i]] &&
+            !(gA[target[i]] && v.acarry[gA[target[i]] - 1])) {
+            req[i] = A_NOOP;
+            target[i] = start[i];
+        }
+    }
+    /* G: nodes = cells, one out-edge per agent.  out[cell] = target cell, or -1 (no agent). */
+    int *out = (int *)malloc(sizeof(int) * (size_t)HW * 3);
+    int *par = out + HW, *owner = out + 2 * HW; /* owner[cell] = agent index whose START is cell */
+    for (int i = 0; i < HW; ++i) {
+        out[i] = -1;
+        par[i] = i;
+        owner[i] = -1;
+    }
+    for (int i = 0; i < N; ++i) {
+        out[start[i]] = target[i];
+        owner[start[i]] = i;
+    }
+    for (int i = 0; i < N; ++i) { /* weakly connected components */
+        int a = uf_find(par, start[i]), b = uf_find(par, target[i]);
+        if (a != b) par[a] = b;
+    }
+    for (int i = 0; i < N; ++i) commit[i] = 0;
+    char comp_done[MAXN];
+    memset(comp_done, 0, sizeof comp_done);
+    for (int i = 0; i < N; ++i) {
+        if (comp_done[i]) continue;
+        int root = uf_find(par, start[i]);
+        int members[MAXN], nm = 0;
+        for (int j = 0; j < N; ++j)
+            if (!comp_done[j] && uf_find(par, start[j]) == root) {
+                members[nm++] = j;
+                comp_done[j] = 1;
+            }
+        /* find_cycle: walk out-edges from a member; nm+1 steps either fall off at the sink or enter the cycle */
+        int cur = start[members[0]], has_cycle = 1;
+        for (int k = 0; k <= nm; ++k) {
+            if (out[cur] < 0) {
+                has_cycle = 0;
+                break;
+            }
+            cur = out[cur];
+        }
+        if (has_cycle) {
+            int len = 0, p = cur;
+            do {
+                p = out[p];
+                ++len;
+            } while (p != cur);
+            if (len == 2) continue; /* [A] <-> [B] swap: nobody in the component commits :855-858 */
+            p = cur;
+            do { /* commit exactly the cycle's agents :859-863 */
+                commit[owner[p]] = 1;
+                p = out[p];
+            } while (p != cur);
+        } else {
+            /* dag_longest_path on an in-tree draining into `cur` (the sink, an empty cell).
+             * dist[cell of agent j] = longest chain of followers behind j. */
+            int dist[MAXN], changed = 1;
+            for (int a = 0; a < nm; ++a) dist[members[a]] = 0;
+            while (changed) { /* relax to fixpoint: depth <= nm */
+                changed = 0;
+                for (int a = 0; a < nm; ++a) {
+                    int j = members[a], tj = owner[target[j]];
+                    if (tj >= 0 && dist[tj] < dist[j] + 1) {
+                        dist[tj] = dist[j] + 1;
+                        changed = 1;
+                    }
+                }
+            }
+            int node = cur; /* walk back from the sink choosing the best predecessor each time */
+            for (;;) {
+                int best = -1;
+                for (int a = 0; a < nm; ++a) {
+                    int j = members[a];
+                    if (target[j] != node) continue;
+                    if (best < 0 || dist[j] > dist[best]) best = j; /* members ascending: ties keep lowest id */
+                }
+                if (best < 0) break;
+                commit[best] = 1; /* :866-869 */
+                node = start[best];
+            }
+        }
+    }
+    free(out);
+    for (int i = 0; i < N; ++i)
+        if (!commit[i]) req[i] = A_NOOP; /* failed agents :871-876 */
+
+    for (int i = 0; i < N; ++i) rew[i] = 0.0f;
+    double r64[MAXN];
+    for (int i = 0; i < N; ++i) r64[i] = 0.0;
+    /* apply :880-899 */
+    for (int i = 0; i < N; ++i) {
+        if (req[i] == A_FORWARD) {
+            v.ax[i] = target[i] % W;
+            v.ay[i] = target[i] / W;
+        } else if (req[i] == A_LEFT || req[i] == A_RIGHT) {
+            static const int wrap[4] = {D_UP, D_RIGHT, D_DOWN, D_LEFT}; /* :119 */
+            int idx = 0;
+            for (int k = 0; k < 4; ++k)
+                if (wrap[k] == v.adir[i]) idx = k;
+            v.adir[i] = wrap[(idx + (req[i] == A_RIGHT ? 1 : 3)) % 4];
+        } else if (req[i] == A_TOGGLE && !v.acarry[i]) {
+            int sid = gS[start[i]];
+            if (sid) v.acarry[i] = sid;
+        } else if (req[i] == A_TOGGLE && v.acarry[i]) {
+            if (!c->highways[start[i]]) {
+                v.acarry[i] = 0;
+                if (v.adeliv[i] && c->reward_type == RW_TWO_STAGE) r64[i] += 0.5;
+                v.adeliv[i] = 0;
+            }
+        }
+    }
+    /* _recalc_grid :749-755 — rebuilt from shelf positions: standing shelves stay, carried ones follow */
+    {
+        int32_t *ns = (int32_t *)calloc((size_t)HW, sizeof(int32_t));
+        char carried_id_moved = 0;
+        (void)carried_id_moved;
+        /* standing shelves: every shelf id in the old layer that is not carried by a FORWARD-committed agent
+         * keeps its cell; a carried shelf sits at its carrier's (new) cell. */
+        for (int cell = 0; cell < HW; ++cell) {
+            int sid = gS[cell];
+            if (!sid) continue;
+            int carried_by = -1;
+            for (int i = 0; i < N; ++i)
+                if (v.acarry[i] == sid && start[i] == cell) carried_by = i;
+            if (carried_by >= 0) continue; /* placed below at the carrier's cell */
+            ns[cell] = sid;
+        }
+        for (int i = 0; i < N; ++i)
+            if (v.acarry[i]) ns[v.ay[i] * W + v.ax[i]] = v.acarry[i];
+        memcpy(gS, ns, sizeof(int32_t) * (size_t)HW);
+        free(ns);
+        memset(gA, 0, sizeof(int32_t) * (size_t)HW);
+        for (int i = 0; i < N; ++i) gA[v.ay[i] * W + v.ax[i]] = i + 1;
+    }
+    /* goals, in list order :903-927 */
+    int delivered = 0;
+    int S = orc_num_shelves(c);
+    for (int gidx = 0; gidx < c->n_goals; ++gidx) {
+        int cell = c->goals[2 * gidx + 1] * W + c->goals[2 * gidx];
+        int sid = gS[cell];
+        if (!sid) continue;
+        int slot = in_queue(v.queue, Q, sid);
+        if (slot < 0) continue;
+        delivered = 1;
+        /* candidates = shelves not in the queue, id order; one bounded draw in [0, n_cand) :915-917 */
+        int n_cand = S - Q;
+        pcg64 g;
+        pcg_load(&g, v.rng);
+        int idx = (int)bounded(&g, (uint32_t)(n_cand - 1));
+        pcg_store(&g, v.rng);
+        int cnt = -1, new_sid = 0;
+        for (int id = 1; id <= S; ++id) {
+            if (in_queue(v.queue, Q, id) >= 0) continue;
+            if (++cnt == idx) {
+                new_sid = id;
+                break;
+            }
+        }
+        v.queue[slot] = new_sid;
+        if (c->reward_type == RW_GLOBAL) {
+            for (int i = 0; i < N; ++i) r64[i] += 1.0;
+        } else {
+            int aid = gA[cell];
+            int ai = aid > 0 ? aid - 1 : N - 1; /* rewards[-1] quirk when no agent stands on the goal */
+            if (c->reward_type == RW_INDIVIDUAL) {
+                r64[ai] += 1.0;
+            } else {
+                v.adeliv[ai] = 1;
+                r64[ai] += 0.5;
+            }
+        }
+    }
+    if (delivered) *v.inactive = 0;
+    else *v.inactive += 1;
+    *v.steps += 1;
+    *done = ((c->max_inactivity && *v.inactive >= c->max_inactivity) ||
+             (c->max_steps && *v.steps >= c->max_steps))
+                ? 1
+                : 0;
+    for (int i = 0; i < N; ++i) rew[i] = (float)r64[i];
+    return 0;
+}
+
+int orc_step(const orc_cfg *c, int B, orc_state *s, const int32_t *actions, float *rewards,
+             uint8_t *done, const uint8_t *mask) {
+    for (int e = 0; e < B; ++e) {
+        if (mask && !mask[e]) continue;
+        int rc = step_one(c, view(c, s, e), actions + (size_t)e * c->N, rewards + (size_t)e * c->N,
+                          done + e);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* FLATTENED observation  (warehouse.py:598-674)                                         */
+/* ------------------------------------------------------------------------------------ */
+static void obs_one(const orc_cfg *c, env_view v, float *obs) {
+    const int H = c->H, W = c->W, N = c->N, R = c->R, HW = H * W, L = orc_obs_len(c);
+    const int32_t *gA = v.grid, *gS = v.grid + HW;
+    for (int i = 0; i < N; ++i) {
+        float *o = obs + (size_t)i * L;
+        int k = 0;
+        if (c->normalised) { /* :636-638, float64 division stored to a float32 vector */
+            o[k++] = (float)((double)v.ax[i] / (double)(W - 1));
+            o[k++] = (float)((double)v.ay[i] / (double)(H - 1));
+        } else {
+            o[k++] = (float)v.ax[i];
+            o[k++] = (float)v.ay[i];
+        }
+        o[k++] = v.acarry[i] ? 1.0f : 0.0f;
+        for (int d = 0; d < 4; ++d) o[k++] = v.adir[i] == d ? 1.0f : 0.0f;
+        o[k++] = c->highways[v.ay[i] * W + v.ax[i]] ? 1.0f : 0.0f;
+        for (int dy = -R; dy <= R; ++dy)       /* window row-major: dy outer, dx inner :628-629 */
+            for (int dx = -R; dx <= R; ++dx) {
+                int x = v.ax[i] + dx, y = v.ay[i] + dy;
+                int ida = 0, ids = 0;
+                if (x >= 0 && x < W && y >= 0 && y < H) { /* off-map == zero padding :612-617 */
+                    ida = gA[y * W + x];
+                    ids = gS[y * W + x];
+                }
+                if (!ida) {
+                    o[k++] = 0.0f;
+                    o[k++] = 1.0f; /* empty cells encode direction [1,0,0,0] :659 */
+                    o[k++] = 0.0f;
+                    o[k++] = 0.0f;
+                    o[k++] = 0.0f;
+                } else {
+                    o[k++] = 1.0f;
+                    for (int d = 0; d < 4; ++d) o[k++] = v.adir[ida - 1] == d ? 1.0f : 0.0f;
+                }
+                if (!ids) {
+                    o[k++] = 0.0f;
+                    o[k++] = 0.0f;
+                } else {
+                    o[k++] = 1.0f;
+                    o[k++] = in_queue(v.queue, c->Q, ids) >= 0 ? 1.0f : 0.0f;
+                }
+            }
+    }
+}
+
+int orc_obs(const orc_cfg *c, int B, const orc_state *s, float *obs) {
+    const int L = orc_obs_len(c);
+    for (int e = 0; e < B; ++e) obs_one(c, view(c, s, e), obs + (size_t)e * c->N * L);
+    return 0;
+}
+
+/* rebuild grid from explicit shelf positions + agents, exactly as _recalc_grid :749-755
+ * (shelf_xy: [S][2] (x,y) in id order; later ids overwrite earlier ones) — for the
+ * state-injection tests that mirror the reference's own tests. */
+int orc_recalc_grid(const orc_cfg *c, int B, orc_state *s, const int32_t *shelf_xy, int S) {
+    const int HW = c->H * c->W;
+    for (int e = 0; e < B; ++e) {
+        env_view v = view(c, s, e);
+        memset(v.grid, 0, sizeof(int32_t) * 2 * (size_t)HW);
+        const int32_t *sx = shelf_xy + (size_t)e * S * 2;
+        for (int k = 0; k < S; ++k) v.grid[HW + sx[2 * k + 1] * c->W + sx[2 * k]] = k + 1;
+        for (int i = 0; i < c->N; ++i) v.grid[v.ay[i] * c->W + v.ax[i]] = i + 1;
+    }
+    return 0;
+}
