@@ -1,0 +1,183 @@
+/*
+ * rware_hip.h — C-ABI of the MI355X-native vectorised RWARE step engine.
+ *
+ * This is the drop-in boundary for ONE path of semitable/robotic-warehouse: the per-step hot
+ * path of `rware.warehouse.Warehouse` (reset / step / FLATTENED observation), batched over
+ * `num_envs` independent warehouses resident in HBM on one HIP device.  The reference has no
+ * native code, so there is no existing FFI to mirror; each entry point below cites the Python
+ * interface it replaces.  The Python binding a maintainer would add is in INTEGRATION.md; the
+ * in-tree one is robotic-warehouse_amd/_capi.py.
+ *
+ * Conventions
+ *   - plain C types only; every call returns an `int` status (RW_OK == 0, negatives are errors)
+ *     and never throws or aborts across the boundary; `rw_last_error` gives the message.
+ *   - the engine owns all device memory for its lifetime; pointers from `rw_get_buffer` are
+ *     borrowed, stable until `rw_destroy`, and the obs/reward/terminated buffers are overwritten
+ *     by the next step.  Callers own the action arrays they pass in.
+ *   - one engine == one HIP device + one stream.  Calls on one engine are not re-entrant;
+ *     different engines (one per GPU) may be driven from different host threads.
+ *   - all work is enqueued asynchronously on the engine's stream; `rw_sync` waits for it.
+ *   - env index e, agent index i (agent id = i+1), cell index c = y*W + x.
+ */
+#ifndef RWARE_HIP_H
+#define RWARE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RW_ABI_VERSION 1
+
+typedef struct rw_engine rw_engine;
+
+enum rw_status {
+    RW_OK = 0,
+    RW_ERR_INVALID_ARG = -1,    /* bad config / null pointer / size mismatch                     */
+    RW_ERR_INVALID_ACTION = -2, /* an action outside 0..4 was seen (reference: Action(a) raises
+                                   ValueError, rware/warehouse.py:814); sticky until rw_sync      */
+    RW_ERR_HIP = -3,            /* a HIP runtime call failed                                      */
+    RW_ERR_UNSUPPORTED = -4,    /* feature outside the accelerated path (msg_bits>0, image obs)   */
+    RW_ERR_NO_DEVICE = -5       /* no usable HIP device: there is NO CPU fallback                 */
+};
+
+/* rware/warehouse.py:31-36 */
+enum rw_action { RW_NOOP = 0, RW_FORWARD = 1, RW_LEFT = 2, RW_RIGHT = 3, RW_TOGGLE_LOAD = 4 };
+/* rware/warehouse.py:39-43 */
+enum rw_direction { RW_UP = 0, RW_DOWN = 1, RW_DIR_LEFT = 2, RW_DIR_RIGHT = 3 };
+/* rware/warehouse.py:46-49 */
+enum rw_reward_type { RW_REWARD_GLOBAL = 0, RW_REWARD_INDIVIDUAL = 1, RW_REWARD_TWO_STAGE = 2 };
+
+/* What a step does with an env whose episode ended (Gymnasium vector-env autoreset modes).
+ * The reference env itself never resets (the caller calls reset()); DISABLED reproduces that. */
+enum rw_autoreset {
+    RW_AUTORESET_DISABLED = 0,
+    RW_AUTORESET_NEXT_STEP = 1, /* the step after `terminated` performs reset(): action ignored,
+                                   reward 0, terminated 0 (Gymnasium >= 1.0 default)              */
+    RW_AUTORESET_SAME_STEP = 2  /* the terminating step returns the reset observation             */
+};
+
+/* Device buffers (all env-major, C-contiguous).  Replaces the attributes callers read off the
+ * reference object: env.grid (:302), env.agents[i].{x,y,dir,carrying_shelf,has_delivered}
+ * (:82-93), env.request_queue (:263), env._cur_steps/_cur_inactive_steps (:249-250),
+ * env.np_random.bit_generator.state, and the step() return tuple (:944-946). */
+enum rw_buffer_kind {
+    RW_BUF_OBS = 0,          /* float32 [B][N][L]  FLATTENED observation (:598-674)               */
+    RW_BUF_REWARDS = 1,      /* float32 [B][N]                                                    */
+    RW_BUF_TERMINATED = 2,   /* uint8   [B]        `done` (:935-941)                              */
+    RW_BUF_TRUNCATED = 3,    /* uint8   [B]        always 0 (:942)                                */
+    RW_BUF_GRID = 4,         /* int32   [B][2][H][W] layer 0 agent ids, layer 1 shelf ids (:11-14)*/
+    RW_BUF_AGENT_X = 5,      /* int32   [B][N]                                                    */
+    RW_BUF_AGENT_Y = 6,      /* int32   [B][N]                                                    */
+    RW_BUF_AGENT_DIR = 7,    /* int32   [B][N]     rw_direction                                   */
+    RW_BUF_AGENT_CARRY = 8,  /* int32   [B][N]     carried shelf id, 0 == none                    */
+    RW_BUF_AGENT_DELIVERED = 9, /* int32 [B][N]    has_delivered                                  */
+    RW_BUF_QUEUE = 10,       /* int32   [B][Q]     requested shelf ids in slot order              */
+    RW_BUF_STEPS = 11,       /* int32   [B]                                                       */
+    RW_BUF_INACTIVE = 12,    /* int32   [B]                                                       */
+    RW_BUF_RNG = 13,         /* uint64  [6][B]     FIELD-major: state_hi, state_lo, inc_hi, inc_lo,
+                                                   has_uint32, uinteger (numpy PCG64 state)       */
+    RW_BUF_NEED_RESET = 14,  /* uint8   [B]        NEXT_STEP autoreset: env resets on next step   */
+    RW_BUF_ACTIONS = 15,     /* int32   [B][N]     staging buffer used by rw_step (host actions)  */
+    RW_BUF_KIND_COUNT = 16
+};
+
+/* Mirrors the constructor of rware.warehouse.Warehouse (rware/warehouse.py:146-170).  The
+ * layout (`highways`, `goals`) is computed host-side exactly as _make_layout_from_params /
+ * _make_layout_from_str do (:294-350) and handed over as plain arrays. */
+typedef struct rw_config {
+    int32_t abi_version;          /* RW_ABI_VERSION                                              */
+    int32_t num_envs;             /* B                                                           */
+    int32_t grid_h, grid_w;       /* grid_size (:297-300)                                        */
+    int32_t n_agents;             /* N, 1..64                                                    */
+    int32_t sensor_range;         /* r, 1..5 ; L = 8 + 7*(2r+1)^2 (:432-443, msg_bits == 0)      */
+    int32_t request_queue_size;   /* Q                                                           */
+    int32_t max_inactivity_steps; /* 0 == None                                                   */
+    int32_t max_steps;            /* 0 == None                                                   */
+    int32_t reward_type;          /* rw_reward_type                                              */
+    int32_t normalised_coordinates;
+    int32_t autoreset_mode;       /* rw_autoreset                                                */
+    int32_t n_goals;
+    int32_t device_id;            /* HIP device ordinal                                          */
+    int32_t envs_per_workgroup;   /* 0 == engine default; otherwise a multiple of 4              */
+    int32_t threads_per_workgroup;/* 0 == engine default; otherwise a multiple of 64             */
+    const uint8_t *highways;      /* host, [H*W], 1 == highway (no shelf spawns, no unloading)   */
+    const int32_t *goals_xy;      /* host, [n_goals][2] = (x, y), list order == reward order     */
+    void *stream;                 /* hipStream_t to enqueue on; NULL == engine creates its own   */
+} rw_config;
+
+/* -- lifetime ------------------------------------------------------------------------- */
+/* replaces Warehouse.__init__ (:146-292) */
+int rw_create(const rw_config *cfg, rw_engine **out);
+int rw_destroy(rw_engine *eng);
+/* message for the most recent failing call on this engine (or on rw_create when eng == NULL) */
+const char *rw_last_error(const rw_engine *eng);
+
+/* -- the hot path ----------------------------------------------------------------------- */
+/* replaces Warehouse.reset(seed, options) (:757-802).
+ *   seeds: host [B] or NULL.  Non-NULL: env e is reseeded with numpy SeedSequence(seeds[e]) ->
+ *          PCG64 (what gymnasium.utils.seeding.np_random does, :758-760) before the reset draws.
+ *          NULL: the env's existing stream continues (reset() with seed=None).
+ *   mask:  host [B] or NULL (all).  Only envs with mask[e] != 0 are reseeded/reset.
+ * Observations of all envs are refreshed in RW_BUF_OBS. */
+int rw_reset(rw_engine *eng, const uint64_t *seeds, const uint8_t *mask);
+
+/* replaces Warehouse.step(actions) (:804-946) for all B envs.
+ *   rw_step:        actions is a HOST array int32 [B][N]; copied to RW_BUF_ACTIONS, then launched.
+ *   rw_step_device: actions is a DEVICE array int32 [B][N] (e.g. the policy's output tensor);
+ *                   no copy.  Must stay valid until the step has executed.
+ * Results land in RW_BUF_OBS / REWARDS / TERMINATED / TRUNCATED. */
+int rw_step(rw_engine *eng, const int32_t *actions_host);
+int rw_step_device(rw_engine *eng, const int32_t *actions_dev);
+
+/* T consecutive steps from a device-resident action tape int32 [T][B][N]; one launch per step,
+ * no host round trip in between (rollout API).  If `obs_tape` /
+ * `reward_tape` / `terminated_tape` are non-NULL device pointers they receive every step's
+ * outputs ([T][B][N][L] f32, [T][B][N] f32, [T][B] u8); otherwise only the last step's remain. */
+int rw_step_many_device(rw_engine *eng, const int32_t *actions_dev, int32_t n_steps,
+                        float *obs_tape, float *reward_tape, uint8_t *terminated_tape);
+
+/* recompute RW_BUF_OBS from the current state (after rw_write of state buffers) */
+int rw_refresh_obs(rw_engine *eng);
+
+/* wait for everything enqueued; returns RW_ERR_INVALID_ACTION if any step since the last
+ * rw_sync saw an out-of-range action (that action was executed as NOOP), else RW_OK */
+int rw_sync(rw_engine *eng);
+
+/* -- buffers ---------------------------------------------------------------------------- */
+int rw_get_buffer(rw_engine *eng, int kind, void **dev_ptr, size_t *bytes);
+/* synchronous copies between a buffer and host memory (state inspection / injection) */
+int rw_read(rw_engine *eng, int kind, void *host_dst, size_t bytes);
+int rw_write(rw_engine *eng, int kind, const void *host_src, size_t bytes);
+/* rebuild RW_BUF_GRID exactly like Warehouse._recalc_grid (:749-755) from explicit shelf
+ * positions (host int32 [B][S][2] = (x,y) per shelf id; later ids overwrite earlier) and the
+ * current agent positions.  This is how the reference's own tests inject state. */
+int rw_recalc_grid(rw_engine *eng, const int32_t *shelf_xy, int32_t n_shelves);
+
+/* -- introspection ---------------------------------------------------------------------- */
+typedef struct rw_info {
+    int32_t num_envs, grid_h, grid_w, n_agents, request_queue_size, n_shelves, obs_length;
+    int32_t envs_per_workgroup, threads_per_workgroup, n_workgroups, lds_bytes;
+    int32_t device_id, compute_units;
+    int64_t algorithmic_bytes_per_env_step; /* SURVEY.md §8(d) formula                           */
+    char device_name[128];
+    char arch_name[64];
+} rw_info;
+int rw_get_info(const rw_engine *eng, rw_info *out);
+
+/* numpy SeedSequence(seed) -> PCG64 initial state, as 6 uint64 in RW_BUF_RNG field order.
+ * Pure host function (exposed so tests can check the seeding against numpy). */
+int rw_seed_state(uint64_t seed, uint64_t out[6]);
+
+/* -- timing on the engine's own stream (hipEvents), used by bench.py --------------------- */
+int rw_event_record(rw_engine *eng, int32_t slot /* 0..7 */);
+int rw_event_elapsed_ms(rw_engine *eng, int32_t slot_begin, int32_t slot_end, float *ms);
+
+int rw_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RWARE_HIP_H */

@@ -1,0 +1,17 @@
+"""MI355X-native vectorised RWARE step engine (drop-in for the step path of
+semitable/robotic-warehouse: reset / step / FLATTENED observation of `rware.warehouse.Warehouse`).
+
+The directory is named `robotic-warehouse_amd` (not an identifier); import it as `rware_amd`
+(the shim module at the repository root) or via importlib.
+"""
+from .enums import Action, Direction, ObservationType, RewardType
+from .layout import Layout, layout_from_params, layout_from_str, obs_length
+from .registry import all_ids, env_kwargs, make_vec, register_gymnasium
+from .vector_env import STATE_FIELDS, WarehouseVecEnv
+
+__all__ = [
+    "Action", "Direction", "ObservationType", "RewardType", "Layout", "layout_from_params",
+    "layout_from_str", "obs_length", "all_ids", "env_kwargs", "make_vec", "register_gymnasium",
+    "WarehouseVecEnv", "STATE_FIELDS",
+]
+__version__ = "0.1.0"

@@ -1,0 +1,225 @@
+"""ctypes binding of include/rware_hip.h (the in-tree equivalent of the stub in INTEGRATION.md).
+
+There is no CPU fallback: if `csrc/librware_hip.so` has not been built this module raises, and
+if no HIP device is visible `rw_create` fails with RW_ERR_NO_DEVICE.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "librware_hip.so")
+
+RW_ABI_VERSION = 1
+RW_OK, RW_ERR_INVALID_ARG, RW_ERR_INVALID_ACTION, RW_ERR_HIP, RW_ERR_UNSUPPORTED, RW_ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+
+BUF = {
+    "obs": 0, "rewards": 1, "terminated": 2, "truncated": 3, "grid": 4, "agent_x": 5, "agent_y": 6,
+    "agent_dir": 7, "agent_carry": 8, "agent_delivered": 9, "queue": 10, "steps": 11, "inactive": 12,
+    "rng": 13, "need_reset": 14, "actions": 15,
+}
+BUF_DTYPE = {
+    "obs": np.float32, "rewards": np.float32, "terminated": np.uint8, "truncated": np.uint8,
+    "rng": np.uint64, "need_reset": np.uint8,
+}
+
+AUTORESET = {"disabled": 0, None: 0, "next_step": 1, "same_step": 2}
+
+
+class RwConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "num_envs", "grid_h", "grid_w", "n_agents", "sensor_range",
+        "request_queue_size", "max_inactivity_steps", "max_steps", "reward_type",
+        "normalised_coordinates", "autoreset_mode", "n_goals", "device_id",
+        "envs_per_workgroup", "threads_per_workgroup")] + [
+        ("highways", C.c_void_p), ("goals_xy", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class RwInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "num_envs", "grid_h", "grid_w", "n_agents", "request_queue_size", "n_shelves", "obs_length",
+        "envs_per_workgroup", "threads_per_workgroup", "n_workgroups", "lds_bytes", "device_id",
+        "compute_units")] + [
+        ("algorithmic_bytes_per_env_step", C.c_int64),
+        ("device_name", C.c_char * 128), ("arch_name", C.c_char * 64)]
+
+
+EXPORTS = (
+    "rw_create", "rw_destroy", "rw_last_error", "rw_reset", "rw_step", "rw_step_device",
+    "rw_step_many_device", "rw_refresh_obs", "rw_sync", "rw_get_buffer", "rw_read", "rw_write",
+    "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
+    "rw_abi_version",
+)
+
+_libs = {}
+
+
+def load(path: str | None = None):
+    """dlopen the engine library (default: the in-tree gfx950 build) and declare its prototypes."""
+    path = os.path.abspath(path or DEFAULT_LIBRARY)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C robotic-warehouse_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.rw_create.argtypes = [C.POINTER(RwConfig), C.POINTER(vp)]
+    lib.rw_destroy.argtypes = [vp]
+    lib.rw_last_error.argtypes = [vp]
+    lib.rw_last_error.restype = C.c_char_p
+    lib.rw_reset.argtypes = [vp, vp, vp]
+    lib.rw_step.argtypes = [vp, vp]
+    lib.rw_step_device.argtypes = [vp, vp]
+    lib.rw_step_many_device.argtypes = [vp, vp, i32, vp, vp, vp]
+    lib.rw_refresh_obs.argtypes = [vp]
+    lib.rw_sync.argtypes = [vp]
+    lib.rw_get_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.rw_read.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.rw_write.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.rw_recalc_grid.argtypes = [vp, vp, i32]
+    lib.rw_get_info.argtypes = [vp, C.POINTER(RwInfo)]
+    lib.rw_seed_state.argtypes = [C.c_uint64, vp]
+    lib.rw_event_record.argtypes = [vp, i32]
+    lib.rw_event_elapsed_ms.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
+    lib.rw_abi_version.argtypes = []
+    for name in EXPORTS:
+        if name != "rw_last_error":
+            getattr(lib, name).restype = C.c_int
+    if lib.rw_abi_version() != RW_ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {lib.rw_abi_version()} != {RW_ABI_VERSION}")
+    _libs[path] = lib
+    return lib
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rware engine error {code}: {msg}")
+        self.code = code
+
+
+class DeviceArray:
+    """Borrowed view of an engine buffer; exposes __cuda_array_interface__ so that
+    `torch.as_tensor(view, device='cuda')` wraps it without a copy (HIP memory on ROCm torch)."""
+
+    def __init__(self, ptr, shape, dtype, owner):
+        self.ptr, self.shape, self.dtype, self._owner = int(ptr), tuple(shape), np.dtype(dtype), owner
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 2, "strides": None}
+
+
+class Engine:
+    """One rw_engine: `num_envs` warehouses on one HIP device."""
+
+    def __init__(self, *, num_envs, layout, n_agents, sensor_range, request_queue_size,
+                 max_inactivity_steps, max_steps, reward_type, normalised_coordinates=False,
+                 autoreset_mode="next_step", device_id=0, envs_per_workgroup=0,
+                 threads_per_workgroup=0, stream=None, library=None):
+        self.lib = load(library)
+        self._h = C.c_void_p()
+        hw = np.ascontiguousarray(layout.highways, dtype=np.uint8)
+        goals = np.ascontiguousarray(np.asarray(layout.goals, dtype=np.int32).reshape(-1))
+        cfg = RwConfig(
+            RW_ABI_VERSION, int(num_envs), int(layout.grid_size[0]), int(layout.grid_size[1]), int(n_agents),
+            int(sensor_range), int(request_queue_size), int(max_inactivity_steps or 0), int(max_steps or 0),
+            int(reward_type), int(bool(normalised_coordinates)), AUTORESET[autoreset_mode], len(layout.goals),
+            int(device_id), int(envs_per_workgroup), int(threads_per_workgroup),
+            hw.ctypes.data, goals.ctypes.data, C.c_void_p(stream or 0))
+        rc = self.lib.rw_create(C.byref(cfg), C.byref(self._h))
+        if rc != RW_OK:
+            raise EngineError(rc, (self.lib.rw_last_error(None) or b"").decode())
+        self.info = RwInfo()
+        self._check(self.lib.rw_get_info(self._h, C.byref(self.info)))
+        i = self.info
+        self.B, self.N, self.Q, self.L, self.S = i.num_envs, i.n_agents, i.request_queue_size, i.obs_length, i.n_shelves
+        self.H, self.W = i.grid_h, i.grid_w
+        self.shapes = {
+            "obs": (self.B, self.N, self.L), "rewards": (self.B, self.N), "terminated": (self.B,),
+            "truncated": (self.B,), "grid": (self.B, 2, self.H, self.W), "agent_x": (self.B, self.N),
+            "agent_y": (self.B, self.N), "agent_dir": (self.B, self.N), "agent_carry": (self.B, self.N),
+            "agent_delivered": (self.B, self.N), "queue": (self.B, self.Q), "steps": (self.B,),
+            "inactive": (self.B,), "rng": (6, self.B), "need_reset": (self.B,), "actions": (self.B, self.N),
+        }
+
+    def _check(self, rc):
+        if rc != RW_OK:
+            msg = (self.lib.rw_last_error(self._h) or b"").decode()
+            if rc == RW_ERR_INVALID_ACTION:
+                raise ValueError(msg or "invalid action")
+            raise EngineError(rc, msg)
+
+    def close(self):
+        if self._h:
+            self.lib.rw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # hot path -----------------------------------------------------------------------------
+    def reset(self, seeds=None, mask=None):
+        s = None if seeds is None else np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).reshape(self.B))
+        m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8).reshape(self.B))
+        self._check(self.lib.rw_reset(self._h, None if s is None else s.ctypes.data, None if m is None else m.ctypes.data))
+
+    def step_host(self, actions_i32):
+        a = np.ascontiguousarray(actions_i32, dtype=np.int32)
+        assert a.size == self.B * self.N
+        self._check(self.lib.rw_step(self._h, a.ctypes.data))
+
+    def step_device(self, dev_ptr):
+        self._check(self.lib.rw_step_device(self._h, C.c_void_p(int(dev_ptr))))
+
+    def step_many_device(self, dev_ptr, n_steps, obs_tape=0, reward_tape=0, terminated_tape=0):
+        self._check(self.lib.rw_step_many_device(self._h, C.c_void_p(int(dev_ptr)), int(n_steps),
+                                                 C.c_void_p(int(obs_tape)), C.c_void_p(int(reward_tape)),
+                                                 C.c_void_p(int(terminated_tape))))
+
+    def refresh_obs(self):
+        self._check(self.lib.rw_refresh_obs(self._h))
+
+    def sync(self):
+        self._check(self.lib.rw_sync(self._h))
+
+    # buffers ------------------------------------------------------------------------------
+    def read(self, name) -> np.ndarray:
+        out = np.empty(self.shapes[name], dtype=BUF_DTYPE.get(name, np.int32))
+        self._check(self.lib.rw_read(self._h, BUF[name], out.ctypes.data, out.nbytes))
+        return out
+
+    def write(self, name, array):
+        a = np.ascontiguousarray(array, dtype=BUF_DTYPE.get(name, np.int32)).reshape(self.shapes[name])
+        self._check(self.lib.rw_write(self._h, BUF[name], a.ctypes.data, a.nbytes))
+
+    def device_array(self, name) -> DeviceArray:
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.rw_get_buffer(self._h, BUF[name], C.byref(ptr), C.byref(nbytes)))
+        return DeviceArray(ptr.value or 0, self.shapes[name], BUF_DTYPE.get(name, np.int32), self)
+
+    def recalc_grid(self, shelf_xy):
+        s = np.ascontiguousarray(shelf_xy, dtype=np.int32).reshape(self.B, -1, 2)
+        self._check(self.lib.rw_recalc_grid(self._h, s.ctypes.data, s.shape[1]))
+
+    def event_record(self, slot):
+        self._check(self.lib.rw_event_record(self._h, slot))
+
+    def event_elapsed_ms(self, a, b) -> float:
+        ms = C.c_float()
+        self._check(self.lib.rw_event_elapsed_ms(self._h, a, b, C.byref(ms)))
+        return float(ms.value)
+
+
+def seed_state(seed: int, library=None) -> np.ndarray:
+    out = np.zeros(6, dtype=np.uint64)
+    rc = load(library).rw_seed_state(C.c_uint64(int(seed)), out.ctypes.data)
+    assert rc == RW_OK
+    return out

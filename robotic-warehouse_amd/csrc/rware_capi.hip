@@ -1,0 +1,519 @@
+// rware_capi.hip — host side of the C-ABI declared in include/rware_hip.h.
+//
+// Owns the HBM-resident batched state of `num_envs` warehouses on one HIP device and
+// enqueues the fused step kernel (rware_kernels.h) on one stream.  No CPU fallback exists:
+// without a usable HIP device rw_create fails with RW_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rware_hip.h"
+#include "rware_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Buf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct rw_engine {
+    rw_config cfg{};
+    rw::Params prm{};
+    int S = 0, L = 0, OW = 0;
+    int E = 0, T = 0, n_wg = 0;
+    size_t lds_bytes = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Buf buf[RW_BUF_KIND_COUNT];
+    uint8_t *d_highways = nullptr;
+    int32_t *d_goal_cells = nullptr;
+    int32_t *d_shelf_init = nullptr;
+    uint8_t *d_mask = nullptr;
+    int32_t *d_status = nullptr;
+    hipEvent_t events[8]{};
+    std::vector<uint8_t> h_highways;
+    std::string err;
+    hipDeviceProp_t prop{};
+};
+
+namespace {
+
+int fail(rw_engine *eng, int code, const char *fmt, ...) {
+    char tmp[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tmp, sizeof tmp, fmt, ap);
+    va_end(ap);
+    if (eng) eng->err = tmp;
+    else g_create_error = tmp;
+    return code;
+}
+
+#define RW_HIP(eng, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(eng, RW_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+template <int R>
+void launch_r(rw_engine *eng, const rw::Params &p, int op) {
+    hipLaunchKernelGGL(rw::rware_step_kernel<R>, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
+                       eng->stream, p, op);
+}
+
+int launch(rw_engine *eng, const rw::Params &p, int op) {
+    switch (eng->cfg.sensor_range) {
+        case 1: launch_r<1>(eng, p, op); break;
+        case 2: launch_r<2>(eng, p, op); break;
+        case 3: launch_r<3>(eng, p, op); break;
+        case 4: launch_r<4>(eng, p, op); break;
+        case 5: launch_r<5>(eng, p, op); break;
+        default: return fail(eng, RW_ERR_UNSUPPORTED, "sensor_range %d not in 1..5", eng->cfg.sensor_range);
+    }
+    RW_HIP(eng, hipGetLastError());
+    return RW_OK;
+}
+
+template <int R>
+hipError_t raise_lds_limit(size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(rw::rware_step_kernel<R>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+size_t elem_size(int kind) {
+    switch (kind) {
+        case RW_BUF_OBS: case RW_BUF_REWARDS: return 4;
+        case RW_BUF_TERMINATED: case RW_BUF_TRUNCATED: case RW_BUF_NEED_RESET: return 1;
+        case RW_BUF_RNG: return 8;
+        default: return 4;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rw_abi_version(void) { return RW_ABI_VERSION; }
+
+const char *rw_last_error(const rw_engine *eng) { return eng ? eng->err.c_str() : g_create_error.c_str(); }
+
+int rw_seed_state(uint64_t seed, uint64_t out[6]) {
+    // numpy SeedSequence(entropy=seed).generate_state(4, uint64) -> PCG64(seed_seq) initial state.
+    // Replaces gymnasium.utils.seeding.np_random(seed), reached from Warehouse.reset(seed=...)
+    // (rware/warehouse.py:758-760).
+    if (!out) return RW_ERR_INVALID_ARG;
+    uint32_t ent[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    const int n_ent = ent[1] ? 2 : 1;
+    uint32_t pool[4], hc = 0x43b0d7e5u;
+    auto hashmix = [&hc](uint32_t v) {
+        v ^= hc;
+        hc *= 0x931e8875u;
+        v *= hc;
+        v ^= v >> 16;
+        return v;
+    };
+    auto mix = [](uint32_t x, uint32_t y) {
+        uint32_t r = 0xca01f9ddu * x - 0x4973f715u * y;
+        r ^= r >> 16;
+        return r;
+    };
+    for (int i = 0; i < 4; ++i) pool[i] = hashmix(i < n_ent ? ent[i] : 0u);
+    for (int s = 0; s < 4; ++s)
+        for (int d = 0; d < 4; ++d)
+            if (s != d) pool[d] = mix(pool[d], hashmix(pool[s]));
+    uint32_t w[8], hb = 0x8b51f9ddu;
+    for (int i = 0; i < 8; ++i) {
+        uint32_t v = pool[i & 3] ^ hb;
+        hb *= 0x58f38dedu;
+        v *= hb;
+        v ^= v >> 16;
+        w[i] = v;
+    }
+    uint64_t s64[4];
+    for (int i = 0; i < 4; ++i) s64[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    const rw::u128 initstate = (((rw::u128)s64[0]) << 64) | s64[1];
+    const rw::u128 initseq = (((rw::u128)s64[2]) << 64) | s64[3];
+    rw::u128 inc = (initseq << 1) | 1u, state = 0;
+    state = state * rw::pcg_mult() + inc;
+    state += initstate;
+    state = state * rw::pcg_mult() + inc;
+    out[0] = (uint64_t)(state >> 64);
+    out[1] = (uint64_t)state;
+    out[2] = (uint64_t)(inc >> 64);
+    out[3] = (uint64_t)inc;
+    out[4] = 0;
+    out[5] = 0;
+    return RW_OK;
+}
+
+int rw_create(const rw_config *cfg, rw_engine **out) {
+    if (!cfg || !out) return fail(nullptr, RW_ERR_INVALID_ARG, "null cfg/out");
+    *out = nullptr;
+    if (cfg->abi_version != RW_ABI_VERSION)
+        return fail(nullptr, RW_ERR_INVALID_ARG, "abi_version %d != %d", cfg->abi_version, RW_ABI_VERSION);
+    const int B = cfg->num_envs, H = cfg->grid_h, W = cfg->grid_w, N = cfg->n_agents, Q = cfg->request_queue_size;
+    if (B < 1 || H < 1 || W < 1 || N < 1 || N > 64 || Q < 0 || !cfg->highways || !cfg->goals_xy || cfg->n_goals < 1)
+        return fail(nullptr, RW_ERR_INVALID_ARG, "bad shape: B=%d H=%d W=%d N=%d Q=%d n_goals=%d", B, H, W, N, Q, cfg->n_goals);
+    if (cfg->sensor_range < 1 || cfg->sensor_range > 5)
+        return fail(nullptr, RW_ERR_UNSUPPORTED, "sensor_range %d not in 1..5", cfg->sensor_range);
+    if (cfg->reward_type < 0 || cfg->reward_type > 2 || cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2)
+        return fail(nullptr, RW_ERR_INVALID_ARG, "bad reward_type/autoreset_mode");
+    const int HW = H * W;
+    if (HW > 10000) return fail(nullptr, RW_ERR_UNSUPPORTED, "H*W > 10000 (numpy switches choice() algorithm)");
+    if (N > HW) return fail(nullptr, RW_ERR_INVALID_ARG, "more agents than cells");
+    int S = 0;
+    for (int i = 0; i < HW; ++i) S += cfg->highways[i] ? 0 : 1;
+    if (Q > S) return fail(nullptr, RW_ERR_INVALID_ARG, "request_queue_size %d > shelves %d", Q, S);
+    for (int g = 0; g < cfg->n_goals; ++g) {
+        const int x = cfg->goals_xy[2 * g], y = cfg->goals_xy[2 * g + 1];
+        if (x < 0 || x >= W || y < 0 || y >= H) return fail(nullptr, RW_ERR_INVALID_ARG, "goal %d out of the grid", g);
+    }
+
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1)
+        return fail(nullptr, RW_ERR_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
+    if (cfg->device_id < 0 || cfg->device_id >= n_dev)
+        return fail(nullptr, RW_ERR_INVALID_ARG, "device_id %d not in [0,%d)", cfg->device_id, n_dev);
+
+    rw_engine *eng = new (std::nothrow) rw_engine();
+    if (!eng) return fail(nullptr, RW_ERR_HIP, "out of host memory");
+    auto bail = [&](int code) {
+        g_create_error = eng->err;
+        rw_destroy(eng);
+        return code;
+    };
+#define RW_HIP_C(call)                                                              \
+    do {                                                                            \
+        hipError_t e_ = (call);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            fail(eng, RW_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
+            return bail(RW_ERR_HIP);                                                \
+        }                                                                           \
+    } while (0)
+
+    eng->cfg = *cfg;
+    eng->cfg.highways = nullptr;
+    eng->cfg.goals_xy = nullptr;
+    eng->h_highways.assign(cfg->highways, cfg->highways + HW);
+    eng->S = S;
+    const int R = cfg->sensor_range, CELLS = (2 * R + 1) * (2 * R + 1);
+    eng->L = 8 + 7 * CELLS;
+    eng->OW = (eng->L + 31) / 32;
+    const int SW = (S + 32) / 32;
+
+    RW_HIP_C(hipSetDevice(cfg->device_id));
+    RW_HIP_C(hipGetDeviceProperties(&eng->prop, cfg->device_id));
+    if (cfg->stream) {
+        eng->stream = (hipStream_t)cfg->stream;
+    } else {
+        RW_HIP_C(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
+        eng->own_stream = true;
+    }
+    for (auto &ev : eng->events) RW_HIP_C(hipEventCreate(&ev));
+
+    // workgroup geometry: E envs per workgroup (multiple of 4 keeps every chunk 16-byte aligned)
+    int E = cfg->envs_per_workgroup, T = cfg->threads_per_workgroup;
+    if (T == 0) T = 256;
+    if (T % 64 || T < 64 || T > 256) {
+        fail(eng, RW_ERR_INVALID_ARG, "threads_per_workgroup %d must be 64..256, multiple of 64", T);
+        return bail(RW_ERR_INVALID_ARG);
+    }
+    if (E == 0) {
+        const size_t per_env = sizeof(int32_t) * (size_t)rw::make_lds_layout(4, N, Q, HW, SW, eng->OW).total / 4;
+        E = (int)((32 * 1024) / per_env) & ~3;
+        if (E < 4) E = 4;
+        if (E > 32) E = 32;
+    }
+    if (E % 4 || E < 4) {
+        fail(eng, RW_ERR_INVALID_ARG, "envs_per_workgroup %d must be a positive multiple of 4", E);
+        return bail(RW_ERR_INVALID_ARG);
+    }
+    eng->E = E;
+    eng->T = T;
+    eng->n_wg = (B + E - 1) / E;
+    eng->lds_bytes = sizeof(int32_t) * (size_t)rw::make_lds_layout(E, N, Q, HW, SW, eng->OW).total;
+    if (eng->lds_bytes > 160 * 1024) {
+        fail(eng, RW_ERR_INVALID_ARG, "LDS footprint %zu B exceeds 160 KiB; lower envs_per_workgroup", eng->lds_bytes);
+        return bail(RW_ERR_INVALID_ARG);
+    }
+    if (eng->lds_bytes > 64 * 1024) {
+        hipError_t lds_err = hipSuccess;
+        switch (R) {
+            case 1: lds_err = raise_lds_limit<1>(eng->lds_bytes); break;
+            case 2: lds_err = raise_lds_limit<2>(eng->lds_bytes); break;
+            case 3: lds_err = raise_lds_limit<3>(eng->lds_bytes); break;
+            case 4: lds_err = raise_lds_limit<4>(eng->lds_bytes); break;
+            default: lds_err = raise_lds_limit<5>(eng->lds_bytes); break;
+        }
+        RW_HIP_C(lds_err);
+    }
+
+    // device buffers
+    const size_t szB = (size_t)B;
+    size_t n_elems[RW_BUF_KIND_COUNT];
+    n_elems[RW_BUF_OBS] = szB * N * eng->L;
+    n_elems[RW_BUF_REWARDS] = szB * N;
+    n_elems[RW_BUF_TERMINATED] = szB;
+    n_elems[RW_BUF_TRUNCATED] = szB;
+    n_elems[RW_BUF_GRID] = szB * 2 * HW;
+    for (int k = RW_BUF_AGENT_X; k <= RW_BUF_AGENT_DELIVERED; ++k) n_elems[k] = szB * N;
+    n_elems[RW_BUF_QUEUE] = szB * (Q > 0 ? Q : 0);
+    n_elems[RW_BUF_STEPS] = szB;
+    n_elems[RW_BUF_INACTIVE] = szB;
+    n_elems[RW_BUF_RNG] = szB * 6;
+    n_elems[RW_BUF_NEED_RESET] = szB;
+    n_elems[RW_BUF_ACTIONS] = szB * N;
+    for (int k = 0; k < RW_BUF_KIND_COUNT; ++k) {
+        eng->buf[k].bytes = n_elems[k] * elem_size(k);
+        const size_t alloc = eng->buf[k].bytes ? eng->buf[k].bytes : 16;
+        RW_HIP_C(hipMalloc(&eng->buf[k].ptr, alloc));
+        RW_HIP_C(hipMemsetAsync(eng->buf[k].ptr, 0, alloc, eng->stream));
+    }
+    RW_HIP_C(hipMalloc(&eng->d_highways, HW));
+    RW_HIP_C(hipMalloc(&eng->d_goal_cells, sizeof(int32_t) * cfg->n_goals));
+    RW_HIP_C(hipMalloc(&eng->d_shelf_init, sizeof(int32_t) * HW));
+    RW_HIP_C(hipMalloc(&eng->d_mask, szB));
+    RW_HIP_C(hipMalloc(&eng->d_status, sizeof(int32_t)));
+    std::vector<int32_t> goal_cells(cfg->n_goals), shelf_init(HW, 0);
+    for (int g = 0; g < cfg->n_goals; ++g) goal_cells[g] = cfg->goals_xy[2 * g + 1] * W + cfg->goals_xy[2 * g];
+    for (int i = 0, s = 0; i < HW; ++i)
+        if (!cfg->highways[i]) shelf_init[i] = ++s;  // ids 1..S, row-major (rware/warehouse.py:771-778)
+    RW_HIP_C(hipMemcpyAsync(eng->d_highways, cfg->highways, HW, hipMemcpyHostToDevice, eng->stream));
+    RW_HIP_C(hipMemcpyAsync(eng->d_goal_cells, goal_cells.data(), sizeof(int32_t) * cfg->n_goals, hipMemcpyHostToDevice, eng->stream));
+    RW_HIP_C(hipMemcpyAsync(eng->d_shelf_init, shelf_init.data(), sizeof(int32_t) * HW, hipMemcpyHostToDevice, eng->stream));
+    RW_HIP_C(hipMemsetAsync(eng->d_status, 0, sizeof(int32_t), eng->stream));
+    RW_HIP_C(hipStreamSynchronize(eng->stream));
+#undef RW_HIP_C
+
+    rw::Params &p = eng->prm;
+    p.B = B; p.H = H; p.W = W; p.HW = HW; p.N = N; p.Q = Q; p.S = S; p.SW = SW;
+    p.n_goals = cfg->n_goals;
+    p.max_inactivity = cfg->max_inactivity_steps;
+    p.max_steps = cfg->max_steps;
+    p.reward_type = cfg->reward_type;
+    p.autoreset = cfg->autoreset_mode;
+    p.normalised = cfg->normalised_coordinates ? 1 : 0;
+    p.envs_per_wg = E;
+    p.highways = eng->d_highways;
+    p.goal_cells = eng->d_goal_cells;
+    p.shelf_init = eng->d_shelf_init;
+    p.grid = (int32_t *)eng->buf[RW_BUF_GRID].ptr;
+    p.ax = (int32_t *)eng->buf[RW_BUF_AGENT_X].ptr;
+    p.ay = (int32_t *)eng->buf[RW_BUF_AGENT_Y].ptr;
+    p.adir = (int32_t *)eng->buf[RW_BUF_AGENT_DIR].ptr;
+    p.acarry = (int32_t *)eng->buf[RW_BUF_AGENT_CARRY].ptr;
+    p.adeliv = (int32_t *)eng->buf[RW_BUF_AGENT_DELIVERED].ptr;
+    p.queue = (int32_t *)eng->buf[RW_BUF_QUEUE].ptr;
+    p.steps = (int32_t *)eng->buf[RW_BUF_STEPS].ptr;
+    p.inactive = (int32_t *)eng->buf[RW_BUF_INACTIVE].ptr;
+    p.rng = (uint64_t *)eng->buf[RW_BUF_RNG].ptr;
+    p.need_reset = (uint8_t *)eng->buf[RW_BUF_NEED_RESET].ptr;
+    p.actions = (const int32_t *)eng->buf[RW_BUF_ACTIONS].ptr;
+    p.reset_mask = nullptr;
+    p.obs = (float *)eng->buf[RW_BUF_OBS].ptr;
+    p.rewards = (float *)eng->buf[RW_BUF_REWARDS].ptr;
+    p.terminated = (uint8_t *)eng->buf[RW_BUF_TERMINATED].ptr;
+    p.truncated = (uint8_t *)eng->buf[RW_BUF_TRUNCATED].ptr;
+    p.status = eng->d_status;
+    *out = eng;
+    return RW_OK;
+}
+
+int rw_destroy(rw_engine *eng) {
+    if (!eng) return RW_OK;
+    (void)hipSetDevice(eng->cfg.device_id);
+    if (eng->stream) (void)hipStreamSynchronize(eng->stream);
+    for (auto &b : eng->buf)
+        if (b.ptr) (void)hipFree(b.ptr);
+    if (eng->d_highways) (void)hipFree(eng->d_highways);
+    if (eng->d_goal_cells) (void)hipFree(eng->d_goal_cells);
+    if (eng->d_shelf_init) (void)hipFree(eng->d_shelf_init);
+    if (eng->d_mask) (void)hipFree(eng->d_mask);
+    if (eng->d_status) (void)hipFree(eng->d_status);
+    for (auto &ev : eng->events)
+        if (ev) (void)hipEventDestroy(ev);
+    if (eng->own_stream && eng->stream) (void)hipStreamDestroy(eng->stream);
+    delete eng;
+    return RW_OK;
+}
+
+int rw_reset(rw_engine *eng, const uint64_t *seeds, const uint8_t *mask) {
+    if (!eng) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    const int B = eng->prm.B;
+    if (seeds) {
+        // reseed masked envs: SeedSequence -> PCG64 on the host, merged into the field-major RNG buffer
+        std::vector<uint64_t> h((size_t)B * 6);
+        RW_HIP(eng, hipMemcpyAsync(h.data(), eng->buf[RW_BUF_RNG].ptr, h.size() * 8, hipMemcpyDeviceToHost, eng->stream));
+        RW_HIP(eng, hipStreamSynchronize(eng->stream));
+        for (int e = 0; e < B; ++e) {
+            if (mask && !mask[e]) continue;
+            uint64_t st[6];
+            rw_seed_state(seeds[e], st);
+            for (int f = 0; f < 6; ++f) h[(size_t)f * B + e] = st[f];
+        }
+        RW_HIP(eng, hipMemcpyAsync(eng->buf[RW_BUF_RNG].ptr, h.data(), h.size() * 8, hipMemcpyHostToDevice, eng->stream));
+        RW_HIP(eng, hipStreamSynchronize(eng->stream));
+    }
+    rw::Params p = eng->prm;
+    if (mask) {
+        RW_HIP(eng, hipMemcpyAsync(eng->d_mask, mask, (size_t)B, hipMemcpyHostToDevice, eng->stream));
+        RW_HIP(eng, hipStreamSynchronize(eng->stream));  // `mask` is caller-owned pageable memory
+        p.reset_mask = eng->d_mask;
+    }
+    return launch(eng, p, rw::OP_RESET);
+}
+
+int rw_step_device(rw_engine *eng, const int32_t *actions_dev) {
+    if (!eng || !actions_dev) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    rw::Params p = eng->prm;
+    p.actions = actions_dev;
+    return launch(eng, p, rw::OP_STEP);
+}
+
+int rw_step(rw_engine *eng, const int32_t *actions_host) {
+    if (!eng || !actions_host) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    RW_HIP(eng, hipMemcpyAsync(eng->buf[RW_BUF_ACTIONS].ptr, actions_host, eng->buf[RW_BUF_ACTIONS].bytes,
+                               hipMemcpyHostToDevice, eng->stream));
+    return launch(eng, eng->prm, rw::OP_STEP);
+}
+
+int rw_step_many_device(rw_engine *eng, const int32_t *actions_dev, int32_t n_steps, float *obs_tape,
+                        float *reward_tape, uint8_t *terminated_tape) {
+    if (!eng || !actions_dev || n_steps < 0) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    const size_t BN = (size_t)eng->prm.B * eng->prm.N;
+    for (int t = 0; t < n_steps; ++t) {
+        rw::Params p = eng->prm;
+        p.actions = actions_dev + (size_t)t * BN;
+        if (obs_tape) p.obs = obs_tape + (size_t)t * BN * eng->L;
+        if (reward_tape) p.rewards = reward_tape + (size_t)t * BN;
+        if (terminated_tape) p.terminated = terminated_tape + (size_t)t * eng->prm.B;
+        const int rc = launch(eng, p, rw::OP_STEP);
+        if (rc != RW_OK) return rc;
+    }
+    return RW_OK;
+}
+
+int rw_refresh_obs(rw_engine *eng) {
+    if (!eng) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    return launch(eng, eng->prm, rw::OP_OBS);
+}
+
+int rw_sync(rw_engine *eng) {
+    if (!eng) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    int32_t st = 0;
+    RW_HIP(eng, hipMemcpyAsync(&st, eng->d_status, sizeof st, hipMemcpyDeviceToHost, eng->stream));
+    RW_HIP(eng, hipStreamSynchronize(eng->stream));
+    if (st) {
+        RW_HIP(eng, hipMemsetAsync(eng->d_status, 0, sizeof st, eng->stream));
+        RW_HIP(eng, hipStreamSynchronize(eng->stream));
+        if (st & rw::STATUS_INVALID_ACTION)
+            return fail(eng, RW_ERR_INVALID_ACTION, "an action outside 0..4 was submitted (executed as NOOP)");
+    }
+    return RW_OK;
+}
+
+int rw_get_buffer(rw_engine *eng, int kind, void **dev_ptr, size_t *bytes) {
+    if (!eng || kind < 0 || kind >= RW_BUF_KIND_COUNT) return RW_ERR_INVALID_ARG;
+    if (dev_ptr) *dev_ptr = eng->buf[kind].ptr;
+    if (bytes) *bytes = eng->buf[kind].bytes;
+    return RW_OK;
+}
+
+int rw_read(rw_engine *eng, int kind, void *host_dst, size_t bytes) {
+    if (!eng || kind < 0 || kind >= RW_BUF_KIND_COUNT || (!host_dst && bytes)) return RW_ERR_INVALID_ARG;
+    if (bytes != eng->buf[kind].bytes)
+        return fail(eng, RW_ERR_INVALID_ARG, "rw_read kind %d: %zu bytes given, buffer holds %zu", kind, bytes, eng->buf[kind].bytes);
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    if (bytes) RW_HIP(eng, hipMemcpyAsync(host_dst, eng->buf[kind].ptr, bytes, hipMemcpyDeviceToHost, eng->stream));
+    RW_HIP(eng, hipStreamSynchronize(eng->stream));
+    return RW_OK;
+}
+
+int rw_write(rw_engine *eng, int kind, const void *host_src, size_t bytes) {
+    if (!eng || kind < 0 || kind >= RW_BUF_KIND_COUNT || (!host_src && bytes)) return RW_ERR_INVALID_ARG;
+    if (bytes != eng->buf[kind].bytes)
+        return fail(eng, RW_ERR_INVALID_ARG, "rw_write kind %d: %zu bytes given, buffer holds %zu", kind, bytes, eng->buf[kind].bytes);
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    if (bytes) RW_HIP(eng, hipMemcpyAsync(eng->buf[kind].ptr, host_src, bytes, hipMemcpyHostToDevice, eng->stream));
+    RW_HIP(eng, hipStreamSynchronize(eng->stream));
+    return RW_OK;
+}
+
+int rw_recalc_grid(rw_engine *eng, const int32_t *shelf_xy, int32_t n_shelves) {
+    // Host-side (state injection is a test/debug path, not the hot path): exactly _recalc_grid (:749-755).
+    if (!eng || !shelf_xy || n_shelves < 0) return RW_ERR_INVALID_ARG;
+    const int B = eng->prm.B, N = eng->prm.N, HW = eng->prm.HW, W = eng->prm.W, H = eng->prm.H;
+    std::vector<int32_t> ax((size_t)B * N), ay((size_t)B * N), grid((size_t)B * 2 * HW, 0);
+    int rc = rw_read(eng, RW_BUF_AGENT_X, ax.data(), ax.size() * 4);
+    if (rc) return rc;
+    rc = rw_read(eng, RW_BUF_AGENT_Y, ay.data(), ay.size() * 4);
+    if (rc) return rc;
+    for (int e = 0; e < B; ++e) {
+        int32_t *g = grid.data() + (size_t)e * 2 * HW;
+        const int32_t *sx = shelf_xy + (size_t)e * n_shelves * 2;
+        for (int k = 0; k < n_shelves; ++k) {
+            const int x = sx[2 * k], y = sx[2 * k + 1];
+            if (x < 0 || x >= W || y < 0 || y >= H) return fail(eng, RW_ERR_INVALID_ARG, "shelf %d of env %d outside the grid", k + 1, e);
+            g[HW + y * W + x] = k + 1;
+        }
+        for (int i = 0; i < N; ++i) {
+            const int x = ax[(size_t)e * N + i], y = ay[(size_t)e * N + i];
+            if (x < 0 || x >= W || y < 0 || y >= H) return fail(eng, RW_ERR_INVALID_ARG, "agent %d of env %d outside the grid", i + 1, e);
+            g[y * W + x] = i + 1;
+        }
+    }
+    return rw_write(eng, RW_BUF_GRID, grid.data(), grid.size() * 4);
+}
+
+int rw_get_info(const rw_engine *eng, rw_info *out) {
+    if (!eng || !out) return RW_ERR_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    const rw::Params &p = eng->prm;
+    out->num_envs = p.B; out->grid_h = p.H; out->grid_w = p.W; out->n_agents = p.N;
+    out->request_queue_size = p.Q; out->n_shelves = p.S; out->obs_length = eng->L;
+    out->envs_per_workgroup = eng->E; out->threads_per_workgroup = eng->T; out->n_workgroups = eng->n_wg;
+    out->lds_bytes = (int32_t)eng->lds_bytes;
+    out->device_id = eng->cfg.device_id;
+    out->compute_units = eng->prop.multiProcessorCount;
+    // A = 8HW + 4N + 40N + 4Q + 16 + 4NL + 4N + 4
+    out->algorithmic_bytes_per_env_step =
+        8LL * p.HW + 4LL * p.N + 40LL * p.N + 4LL * p.Q + 16 + 4LL * p.N * eng->L + 4LL * p.N + 4;
+    snprintf(out->device_name, sizeof out->device_name, "%s", eng->prop.name);
+    snprintf(out->arch_name, sizeof out->arch_name, "%s", eng->prop.gcnArchName);
+    return RW_OK;
+}
+
+int rw_event_record(rw_engine *eng, int32_t slot) {
+    if (!eng || slot < 0 || slot >= 8) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    RW_HIP(eng, hipEventRecord(eng->events[slot], eng->stream));
+    return RW_OK;
+}
+
+int rw_event_elapsed_ms(rw_engine *eng, int32_t a, int32_t b, float *ms) {
+    if (!eng || !ms || a < 0 || a >= 8 || b < 0 || b >= 8) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    RW_HIP(eng, hipEventSynchronize(eng->events[b]));
+    RW_HIP(eng, hipEventElapsedTime(ms, eng->events[a], eng->events[b]));
+    return RW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+"""Batched drop-in for `rware.warehouse.Warehouse` on the step path.
+
+`WarehouseVecEnv` takes the reference constructor's arguments (rware/warehouse.py:146-170)
+plus `num_envs`, and exposes the Gymnasium VectorEnv surface:
+
+    obs, info                                   = env.reset(seed=..., options=...)
+    obs, rewards, terminated, truncated, info   = env.step(actions)
+
+with obs float32 (B, N, L), rewards float32 (B, N), terminated/truncated bool (B,), info {}.
+`obs[:, i, :]` is agent i's FLATTENED observation, i.e. element i of the reference's obs tuple
+(:944); `terminated` is the reference's `done` (:935-941); `truncated` is always False (:942).
+
+All simulation runs in the HIP engine (csrc/); this file only marshals arguments.  There is
+no CPU path: constructing the env without the built library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import _capi
+from .enums import Action, ObservationType, RewardType, enum_value
+from .layout import Layout, layout_from_params, layout_from_str, obs_length
+
+try:  # gymnasium is optional (absent in the build image); subclass VectorEnv when present
+    import gymnasium as _gym
+    from gymnasium.vector import VectorEnv as _VectorEnvBase
+
+    if getattr(_gym, "IS_STANDIN", False):  # never treat the test stand-in as the real package
+        raise ImportError
+except Exception:  # pragma: no cover - exercised only where gymnasium is missing
+    _gym = None
+
+    class _VectorEnvBase:  # minimal duck-typed base
+        metadata = {}
+        closed = False
+
+
+STATE_FIELDS = ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry", "agent_delivered",
+                "queue", "steps", "inactive", "rng")
+
+
+class _Space:
+    """Shape/dtype descriptor used when gymnasium is not installed."""
+
+    def __init__(self, shape, dtype, n=None):
+        self.shape, self.dtype, self.n = tuple(shape), np.dtype(dtype), n
+
+    def __repr__(self):
+        return f"Space(shape={self.shape}, dtype={self.dtype}, n={self.n})"
+
+
+class WarehouseVecEnv(_VectorEnvBase):
+    metadata = {"render_modes": [], "autoreset_mode": "next_step"}
+
+    def __init__(self, num_envs: int, shelf_columns: int = 3, column_height: int = 8, shelf_rows: int = 1,
+                 n_agents: int = 2, msg_bits: int = 0, sensor_range: int = 1, request_queue_size: int = 2,
+                 max_inactivity_steps=None, max_steps=500, reward_type=RewardType.INDIVIDUAL,
+                 layout: str | None = None, observation_type=ObservationType.FLATTENED,
+                 image_observation_layers=None, image_observation_directional: bool = True,
+                 normalised_coordinates: bool = False, render_mode=None, *,
+                 autoreset_mode: str = "next_step", devices=None, output: str = "numpy",
+                 envs_per_workgroup: int = 0, threads_per_workgroup: int = 0, library: str | None = None):
+        if msg_bits != 0:
+            raise NotImplementedError("msg_bits > 0 is outside the accelerated path (every registered id uses 0)")
+        if enum_value(observation_type) != ObservationType.FLATTENED.value:
+            raise NotImplementedError("only ObservationType.FLATTENED (the reference default) is accelerated")
+        if output not in ("numpy", "torch"):
+            raise ValueError("output must be 'numpy' or 'torch'")
+        self.layout: Layout = layout_from_str(layout) if layout else layout_from_params(shelf_columns, shelf_rows, column_height)
+        self.num_envs = int(num_envs)
+        self.n_agents = int(n_agents)
+        self.msg_bits = 0
+        self.sensor_range = int(sensor_range)
+        self.request_queue_size = int(request_queue_size)
+        self.max_inactivity_steps = max_inactivity_steps
+        self.max_steps = max_steps
+        self.reward_type = RewardType(enum_value(reward_type))
+        self.normalised_coordinates = bool(normalised_coordinates)
+        self.grid_size = self.layout.grid_size
+        self.highways = self.layout.highways
+        self.goals = list(self.layout.goals)
+        self.autoreset_mode = autoreset_mode
+        self.metadata = dict(self.metadata, autoreset_mode=autoreset_mode)
+        self.output = output
+        self.obs_length = obs_length(self.sensor_range)
+        self._seeded = False
+        self.closed = False
+
+        devices = [0] if devices is None else list(devices)
+        if output == "torch" and len(devices) != 1:
+            raise ValueError("torch output is per-device: use one WarehouseVecEnv (one process) per GPU")
+        base, rem = divmod(self.num_envs, len(devices))
+        self._bounds, lo = [], 0
+        for d in range(len(devices)):
+            n = base + (1 if d < rem else 0)
+            self._bounds.append((lo, lo + n))
+            lo += n
+        self._torch = None
+        self.engines = []
+        for dev, (lo, hi) in zip(devices, self._bounds):
+            if hi == lo:
+                continue
+            stream = None
+            if output == "torch":
+                import torch
+
+                self._torch = torch
+                stream = torch.cuda.current_stream(dev).cuda_stream
+            self.engines.append(_capi.Engine(
+                num_envs=hi - lo, layout=self.layout, n_agents=self.n_agents, sensor_range=self.sensor_range,
+                request_queue_size=self.request_queue_size, max_inactivity_steps=max_inactivity_steps,
+                max_steps=max_steps, reward_type=self.reward_type.value,
+                normalised_coordinates=normalised_coordinates, autoreset_mode=autoreset_mode, device_id=dev,
+                envs_per_workgroup=envs_per_workgroup, threads_per_workgroup=threads_per_workgroup,
+                stream=stream, library=library))
+        self._bounds = [b for b in self._bounds if b[1] > b[0]]
+        self.devices = devices[: len(self.engines)]
+        self.n_shelves = self.engines[0].S
+        self._make_spaces()
+        self._tviews = None
+
+    # ------------------------------------------------------------------------------- spaces
+    def _make_spaces(self):
+        n, l, b = self.n_agents, self.obs_length, self.num_envs
+        if _gym is not None:
+            sp = _gym.spaces
+            sa_obs = sp.Box(low=-float("inf"), high=float("inf"), shape=(l,), dtype=np.float32)
+            self.single_observation_space = sp.Tuple(tuple(n * [sa_obs]))      # rware/warehouse.py:505-522
+            self.single_action_space = sp.Tuple(tuple(n * [sp.Discrete(len(Action))]))  # :255-260
+            self.observation_space = sp.Box(-float("inf"), float("inf"), shape=(b, n, l), dtype=np.float32)
+            self.action_space = sp.MultiDiscrete(np.full((b, n), len(Action)))
+        else:
+            self.single_observation_space = tuple(_Space((l,), np.float32) for _ in range(n))
+            self.single_action_space = tuple(_Space((), np.int64, n=len(Action)) for _ in range(n))
+            self.observation_space = _Space((b, n, l), np.float32)
+            self.action_space = _Space((b, n), np.int64, n=len(Action))
+
+    # ------------------------------------------------------------------------------- hot path
+    def reset(self, *, seed=None, options=None, mask=None):
+        """Warehouse.reset (:757-802) for every env (or those in `mask`).  `seed` int -> env i gets
+        seed + i (Gymnasium vector convention); a sequence gives per-env seeds; None continues each
+        env's own PCG64 stream (first ever reset: a fresh OS-entropy base seed)."""
+        seeds = None
+        if seed is None and not self._seeded:
+            seed = int.from_bytes(os.urandom(7), "little")
+        if seed is not None:
+            if np.isscalar(seed):
+                if int(seed) < 0:
+                    raise ValueError(f"Seed must be a non-negative integer, got {seed!r}")
+                seeds = (np.uint64(int(seed)) + np.arange(self.num_envs, dtype=np.uint64)).astype(np.uint64)
+            else:
+                seeds = np.asarray(seed, dtype=np.uint64).reshape(self.num_envs)
+            self._seeded = True
+        m = None if mask is None else np.asarray(mask).astype(np.uint8).reshape(self.num_envs)
+        for eng, (lo, hi) in zip(self.engines, self._bounds):
+            eng.reset(None if seeds is None else seeds[lo:hi], None if m is None else m[lo:hi])
+        return self._observations(), {}
+
+    def step(self, actions):
+        """Warehouse.step (:804-946) for every env; actions (B, N) ints in 0..4 or Action members."""
+        self.step_async(actions)
+        return self.step_wait()
+
+    def step_async(self, actions):
+        t = self._torch
+        if t is not None and isinstance(actions, t.Tensor) and actions.is_cuda:
+            if actions.dtype != t.int32 or not actions.is_contiguous() or actions.numel() != self.num_envs * self.n_agents:
+                raise ValueError("device actions must be a contiguous int32 tensor of B*N elements")
+            self._live_actions = actions  # keep alive until the step has run
+            self.engines[0].step_device(actions.data_ptr())
+            return
+        a = np.asarray(actions)
+        if a.dtype == object:
+            a = np.vectorize(enum_value, otypes=[np.int64])(a)
+        if a.size != self.num_envs * self.n_agents:
+            raise AssertionError(f"expected {self.num_envs}x{self.n_agents} actions, got shape {a.shape}")  # :807
+        a = a.reshape(self.num_envs, self.n_agents)
+        if a.size and (a.min() < 0 or a.max() > 4):
+            bad = a[(a < 0) | (a > 4)].flat[0]
+            raise ValueError(f"{bad} is not a valid Action")  # Action(action) at :814
+        a = a.astype(np.int32, copy=False)
+        for eng, (lo, hi) in zip(self.engines, self._bounds):
+            eng.step_host(a[lo:hi])
+
+    def step_wait(self):
+        if self.output == "torch":
+            v = self._torch_views()
+            return v["obs"], v["rewards"], v["terminated"].bool(), v["truncated"].bool(), {}
+        obs = self._observations()
+        rew = self._gather("rewards")
+        term = self._gather("terminated").astype(bool)
+        trunc = self._gather("truncated").astype(bool)
+        return obs, rew, term, trunc, {}
+
+    def sync(self):
+        """Wait for enqueued work; raises ValueError if a device-side action was out of range."""
+        for eng in self.engines:
+            eng.sync()
+
+    # ------------------------------------------------------------------------------- buffers
+    def _gather(self, name):
+        parts = [eng.read(name) for eng in self.engines]
+        return parts[0] if len(parts) == 1 else np.concatenate(parts, axis=1 if name == "rng" else 0)
+
+    def _observations(self):
+        if self.output == "torch":
+            return self._torch_views()["obs"]
+        return self._gather("obs")
+
+    def _torch_views(self):
+        if self._tviews is None:
+            t, eng, dev = self._torch, self.engines[0], self.devices[0]
+            self._tviews = {k: t.as_tensor(eng.device_array(k), device=f"cuda:{dev}")
+                            for k in ("obs", "rewards", "terminated", "truncated")}
+        return self._tviews
+
+    def device_tensor(self, name):
+        """Zero-copy torch view of any engine buffer (single-device envs)."""
+        import torch
+
+        return torch.as_tensor(self.engines[0].device_array(name), device=f"cuda:{self.devices[0]}")
+
+    # ------------------------------------------------------------------------------- state
+    def get_state(self) -> dict:
+        """Batched SoA state: grid (B,2,H,W), agent_* (B,N), queue (B,Q), steps/inactive (B,), rng (B,6)."""
+        out = {k: self._gather(k) for k in STATE_FIELDS}
+        out["rng"] = np.ascontiguousarray(out["rng"].T)
+        return out
+
+    def set_state(self, refresh_obs: bool = True, **fields):
+        for k, v in fields.items():
+            if k not in STATE_FIELDS and k != "need_reset":
+                raise KeyError(k)
+            v = np.asarray(v)
+            for eng, (lo, hi) in zip(self.engines, self._bounds):
+                eng.write(k, np.ascontiguousarray(v[lo:hi].T) if k == "rng" else v[lo:hi])
+        if refresh_obs:
+            for eng in self.engines:
+                eng.refresh_obs()
+
+    def shelf_xy(self) -> np.ndarray:
+        """(B, S, 2) (x, y) of every shelf id, read off the shelf layer (`env.shelfs[j].x/.y`)."""
+        grid = self._gather("grid")
+        out = np.zeros((self.num_envs, self.n_shelves, 2), np.int32)
+        e, ys, xs = np.nonzero(grid[:, 1])
+        ids = grid[e, 1, ys, xs]
+        out[e, ids - 1, 0] = xs
+        out[e, ids - 1, 1] = ys
+        return out
+
+    def recalc_grid(self, shelf_xy, refresh_obs: bool = True):
+        """Warehouse._recalc_grid (:749-755) from explicit shelf positions + current agent positions."""
+        s = np.asarray(shelf_xy, np.int32).reshape(self.num_envs, -1, 2)
+        for eng, (lo, hi) in zip(self.engines, self._bounds):
+            eng.recalc_grid(s[lo:hi])
+            if refresh_obs:
+                eng.refresh_obs()
+
+    def observations(self):
+        return self._observations()
+
+    def close(self, **kwargs):
+        for eng in self.engines:
+            eng.close()
+        self.engines = []
+        self.closed = True
+
+    def close_extras(self, **kwargs):
+        self.close()
