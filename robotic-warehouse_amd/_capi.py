@@ -57,6 +57,28 @@ EXPORTS = (
 _libs = {}
 
 
+def _preload_hip_runtime():
+    """Keep ONE HIP runtime in the process.  PyTorch-ROCm wheels bundle their own libamdhip64;
+    if that copy and /opt/rocm's are both initialised in one process the second one sees no GPUs
+    (and device pointers could not be shared zero-copy).  So when torch is installed, its bundled
+    runtime is loaded first and librware_hip.so (NEEDED libamdhip64.so.7) binds to it."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            return None
+    return None
+
+
 def load(path: str | None = None):
     """dlopen the engine library (default: the in-tree gfx950 build) and declare its prototypes."""
     path = os.path.abspath(path or DEFAULT_LIBRARY)
@@ -66,6 +88,7 @@ def load(path: str | None = None):
         raise RuntimeError(
             f"{path} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (or `make -C robotic-warehouse_amd/csrc`). There is no CPU fallback.")
+    _preload_hip_runtime()
     lib = C.CDLL(path)
     vp, i32 = C.c_void_p, C.c_int32
     lib.rw_create.argtypes = [C.POINTER(RwConfig), C.POINTER(vp)]

@@ -1,0 +1,152 @@
+"""Parity tests proper: the HIP engine on a real MI355X, called through the C-ABI
+(include/rware_hip.h via robotic-warehouse_amd/_capi.py), against
+  (1) the golden vectors produced by the unmodified reference, and
+  (2) the CPU oracle on the same seeded inputs at larger batches,
+bit-exact on every field (grid, agent SoA, queue, counters, PCG64 state, obs, rewards, done)."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from engine_backend import EngineBackend
+from rware_oracle import OracleVecEnv
+
+import rware_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def _loaded_native():
+    from rware_amd import _capi
+    return _capi.load()._name
+
+
+@pytest.mark.parametrize("name", gu.fixture_names())
+def test_engine_matches_reference_golden(name):
+    meta, z = gu.load_fixture(name)
+    be = EngineBackend(meta["E"], **gu.ctor_kwargs(meta))
+    assert be.env.engines[0].info.arch_name.decode().startswith("gfx"), "not running on the HIP device"
+    assert gu.replay(be, meta, z) == meta["T"]
+    be.env.close()
+
+
+CASES = [
+    # id, extra kwargs, B, T, geometry (envs/wg, threads/wg)
+    ("rware-tiny-2ag-v1", {}, 4096, 560, (0, 0)),
+    ("rware-small-4ag-v1", {}, 2048, 560, (0, 0)),
+    ("rware-small-4ag-v1", {}, 1023, 120, (8, 64)),      # ragged batch: last workgroup is partial
+    ("rware-medium-6ag-hard-v1", {}, 1024, 300, (0, 0)),
+    ("rware-large-16ag-v1", {"sensor_range": 2}, 512, 200, (0, 0)),
+    ("rware-small-19ag-v1", {"reward_type": 0, "max_inactivity_steps": 50}, 256, 200, (4, 128)),
+    ("rware-tiny-4ag-easy-v1", {"reward_type": 2, "max_steps": 60}, 512, 200, (16, 256)),
+]
+
+
+@pytest.mark.parametrize("env_id,extra,B,T,geom", CASES)
+@pytest.mark.parametrize("mode", ["next_step", "same_step"])
+def test_engine_matches_oracle_large_batch(env_id, extra, B, T, geom, mode):
+    kw = rware_amd.env_kwargs(env_id)
+    kw.update(extra)
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    env = rware_amd.WarehouseVecEnv(B, autoreset_mode=mode, envs_per_workgroup=geom[0],
+                                    threads_per_workgroup=geom[1], **kw)
+    orc = OracleVecEnv(B, **kw)
+    seed = 31337
+    obs, _ = env.reset(seed=seed)
+    assert np.array_equal(obs, orc.reset(seed=seed))
+    rng = np.random.default_rng(5)
+    N = kw["n_agents"]
+    for t in range(T):
+        p = [0.2] * 5 if (t // 50) % 2 == 0 else [0.1, 0.6, 0.1, 0.1, 0.1]
+        a = rng.choice(5, size=(B, N), p=p).astype(np.int32)
+        obs, rew, term, trunc, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, mode)
+        assert np.array_equal(rew, r2), f"rewards t={t}"
+        assert np.array_equal(term, d2.astype(bool)), f"done t={t}"
+        assert np.array_equal(obs, o2), f"obs t={t}"
+        if t % 25 == 0 or t == T - 1:
+            st, so = env.get_state(), orc.get_state()
+            for k in so:
+                assert np.array_equal(st[k], so[k]), f"{k} t={t}"
+    env.close()
+
+
+def test_invalid_action_is_reported():
+    env = rware_amd.make_vec("rware-tiny-2ag-v1", 8)
+    env.reset(seed=0)
+    with pytest.raises(ValueError):
+        env.step(np.full((8, 2), 7))
+    import torch
+    tenv = rware_amd.make_vec("rware-tiny-2ag-v1", 8, output="torch")
+    tenv.reset(seed=0)
+    bad = torch.full((8, 2), 9, dtype=torch.int32, device="cuda")
+    tenv.step(bad)
+    with pytest.raises(ValueError):
+        tenv.sync()
+    tenv.close()
+    env.close()
+
+
+def test_torch_zero_copy_views_and_device_actions():
+    import torch
+    B = 256
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    tenv = rware_amd.WarehouseVecEnv(B, output="torch", **kw)
+    nenv = rware_amd.WarehouseVecEnv(B, **kw)
+    o_t, _ = tenv.reset(seed=9)
+    o_n, _ = nenv.reset(seed=9)
+    assert o_t.is_cuda and o_t.shape == (B, 4, 71) and o_t.dtype == torch.float32
+    assert np.array_equal(o_t.cpu().numpy(), o_n)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for _ in range(30):
+        a = torch.randint(0, 5, (B, 4), generator=g, dtype=torch.int32)
+        ot, rt, tt, _, _ = tenv.step(a.cuda())
+        on, rn, tn, _, _ = nenv.step(a.numpy())
+        tenv.sync()
+        assert np.array_equal(ot.cpu().numpy(), on) and np.array_equal(rt.cpu().numpy(), rn)
+        assert np.array_equal(tt.cpu().numpy(), tn)
+    assert ot.data_ptr() == tenv.device_tensor("obs").data_ptr()
+    tenv.close(); nenv.close()
+
+
+def test_full_size_headline_batch_properties():
+    """BASELINE config 3 at full size (small-4ag, B=16384): size-independent invariants + an
+    oracle spot-check of a strided subset of envs."""
+    B, N = 16384, 4
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    env = rware_amd.WarehouseVecEnv(B, **kw)
+    env.reset(seed=0)
+    rng = np.random.default_rng(12345)
+    S = env.n_shelves
+    acts = []
+    for t in range(520):
+        a = rng.integers(0, 5, size=(B, N), dtype=np.int32)
+        acts.append(a)
+        obs, rew, term, trunc, _ = env.step(a)
+        assert term.all() == (t == 499) and term.any() == (t == 499)   # max_steps=500, all at once
+    st = env.get_state()
+    g = st["grid"]
+    assert ((g[:, 0] > 0).sum(axis=(1, 2)) == N).all()                 # one cell per agent
+    assert ((g[:, 1] > 0).sum(axis=(1, 2)) == S).all()                 # shelves are conserved
+    ids = np.sort(g[:, 1].reshape(B, -1), axis=1)[:, -S:]
+    assert (ids == np.arange(1, S + 1)).all()                          # each shelf id exactly once
+    e = np.arange(B)[:, None]
+    assert (g[e, 0, st["agent_y"], st["agent_x"]] == np.arange(1, N + 1)).all()
+    carry = st["agent_carry"]
+    assert ((carry == 0) | (g[e, 1, st["agent_y"], st["agent_x"]] == carry)).all()  # carried shelf under carrier
+    q = np.sort(st["queue"], axis=1)
+    assert (np.diff(q, axis=1) > 0).all() and q.min() >= 1 and q.max() <= S        # distinct requests
+    assert (st["steps"] == 19).all()                                    # 520 steps = 500 + reset + 19
+    sub = np.arange(0, B, 257)
+    orc = OracleVecEnv(len(sub), **dict(kw, reward_type=kw["reward_type"].value))
+    orc.seed(0)
+    for i, e_ in enumerate(sub):
+        from rware_oracle import seed_state
+        orc.rng[i] = seed_state(int(e_))
+    orc.reset()
+    for a in acts:
+        o2, _, _ = orc.step_autoreset(a[sub], "next_step")
+    assert np.array_equal(obs[sub], o2)
+    so = orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k][sub], so[k]), k
+    env.close()
