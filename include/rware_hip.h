@@ -175,6 +175,12 @@ int rw_seed_state(uint64_t seed, uint64_t out[6]);
 int rw_event_record(rw_engine *eng, int32_t slot /* 0..7 */);
 int rw_event_elapsed_ms(rw_engine *eng, int32_t slot_begin, int32_t slot_end, float *ms);
 
+/* profiling aid: runs ONE step (device actions) with per-workgroup phase stamps taken from the
+ * 100 MHz wall clock; host_out receives uint64 [n_workgroups][n_marks].  Call with host_out ==
+ * NULL to query the two sizes first. */
+int rw_debug_timeline(rw_engine *eng, const int32_t *actions_dev, uint64_t *host_out,
+                      int32_t *n_workgroups, int32_t *n_marks);
+
 int rw_abi_version(void);
 
 #ifdef __cplusplus

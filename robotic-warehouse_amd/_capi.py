@@ -51,7 +51,7 @@ EXPORTS = (
     "rw_create", "rw_destroy", "rw_last_error", "rw_reset", "rw_step", "rw_step_device",
     "rw_step_many_device", "rw_refresh_obs", "rw_sync", "rw_get_buffer", "rw_read", "rw_write",
     "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
-    "rw_abi_version",
+    "rw_abi_version", "rw_debug_timeline",
 )
 
 _libs = {}
@@ -110,6 +110,7 @@ def load(path: str | None = None):
     lib.rw_event_record.argtypes = [vp, i32]
     lib.rw_event_elapsed_ms.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
     lib.rw_abi_version.argtypes = []
+    lib.rw_debug_timeline.argtypes = [vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     for name in EXPORTS:
         if name != "rw_last_error":
             getattr(lib, name).restype = C.c_int
@@ -231,6 +232,14 @@ class Engine:
     def recalc_grid(self, shelf_xy):
         s = np.ascontiguousarray(shelf_xy, dtype=np.int32).reshape(self.B, -1, 2)
         self._check(self.lib.rw_recalc_grid(self._h, s.ctypes.data, s.shape[1]))
+
+    def debug_timeline(self, actions_dev_ptr) -> np.ndarray:
+        """uint64 [n_workgroups, n_marks] phase stamps (10 ns ticks) of one step; profiling aid."""
+        nwg, nm = C.c_int32(), C.c_int32()
+        self._check(self.lib.rw_debug_timeline(self._h, C.c_void_p(int(actions_dev_ptr)), None, C.byref(nwg), C.byref(nm)))
+        out = np.zeros((nwg.value, nm.value), dtype=np.uint64)
+        self._check(self.lib.rw_debug_timeline(self._h, C.c_void_p(int(actions_dev_ptr)), out.ctypes.data, None, None))
+        return out
 
     def event_record(self, slot):
         self._check(self.lib.rw_event_record(self._h, slot))

@@ -35,10 +35,13 @@ struct rw_engine {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     Buf buf[RW_BUF_KIND_COUNT];
-    uint8_t *d_highways = nullptr;
-    int32_t *d_goal_cells = nullptr;
+    uint32_t *d_highway_bits = nullptr;
     int32_t *d_shelf_init = nullptr;
     uint8_t *d_mask = nullptr;
+    void *slab = nullptr;      // the single device allocation behind every buffer below
+    size_t shadow_off = 0;
+    void *d_shadow = nullptr;  // compact shelf layer (uint8 when S <= 255, else uint16), the kernel's read path
+    bool wide = false;
     int32_t *d_status = nullptr;
     hipEvent_t events[8]{};
     std::vector<uint8_t> h_highways;
@@ -67,10 +70,15 @@ int fail(rw_engine *eng, int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
+template <int R, typename CellT>
+void launch_rc(rw_engine *eng, const rw::Params &p, int op) {
+    hipLaunchKernelGGL((rw::rware_step_kernel<R, CellT>), dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
+                       eng->stream, p, op);
+}
 template <int R>
 void launch_r(rw_engine *eng, const rw::Params &p, int op) {
-    hipLaunchKernelGGL(rw::rware_step_kernel<R>, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
-                       eng->stream, p, op);
+    if (eng->wide) launch_rc<R, uint16_t>(eng, p, op);
+    else launch_rc<R, uint8_t>(eng, p, op);
 }
 
 int launch(rw_engine *eng, const rw::Params &p, int op) {
@@ -86,10 +94,29 @@ int launch(rw_engine *eng, const rw::Params &p, int op) {
     return RW_OK;
 }
 
-template <int R>
-hipError_t raise_lds_limit(size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(rw::rware_step_kernel<R>),
+// the shelf shadow mirrors layer 1 of RW_BUF_GRID; rebuilt after any host write of the grid
+int rebuild_shadow(rw_engine *eng) {
+    const int B = eng->prm.B, HW = eng->prm.HW;
+    const size_t n = (size_t)B * HW;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    if (eng->wide)
+        hipLaunchKernelGGL((rw::rware_shadow_kernel<uint16_t>), dim3(blocks), dim3(256), 0, eng->stream,
+                           (const int32_t *)eng->buf[RW_BUF_GRID].ptr, (uint16_t *)eng->d_shadow, B, HW);
+    else
+        hipLaunchKernelGGL((rw::rware_shadow_kernel<uint8_t>), dim3(blocks), dim3(256), 0, eng->stream,
+                           (const int32_t *)eng->buf[RW_BUF_GRID].ptr, (uint8_t *)eng->d_shadow, B, HW);
+    RW_HIP(eng, hipGetLastError());
+    return RW_OK;
+}
+
+template <int R, typename CellT>
+hipError_t raise_lds_limit_rc(size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(rw::rware_step_kernel<R, CellT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+template <int R>
+hipError_t raise_lds_limit(size_t bytes, bool wide) {
+    return wide ? raise_lds_limit_rc<R, uint16_t>(bytes) : raise_lds_limit_rc<R, uint8_t>(bytes);
 }
 
 size_t elem_size(int kind) {
@@ -176,6 +203,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     int S = 0;
     for (int i = 0; i < HW; ++i) S += cfg->highways[i] ? 0 : 1;
     if (Q > S) return fail(nullptr, RW_ERR_INVALID_ARG, "request_queue_size %d > shelves %d", Q, S);
+    if (cfg->n_goals > rw::MAX_GOALS) return fail(nullptr, RW_ERR_UNSUPPORTED, "more than %d goal cells", (int)rw::MAX_GOALS);
     for (int g = 0; g < cfg->n_goals; ++g) {
         const int x = cfg->goals_xy[2 * g], y = cfg->goals_xy[2 * g + 1];
         if (x < 0 || x >= W || y < 0 || y >= H) return fail(nullptr, RW_ERR_INVALID_ARG, "goal %d out of the grid", g);
@@ -208,6 +236,8 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     eng->cfg.goals_xy = nullptr;
     eng->h_highways.assign(cfg->highways, cfg->highways + HW);
     eng->S = S;
+    eng->wide = S > 255;
+    const int cell_bytes = eng->wide ? 2 : 1;
     const int R = cfg->sensor_range, CELLS = (2 * R + 1) * (2 * R + 1);
     eng->L = 8 + 7 * CELLS;
     eng->OW = (eng->L + 31) / 32;
@@ -231,19 +261,26 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         return bail(RW_ERR_INVALID_ARG);
     }
     if (E == 0) {
-        const size_t per_env = sizeof(int32_t) * (size_t)rw::make_lds_layout(4, N, Q, HW, SW, eng->OW).total / 4;
+        const size_t per_env = sizeof(int32_t) * (size_t)rw::make_lds_layout(4, N, Q, HW, SW, eng->OW, cell_bytes).total / 4;
         E = (int)((32 * 1024) / per_env) & ~3;
         if (E < 4) E = 4;
-        if (E > 32) E = 32;
+        if (E > 16) E = 16;  // measured best on MI355X for the registered configs (profiles/)
     }
     if (E % 4 || E < 4) {
         fail(eng, RW_ERR_INVALID_ARG, "envs_per_workgroup %d must be a positive multiple of 4", E);
         return bail(RW_ERR_INVALID_ARG);
     }
+    {
+        // x / N == (x * ceil(2^18 / N)) >> 18 needs x * N < 2^18 for every x < E * N
+        if ((long long)E * N * N >= (1 << 18)) {
+            fail(eng, RW_ERR_INVALID_ARG, "envs_per_workgroup %d too large for N=%d Q=%d", E, N, Q);
+            return bail(RW_ERR_INVALID_ARG);
+        }
+    }
     eng->E = E;
     eng->T = T;
     eng->n_wg = (B + E - 1) / E;
-    eng->lds_bytes = sizeof(int32_t) * (size_t)rw::make_lds_layout(E, N, Q, HW, SW, eng->OW).total;
+    eng->lds_bytes = sizeof(int32_t) * (size_t)rw::make_lds_layout(E, N, Q, HW, SW, eng->OW, cell_bytes).total;
     if (eng->lds_bytes > 160 * 1024) {
         fail(eng, RW_ERR_INVALID_ARG, "LDS footprint %zu B exceeds 160 KiB; lower envs_per_workgroup", eng->lds_bytes);
         return bail(RW_ERR_INVALID_ARG);
@@ -251,11 +288,11 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     if (eng->lds_bytes > 64 * 1024) {
         hipError_t lds_err = hipSuccess;
         switch (R) {
-            case 1: lds_err = raise_lds_limit<1>(eng->lds_bytes); break;
-            case 2: lds_err = raise_lds_limit<2>(eng->lds_bytes); break;
-            case 3: lds_err = raise_lds_limit<3>(eng->lds_bytes); break;
-            case 4: lds_err = raise_lds_limit<4>(eng->lds_bytes); break;
-            default: lds_err = raise_lds_limit<5>(eng->lds_bytes); break;
+            case 1: lds_err = raise_lds_limit<1>(eng->lds_bytes, eng->wide); break;
+            case 2: lds_err = raise_lds_limit<2>(eng->lds_bytes, eng->wide); break;
+            case 3: lds_err = raise_lds_limit<3>(eng->lds_bytes, eng->wide); break;
+            case 4: lds_err = raise_lds_limit<4>(eng->lds_bytes, eng->wide); break;
+            default: lds_err = raise_lds_limit<5>(eng->lds_bytes, eng->wide); break;
         }
         RW_HIP_C(lds_err);
     }
@@ -275,23 +312,40 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     n_elems[RW_BUF_RNG] = szB * 6;
     n_elems[RW_BUF_NEED_RESET] = szB;
     n_elems[RW_BUF_ACTIONS] = szB * N;
-    for (int k = 0; k < RW_BUF_KIND_COUNT; ++k) {
+    // One slab for every buffer: the per-step working set (agent SoA, queue, counters, flags, rewards,
+    // shelf shadow) sits in a few contiguous MiB, so a workgroup's ~15 streams share TLB entries
+    // instead of touching 15 separate allocations.  Order = hot and small first.
+    static const int order[RW_BUF_KIND_COUNT] = {
+        RW_BUF_AGENT_X, RW_BUF_AGENT_Y, RW_BUF_AGENT_DIR, RW_BUF_AGENT_CARRY, RW_BUF_AGENT_DELIVERED, RW_BUF_QUEUE,
+        RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_NEED_RESET, RW_BUF_REWARDS, RW_BUF_TERMINATED, RW_BUF_TRUNCATED,
+        RW_BUF_ACTIONS, RW_BUF_RNG, RW_BUF_OBS, RW_BUF_GRID};
+    auto up = [](size_t x) { return (x + 4095) & ~(size_t)4095; };
+    size_t slab_bytes = 0, off[RW_BUF_KIND_COUNT];
+    for (int k : order) {
         eng->buf[k].bytes = n_elems[k] * elem_size(k);
-        const size_t alloc = eng->buf[k].bytes ? eng->buf[k].bytes : 16;
-        RW_HIP_C(hipMalloc(&eng->buf[k].ptr, alloc));
-        RW_HIP_C(hipMemsetAsync(eng->buf[k].ptr, 0, alloc, eng->stream));
+        off[k] = slab_bytes;
+        slab_bytes += up(eng->buf[k].bytes ? eng->buf[k].bytes : 16);
+        if (k == RW_BUF_ACTIONS) {  // the shelf shadow rides with the hot set
+            eng->shadow_off = slab_bytes;
+            slab_bytes += up(szB * HW * cell_bytes + 16);
+        }
     }
-    RW_HIP_C(hipMalloc(&eng->d_highways, HW));
-    RW_HIP_C(hipMalloc(&eng->d_goal_cells, sizeof(int32_t) * cfg->n_goals));
+    RW_HIP_C(hipMalloc(&eng->slab, slab_bytes));
+    RW_HIP_C(hipMemsetAsync(eng->slab, 0, slab_bytes, eng->stream));
+    for (int k = 0; k < RW_BUF_KIND_COUNT; ++k) eng->buf[k].ptr = (char *)eng->slab + off[k];
+    eng->d_shadow = (char *)eng->slab + eng->shadow_off;
+    const int HWW = (HW + 31) / 32;
+    RW_HIP_C(hipMalloc(&eng->d_highway_bits, sizeof(uint32_t) * HWW));
     RW_HIP_C(hipMalloc(&eng->d_shelf_init, sizeof(int32_t) * HW));
     RW_HIP_C(hipMalloc(&eng->d_mask, szB));
     RW_HIP_C(hipMalloc(&eng->d_status, sizeof(int32_t)));
-    std::vector<int32_t> goal_cells(cfg->n_goals), shelf_init(HW, 0);
-    for (int g = 0; g < cfg->n_goals; ++g) goal_cells[g] = cfg->goals_xy[2 * g + 1] * W + cfg->goals_xy[2 * g];
+    std::vector<int32_t> shelf_init(HW, 0);
+    std::vector<uint32_t> hw_bits(HWW, 0u);
+    for (int i = 0; i < HW; ++i)
+        if (cfg->highways[i]) hw_bits[i >> 5] |= 1u << (i & 31);
     for (int i = 0, s = 0; i < HW; ++i)
         if (!cfg->highways[i]) shelf_init[i] = ++s;  // ids 1..S, row-major (rware/warehouse.py:771-778)
-    RW_HIP_C(hipMemcpyAsync(eng->d_highways, cfg->highways, HW, hipMemcpyHostToDevice, eng->stream));
-    RW_HIP_C(hipMemcpyAsync(eng->d_goal_cells, goal_cells.data(), sizeof(int32_t) * cfg->n_goals, hipMemcpyHostToDevice, eng->stream));
+    RW_HIP_C(hipMemcpyAsync(eng->d_highway_bits, hw_bits.data(), sizeof(uint32_t) * HWW, hipMemcpyHostToDevice, eng->stream));
     RW_HIP_C(hipMemcpyAsync(eng->d_shelf_init, shelf_init.data(), sizeof(int32_t) * HW, hipMemcpyHostToDevice, eng->stream));
     RW_HIP_C(hipMemsetAsync(eng->d_status, 0, sizeof(int32_t), eng->stream));
     RW_HIP_C(hipStreamSynchronize(eng->stream));
@@ -306,8 +360,12 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.autoreset = cfg->autoreset_mode;
     p.normalised = cfg->normalised_coordinates ? 1 : 0;
     p.envs_per_wg = E;
-    p.highways = eng->d_highways;
-    p.goal_cells = eng->d_goal_cells;
+    p.magic_n = rw::rw_magic18(N);
+    p.groups_per_wave = 64 / N;
+    p.HWW = HWW;
+    for (int g = 0; g < rw::MAX_GOALS; ++g)
+        p.goal_cells[g] = g < cfg->n_goals ? cfg->goals_xy[2 * g + 1] * W + cfg->goals_xy[2 * g] : 0;
+    p.highway_bits = eng->d_highway_bits;
     p.shelf_init = eng->d_shelf_init;
     p.grid = (int32_t *)eng->buf[RW_BUF_GRID].ptr;
     p.ax = (int32_t *)eng->buf[RW_BUF_AGENT_X].ptr;
@@ -318,6 +376,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.queue = (int32_t *)eng->buf[RW_BUF_QUEUE].ptr;
     p.steps = (int32_t *)eng->buf[RW_BUF_STEPS].ptr;
     p.inactive = (int32_t *)eng->buf[RW_BUF_INACTIVE].ptr;
+    p.shelf_shadow = eng->d_shadow;
     p.rng = (uint64_t *)eng->buf[RW_BUF_RNG].ptr;
     p.need_reset = (uint8_t *)eng->buf[RW_BUF_NEED_RESET].ptr;
     p.actions = (const int32_t *)eng->buf[RW_BUF_ACTIONS].ptr;
@@ -327,6 +386,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.terminated = (uint8_t *)eng->buf[RW_BUF_TERMINATED].ptr;
     p.truncated = (uint8_t *)eng->buf[RW_BUF_TRUNCATED].ptr;
     p.status = eng->d_status;
+    p.timeline = nullptr;
     *out = eng;
     return RW_OK;
 }
@@ -335,10 +395,8 @@ int rw_destroy(rw_engine *eng) {
     if (!eng) return RW_OK;
     (void)hipSetDevice(eng->cfg.device_id);
     if (eng->stream) (void)hipStreamSynchronize(eng->stream);
-    for (auto &b : eng->buf)
-        if (b.ptr) (void)hipFree(b.ptr);
-    if (eng->d_highways) (void)hipFree(eng->d_highways);
-    if (eng->d_goal_cells) (void)hipFree(eng->d_goal_cells);
+    if (eng->slab) (void)hipFree(eng->slab);
+    if (eng->d_highway_bits) (void)hipFree(eng->d_highway_bits);
     if (eng->d_shelf_init) (void)hipFree(eng->d_shelf_init);
     if (eng->d_mask) (void)hipFree(eng->d_mask);
     if (eng->d_status) (void)hipFree(eng->d_status);
@@ -409,6 +467,30 @@ int rw_step_many_device(rw_engine *eng, const int32_t *actions_dev, int32_t n_st
     return RW_OK;
 }
 
+int rw_debug_timeline(rw_engine *eng, const int32_t *actions_dev, uint64_t *host_out, int32_t *n_workgroups, int32_t *n_marks) {
+    // One OP_STEP launch with per-workgroup phase stamps (wall_clock64, 100 MHz); profiling aid only.
+    if (!eng || !actions_dev) return RW_ERR_INVALID_ARG;
+    if (n_workgroups) *n_workgroups = eng->n_wg;
+    if (n_marks) *n_marks = rw::TL_MARKS;
+    if (!host_out) return RW_OK;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    const size_t bytes = sizeof(uint64_t) * (size_t)eng->n_wg * rw::TL_MARKS;
+    uint64_t *d = nullptr;
+    RW_HIP(eng, hipMalloc(&d, bytes));
+    RW_HIP(eng, hipMemsetAsync(d, 0, bytes, eng->stream));
+    rw::Params p = eng->prm;
+    p.actions = actions_dev;
+    p.timeline = d;
+    int rc = launch(eng, p, rw::OP_STEP);
+    if (rc == RW_OK) {
+        hipError_t e1 = hipMemcpyAsync(host_out, d, bytes, hipMemcpyDeviceToHost, eng->stream);
+        hipError_t e2 = hipStreamSynchronize(eng->stream);
+        if (e1 != hipSuccess || e2 != hipSuccess) rc = fail(eng, RW_ERR_HIP, "timeline copy failed");
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 int rw_refresh_obs(rw_engine *eng) {
     if (!eng) return RW_ERR_INVALID_ARG;
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
@@ -453,6 +535,10 @@ int rw_write(rw_engine *eng, int kind, const void *host_src, size_t bytes) {
         return fail(eng, RW_ERR_INVALID_ARG, "rw_write kind %d: %zu bytes given, buffer holds %zu", kind, bytes, eng->buf[kind].bytes);
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
     if (bytes) RW_HIP(eng, hipMemcpyAsync(eng->buf[kind].ptr, host_src, bytes, hipMemcpyHostToDevice, eng->stream));
+    if (kind == RW_BUF_GRID) {
+        const int rc = rebuild_shadow(eng);
+        if (rc != RW_OK) return rc;
+    }
     RW_HIP(eng, hipStreamSynchronize(eng->stream));
     return RW_OK;
 }

@@ -2,26 +2,32 @@
 //
 // One fused kernel advances `envs_per_wg` independent warehouses per workgroup through every
 // phase of rware.warehouse.Warehouse.step (rware/warehouse.py:804-946) and the FLATTENED
-// observation gather (:598-674), with the whole per-env state staged in LDS:
+// observation gather (:598-674), with the per-env working set staged in LDS:
 //
-//   P0  coalesced dwordx4 loads of the workgroup's env chunk (grid, agent SoA, queue, actions)
-//   P1  move intent + shelf-block cancel                       (:825-846, Agent.req_location :102-116)
-//   P2  collision resolution in closed form — no graph library (:848-876; see resolve notes)
-//   P3  apply (move / turn / load / unload), incremental grid update instead of _recalc_grid
-//                                                              (:880-901, :749-755)
-//   P5  goals, request replacement (numpy-exact PCG64 draw), rewards, termination (:903-942)
-//   RS  on-device reset for autoreset / rw_reset, numpy-exact draws      (:757-802)
-//   P7  observation: per (agent, window cell) 7-bit codes OR-ed into an L-bit string in LDS,
-//       expanded to float32 and written with coalesced dwordx4 stores     (:598-674)
-//   ST  coalesced write-back of the agent SoA / queue / counters; the int32 grid in HBM is
-//       patched only at the <= 2N cells per layer that changed.
-//
-// HBM layout (env-major, see include/rware_hip.h): grid int32 [B][2][H][W]; agent fields int32
-// [B][N] x5; queue int32 [B][Q]; counters int32 [B]; PCG64 state uint64 [6][B] (field-major so
-// that a mass reset reads it coalesced); obs float32 [B][N][L].
+//   P0  HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): the agent SoA, the request queue, the
+//       actions and the env's SHELF layer.  The kernel reads the shelf layer from a compact
+//       shadow (uint8/uint16 per cell, `shelf_shadow`) rather than from the exported int32 grid:
+//       the grid is 93 % of a step's read bytes, the shadow is 1/8 of it.  The agent layer is not
+//       read at all — it is rebuilt in LDS from the agent coordinates.  The int32 grid
+//       [B][2][H][W] stays current in HBM (patched below) as the buffer callers see.
+//   AG  the per-agent phases, one lane per (env, agent), all agents of an env inside ONE
+//       wavefront, ordered by wave-local LDS syncs (no workgroup barrier):
+//         P1  move intent + shelf-block cancel              (:825-846, Agent.req_location :102-116)
+//         P2  collision resolution in closed form            (:848-876; notes below)
+//         P3  apply (move / turn / load / unload) + incremental grid update instead of
+//             _recalc_grid                                   (:880-901, :749-755)
+//         P5  goals, request replacement (numpy-exact PCG64 draw), rewards, termination (:903-942)
+//       and, straight from the agent lanes' registers, the state write-back: agent SoA, rewards,
+//       queue, counters, and the grid/shadow patch of the <= 2N cells per layer that changed.
+//   RS  on-device reset for autoreset / rw_reset, numpy-exact draws (rare path)   (:757-802)
+//   P7  observation: per (agent, window cell) 7-bit codes OR-ed into ONE contiguous bit string
+//       per workgroup (bit g == obs element g of the chunk), so float4 #q is nibble #q (:598-674),
+//       written with dwordx4 stores.  The barriers around it wait on LDS only, so the state
+//       stores issued in AG drain underneath.
 //
 // Roofline: integer/indexing work, no MFMA; bound by HBM bytes.  Algorithmic bytes per
-// env-step A = 8HW + 4N + 40N + 4Q + 16 + 4NL + 4N + 4.
+// env-step A = 8HW + 4N + 40N + 4Q + 16 + 4NL + 4N + 4; the shadow makes the
+// real traffic smaller than A.
 //
 // Collision resolution, closed form.  The reference builds a digraph on cells with one
 // out-edge per agent (start -> target) and, per weakly connected component, commits either
@@ -30,7 +36,8 @@
 // one sink or one cycle, so with nxt(i) = the agent standing on i's target cell:
 //   - i stationary (target == start, incl. wall-clamped FORWARD and cancelled moves): commits.
 //   - depth(i) = longest chain of movers following i (atomicMax walk, <= N hops).
-//   - win(i)   = i has the largest (depth, then LOWEST id) among movers with the same target.
+//   - win(i)   = i holds the largest (depth, then LOWEST id) among movers with the same target:
+//                one LDS atomicMax per mover on a per-cell claim word, then one read.
 //   - walk i -> nxt(i) -> ...: reaches an empty cell  => commit iff every agent on the walk wins;
 //                              reaches a stationary agent => fail;
 //                              returns to i after len hops => commit iff len >= 3 (cycle);
@@ -38,6 +45,8 @@
 // The tie rule (lowest agent id among equal depths) is the pinned rule of DESIGN.md §tie-break.
 #pragma once
 #include <stdint.h>
+
+#include <rware_cdna4.h>
 
 #include "rware_pcg64.h"
 
@@ -49,18 +58,23 @@ enum : int { DIR_UP = 0, DIR_DOWN = 1, DIR_LEFT = 2, DIR_RIGHT = 3 };
 enum : int { REW_GLOBAL = 0, REW_INDIVIDUAL = 1, REW_TWO_STAGE = 2 };
 enum : int { AR_DISABLED = 0, AR_NEXT_STEP = 1, AR_SAME_STEP = 2 };
 enum : int { STATUS_INVALID_ACTION = 1 };
+enum : int { MAX_GOALS = 16 };
 
 struct Params {
     // config
     int32_t B, H, W, HW, N, Q, S, SW;  // SW = dwords of the requested-shelf bitmap = (S+32)/32
+    int32_t HWW;                       // dwords of the highway bitmap = (HW+31)/32
     int32_t n_goals, max_inactivity, max_steps, reward_type, autoreset, normalised;
     int32_t envs_per_wg;
+    int32_t groups_per_wave;           // envs whose agents share one wavefront = 64 / N
+    uint32_t magic_n;                  // ceil(2^18 / N): x / N == (x * magic) >> 18 for x * N < 2^18
+    int32_t goal_cells[MAX_GOALS];     // cell index y*W+x per goal, list order (kernarg -> SGPRs)
     // static per config (device)
-    const uint8_t *highways;    // [HW]
-    const int32_t *goal_cells;  // [n_goals] cell index y*W+x, list order
-    const int32_t *shelf_init;  // [HW] shelf layer right after reset: ids 1..S row-major on non-highway cells
+    const uint32_t *highway_bits;  // [HWW] bit c == highways[c]
+    const int32_t *shelf_init;     // [HW] shelf layer right after reset: ids 1..S row-major on non-highway cells
     // state (device)
     int32_t *grid, *ax, *ay, *adir, *acarry, *adeliv, *queue, *steps, *inactive;
+    void *shelf_shadow;   // CellT [B][HW] (+ padding): compact copy of grid layer 1, the kernel's read path
     uint64_t *rng;        // [6][B]
     uint8_t *need_reset;  // [B]
     // per-launch io
@@ -70,20 +84,27 @@ struct Params {
     float *rewards;             // [B][N]
     uint8_t *terminated, *truncated;  // [B]
     int32_t *status;            // [1] sticky error bits
+    uint64_t *timeline;         // nullptr, or [n_wg][TL_MARKS] wall-clock stamps (rw_debug_timeline)
 };
+enum : int { TL_START = 0, TL_ZEROED, TL_DMA_ISSUED, TL_ENV_LOADED, TL_LOADED, TL_AGENTS, TL_RESET, TL_OBS_BITS,
+             TL_OBS_STORED, TL_END, TL_MARKS = 12 };
 
 // LDS carve-up, in dwords.  Every sub-array starts on a 16-byte boundary.
 struct LdsLayout {
-    int grid, ax, ay, dir, carry, deliv, act, start, tgt, nxt, depth, win, rew, queue, req, obits, envi, misc, total;
+    int gs, ga, claim, ax, ay, dir, carry, deliv, act, tgt, nxt, depth, win, rew, queue, req, hw, obits, envi, misc, total;
 };
 enum : int { ENVI_STEPS = 0, ENVI_INACTIVE = 1, ENVI_RESET = 2, ENVI_DONE = 3, ENVI_SKIP = 4, ENVI_W = 8 };
 
 RW_HD int rw_up4(int x) { return (x + 3) & ~3; }
+RW_HD uint32_t rw_magic18(int d) { return d > 0 ? (uint32_t)(((1u << 18) + (uint32_t)d - 1u) / (uint32_t)d) : 0u; }
+RW_HD int rw_div18(int x, uint32_t magic) { return (int)(((uint32_t)x * magic) >> 18); }
 
-RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW) {
+RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int cell_bytes) {
     LdsLayout l;
     int o = 0;
-    l.grid = o;  o += rw_up4(E * 2 * HW);
+    l.gs = o;    o += rw_up4((E * HW * cell_bytes + 3) / 4 + 1);  // shelf layer, CellT per cell (+ DMA round-up)
+    l.ga = o;    o += rw_up4((E * HW + 3) / 4);                   // agent layer, 1 byte per cell: id | 0x80 if loaded
+    l.claim = o; o += rw_up4(E * HW);                             // per-cell claim word of the collision resolution
     const int en = rw_up4(E * N);
     l.ax = o;    o += en;
     l.ay = o;    o += en;
@@ -91,7 +112,6 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW) {
     l.carry = o; o += en;
     l.deliv = o; o += en;
     l.act = o;   o += en;
-    l.start = o; o += en;
     l.tgt = o;   o += en;
     l.nxt = o;   o += en;
     l.depth = o; o += en;
@@ -99,34 +119,28 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW) {
     l.rew = o;   o += en;
     l.queue = o; o += rw_up4(E * Q);
     l.req = o;   o += rw_up4(E * SW);
-    l.obits = o; o += rw_up4(E * N * OW);
+    l.hw = o;    o += rw_up4((HW + 31) / 32);
+    l.obits = o; o += rw_up4(E * N * OW + 1);  // one contiguous string of E*N*L bits (+1 spill word)
     l.envi = o;  o += rw_up4(E * ENVI_W);
     l.misc = o;  o += 4;
     l.total = o;
     return l;
 }
 
-// flat dword copy global -> LDS, dwordx4 when both sides are 16-byte aligned
-__device__ __forceinline__ void copy_in(int32_t *dst, const int32_t *src, int n, int tid, int T) {
-    if ((((uintptr_t)src) & 15u) == 0) {
+// Asynchronous flat dword copy HBM -> LDS through the LDS-DMA path.  dwordx4 pieces (1 KiB per wave
+// instruction) when the source is 16-byte aligned, dword pieces otherwise; `lds_dst` is 16-byte
+// aligned.  Nothing is waited for here.
+__device__ __forceinline__ void dma_in(int32_t *lds_dst, const int32_t *src, int n, int tid, int T) {
+    const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+    if ((((uintptr_t)src) & 15u) == 0) {  // wave-uniform
         const int n4 = n >> 2;
-        const int4 *s4 = reinterpret_cast<const int4 *>(src);
-        int4 *d4 = reinterpret_cast<int4 *>(dst);
-        for (int i = tid; i < n4; i += T) d4[i] = s4[i];
-        for (int i = (n4 << 2) + tid; i < n; i += T) dst[i] = src[i];
+        for (int b = wave * 64; b < n4; b += nw * 64)
+            if (b + lane < n4) lds_dma_b128(src + 4 * (b + lane), lds_dst + 4 * b);
+        const int t0 = n4 << 2;
+        if (wave == 0 && lane < n - t0) lds_dma_b32(src + t0 + lane, lds_dst + t0);
     } else {
-        for (int i = tid; i < n; i += T) dst[i] = src[i];
-    }
-}
-__device__ __forceinline__ void copy_out(int32_t *dst, const int32_t *src, int n, int tid, int T) {
-    if ((((uintptr_t)dst) & 15u) == 0) {
-        const int n4 = n >> 2;
-        const int4 *s4 = reinterpret_cast<const int4 *>(src);
-        int4 *d4 = reinterpret_cast<int4 *>(dst);
-        for (int i = tid; i < n4; i += T) d4[i] = s4[i];
-        for (int i = (n4 << 2) + tid; i < n; i += T) dst[i] = src[i];
-    } else {
-        for (int i = tid; i < n; i += T) dst[i] = src[i];
+        for (int b = wave * 64; b < n; b += nw * 64)
+            if (b + lane < n) lds_dma_b32(src + b + lane, lds_dst + b);
     }
 }
 
@@ -145,73 +159,129 @@ __device__ __forceinline__ void rng_store(const Pcg64 &g, uint64_t *rng, int B, 
     rng[5 * (size_t)B + e] = (uint64_t)g.uinteger;
 }
 
-template <int R>
+// Rebuilds the shelf shadow from the int32 grid (after a host write of RW_BUF_GRID).
+template <typename CellT>
+__global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, int HW) {
+    const size_t n = (size_t)B * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / HW, c = i - e * HW;
+        shadow[i] = (CellT)grid[e * 2 * HW + HW + c];
+    }
+}
+
+template <int R, typename CellT>
 __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const int op) {
     constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L = 8 + 7 * CELLS, OW = (L + 31) / 32;
     extern __shared__ __align__(16) int32_t smem[];
 
     const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
     const int E = p.envs_per_wg;
     const int e0 = blockIdx.x * E;
     const int ne = min(E, p.B - e0);
     if (ne <= 0) return;
     const int N = p.N, Q = p.Q, HW = p.HW, W = p.W, H = p.H, SW = p.SW, B = p.B;
     const int nea = ne * N;
+    const uint32_t mN = p.magic_n;
+    // optional per-workgroup phase stamps (100 MHz wall clock); one scalar branch per mark when off
+#define RW_MARK(k) do { if (p.timeline && tid == 0) p.timeline[(size_t)blockIdx.x * TL_MARKS + (k)] = wall_clock64(); } while (0)
+    RW_MARK(TL_START);
 
-    const LdsLayout lo = make_lds_layout(E, N, Q, HW, SW, OW);
-    int32_t *s_grid = smem + lo.grid;
+    const LdsLayout lo = make_lds_layout(E, N, Q, HW, SW, OW, (int)sizeof(CellT));
+    CellT *s_gs = reinterpret_cast<CellT *>(smem + lo.gs);
+    uint8_t *s_ga = reinterpret_cast<uint8_t *>(smem + lo.ga);
+    int32_t *s_claim = smem + lo.claim;
     int32_t *s_ax = smem + lo.ax, *s_ay = smem + lo.ay, *s_dir = smem + lo.dir;
-    int32_t *s_carry = smem + lo.carry, *s_deliv = smem + lo.deliv;
-    int32_t *s_act = smem + lo.act, *s_start = smem + lo.start, *s_tgt = smem + lo.tgt;
-    int32_t *s_nxt = smem + lo.nxt, *s_depth = smem + lo.depth, *s_win = smem + lo.win;
+    int32_t *s_carry = smem + lo.carry, *s_deliv = smem + lo.deliv, *s_act = smem + lo.act;
+    int32_t *s_tgt = smem + lo.tgt, *s_nxt = smem + lo.nxt, *s_depth = smem + lo.depth, *s_win = smem + lo.win;
     float *s_rew = reinterpret_cast<float *>(smem + lo.rew);
     int32_t *s_queue = smem + lo.queue;
     uint32_t *s_req = reinterpret_cast<uint32_t *>(smem + lo.req);
+    const uint32_t *s_hw = reinterpret_cast<const uint32_t *>(smem + lo.hw);
     uint32_t *s_obits = reinterpret_cast<uint32_t *>(smem + lo.obits);
     int32_t *s_envi = smem + lo.envi;
     int32_t *s_misc = smem + lo.misc;
+    CellT *g_shadow = reinterpret_cast<CellT *>(p.shelf_shadow);
+    auto on_highway = [&](int c) -> bool { return (s_hw[c >> 5] >> (c & 31)) & 1u; };
+    auto coordf = [&](int k, int v) -> float {
+        if (p.normalised) return (float)((double)v / (double)((k == 0 ? W : H) - 1));  // :636-638
+        return (float)v;
+    };
 
     // ---------------------------------------------------------------- P0: stage the env chunk
-    copy_in(s_grid, p.grid + (size_t)e0 * 2 * HW, ne * 2 * HW, tid, T);
-    copy_in(s_ax, p.ax + (size_t)e0 * N, nea, tid, T);
-    copy_in(s_ay, p.ay + (size_t)e0 * N, nea, tid, T);
-    copy_in(s_dir, p.adir + (size_t)e0 * N, nea, tid, T);
-    copy_in(s_carry, p.acarry + (size_t)e0 * N, nea, tid, T);
-    copy_in(s_deliv, p.adeliv + (size_t)e0 * N, nea, tid, T);
-    copy_in(s_queue, p.queue + (size_t)e0 * Q, ne * Q, tid, T);
-    if (op == OP_STEP) copy_in(s_act, p.actions + (size_t)e0 * N, nea, tid, T);
-    for (int e = tid; e < ne; e += T) {
-        int32_t *ev = s_envi + e * ENVI_W;
-        ev[ENVI_STEPS] = p.steps[e0 + e];
-        ev[ENVI_INACTIVE] = p.inactive[e0 + e];
-        int rs = 0;
-        if (op == OP_STEP) rs = (p.autoreset == AR_NEXT_STEP) ? (int)p.need_reset[e0 + e] : 0;
-        else if (op == OP_RESET) rs = p.reset_mask ? (int)p.reset_mask[e0 + e] : 1;
-        ev[ENVI_RESET] = rs;
-        ev[ENVI_SKIP] = rs;  // an env that resets in this call does not step
-        ev[ENVI_DONE] = 0;
+    // scratch is cleared first so that no LDS write has to be ordered behind the in-flight DMA
+    {
+        int4 *z = reinterpret_cast<int4 *>(smem + lo.ga);  // agent layer + claim words are adjacent
+        const int nz = (lo.ax - lo.ga) >> 2;
+        for (int i = tid; i < nz; i += T) z[i] = int4{0, 0, 0, 0};
     }
     for (int i = tid; i < nea; i += T) {
         s_depth[i] = 0;
         s_rew[i] = 0.0f;
     }
-    for (int i = tid; i < nea * OW; i += T) s_obits[i] = 0u;
+    for (int i = tid; i < nea * OW + 1; i += T) s_obits[i] = 0u;
     for (int i = tid; i < ne * SW; i += T) s_req[i] = 0u;
     if (tid == 0) s_misc[0] = 0;
-    __syncthreads();
+    RW_MARK(TL_ZEROED);
+    dma_in(smem + lo.gs, reinterpret_cast<const int32_t *>(g_shadow + (size_t)e0 * HW),
+           (ne * HW * (int)sizeof(CellT) + 3) >> 2, tid, T);
+    dma_in(s_ax, p.ax + (size_t)e0 * N, nea, tid, T);
+    dma_in(s_ay, p.ay + (size_t)e0 * N, nea, tid, T);
+    dma_in(s_dir, p.adir + (size_t)e0 * N, nea, tid, T);
+    dma_in(s_carry, p.acarry + (size_t)e0 * N, nea, tid, T);
+    dma_in(s_deliv, p.adeliv + (size_t)e0 * N, nea, tid, T);
+    dma_in(s_queue, p.queue + (size_t)e0 * Q, ne * Q, tid, T);
+    if (op == OP_STEP) dma_in(s_act, p.actions + (size_t)e0 * N, nea, tid, T);
+    dma_in(smem + lo.hw, reinterpret_cast<const int32_t *>(p.highway_bits), p.HWW, tid, T);
+    RW_MARK(TL_DMA_ISSUED);
+    lds_barrier();  // orders the s_misc clear above before the flag writes below
+    for (int e = tid; e < ne; e += T) {
+        int32_t *ev = s_envi + e * ENVI_W;
+        int rs = 0;
+        if (op == OP_STEP) rs = (p.autoreset == AR_NEXT_STEP) ? (int)p.need_reset[e0 + e] : 0;
+        else if (op == OP_RESET) rs = p.reset_mask ? (int)p.reset_mask[e0 + e] : 1;
+        ev[ENVI_STEPS] = p.steps[e0 + e];
+        ev[ENVI_INACTIVE] = p.inactive[e0 + e];
+        ev[ENVI_RESET] = rs;
+        ev[ENVI_SKIP] = rs;  // an env that resets in this call does not step
+        ev[ENVI_DONE] = 0;
+        if (rs) s_misc[0] = 1;
+    }
+    RW_MARK(TL_ENV_LOADED);
+    __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
+    RW_MARK(TL_LOADED);
 
-    if (op == OP_STEP) {
+    // ---------------------------------------------------------------- AG: per-agent phases, wave-local
+    // Lane -> (env group g, agent a): all N agents of an env sit in one wavefront, so the sub-phases
+    // below exchange data through LDS under wave_sync() only.
+    const int G = p.groups_per_wave;
+    for (int eb = wave * G; eb < ne; eb += nw * G) {  // wave-uniform
+        const int g = rw_div18(lane, mN), a_idx = lane - g * N;
+        const bool mine = (g < G) && (eb + g < ne);
+        const int e = mine ? eb + g : eb;  // keep every address in range for idle lanes
+        const int base = e * N, i = base + (mine ? a_idx : 0);
+        CellT *gS = s_gs + e * HW;
+        uint8_t *gA = s_ga + e * HW;
+        int32_t *claim = s_claim + e * HW;
+        int32_t *ev = s_envi + e * ENVI_W;
+        const int ge = e0 + e;  // global env index
+        const bool stepping = (op == OP_STEP) && mine && !ev[ENVI_SKIP];
+        // ---- R1: own record into registers; rebuild the agent layer (id | 0x80 if loaded)
+        int x = 0, y = 0, d = 0, carry = 0, deliv = 0, a = ACT_NOOP;
+        if (mine) {
+            x = s_ax[i]; y = s_ay[i]; d = s_dir[i]; carry = s_carry[i]; deliv = s_deliv[i];
+            if (stepping) a = s_act[i];
+        }
+        const int st = y * W + x;
+        if (mine && !ev[ENVI_RESET]) gA[st] = (uint8_t)((a_idx + 1) | (carry ? 0x80 : 0));
+        wave_sync();
         // ------------------------------------------------------------ P1: intent (:825-846)
-        for (int i = tid; i < nea; i += T) {
-            const int e = i / N;
-            if (s_envi[e * ENVI_W + ENVI_SKIP]) continue;
-            const int32_t *gA = s_grid + e * 2 * HW, *gS = gA + HW;
-            int a = s_act[i];
+        int tg = st, nxt = -2, shelf_here = 0;
+        if (stepping) {
             if ((unsigned)a > 4u) {  // Action(a) raises in the reference (:814); flagged, runs as NOOP
                 atomicOr(p.status, STATUS_INVALID_ACTION);
                 a = ACT_NOOP;
             }
-            const int x = s_ax[i], y = s_ay[i], d = s_dir[i];
             int tx = x, ty = y;
             if (a == ACT_FORWARD) {  // clamped at the walls (:105-112)
                 if (d == DIR_UP) ty = max(0, y - 1);
@@ -219,128 +289,93 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
                 else if (d == DIR_LEFT) tx = max(0, x - 1);
                 else tx = min(W - 1, x + 1);
             }
-            const int st = y * W + x;
-            int tg = ty * W + tx;
-            if (s_carry[i] && tg != st && gS[tg]) {
-                const int occ = gA[tg];
-                if (!(occ && s_carry[e * N + occ - 1])) {  // a standing shelf blocks a loaded agent
-                    a = ACT_NOOP;
-                    tg = st;
-                }
+            tg = ty * W + tx;
+            const int sh_tg = gS[tg], ag_tg = gA[tg];
+            shelf_here = gS[st];
+            if (carry && tg != st && sh_tg && !(ag_tg & 0x80)) {  // a standing shelf blocks a loaded agent
+                a = ACT_NOOP;
+                tg = st;
             }
-            s_act[i] = a;
-            s_start[i] = st;
-            s_tgt[i] = tg;
             // successor on the chain: agent index on the target cell, -1 empty, -2 == i is stationary
-            s_nxt[i] = (tg == st) ? -2 : (gA[tg] - 1);
+            nxt = (tg == st) ? -2 : ((ag_tg & 0x7f) - 1);
+            s_tgt[i] = tg;
+            s_nxt[i] = nxt;
         }
-        __syncthreads();
+        wave_sync();
         // ------------------------------------------------------------ P2a: follower depth
-        for (int i = tid; i < nea; i += T) {
-            const int e = i / N, base = e * N, me = i - base;
-            if (s_envi[e * ENVI_W + ENVI_SKIP] || s_nxt[i] == -2) continue;
-            int j = s_nxt[i], dd = 1;
-            while (j >= 0 && j != me && dd <= N && s_nxt[base + j] != -2) {
+        if (stepping && nxt != -2) {
+            int j = nxt, dd = 1;
+            while (j >= 0 && j != a_idx && dd <= N && s_nxt[base + j] != -2) {
                 atomicMax(&s_depth[base + j], dd);
                 j = s_nxt[base + j];
                 ++dd;
             }
         }
-        __syncthreads();
+        wave_sync();
         // ------------------------------------------------------------ P2b: winner per contested cell
-        for (int i = tid; i < nea; i += T) {
-            const int e = i / N, base = e * N, me = i - base;
-            if (s_envi[e * ENVI_W + ENVI_SKIP]) continue;
-            int w = 1;
-            if (s_nxt[i] != -2) {
-                const int tg = s_tgt[i], dme = s_depth[i];
-                for (int k = 0; k < N; ++k) {
-                    if (k == me || s_nxt[base + k] == -2 || s_tgt[base + k] != tg) continue;
-                    const int dk = s_depth[base + k];
-                    if (dk > dme || (dk == dme && k < me)) w = 0;
-                }
-            }
-            s_win[i] = w;
+        int prio = 0;
+        if (stepping && nxt != -2) {  // larger depth wins, then the LOWER agent id
+            prio = (s_depth[i] << 8) | (255 - a_idx);
+            atomicMax(&claim[tg], prio);
         }
-        __syncthreads();
+        wave_sync();
+        if (stepping) s_win[i] = (nxt == -2) ? 1 : (claim[tg] == prio ? 1 : 0);
+        wave_sync();
         // ------------------------------------------------------------ P2c + P3: commit, apply (:871-899)
-        for (int i = tid; i < nea; i += T) {
-            const int e = i / N, base = e * N, me = i - base;
-            if (s_envi[e * ENVI_W + ENVI_SKIP]) continue;
-            int32_t *gA = s_grid + e * 2 * HW, *gS = gA + HW;
-            int a = s_act[i];
-            if (s_nxt[i] != -2) {  // a mover: walk the chain ahead
-                int j = me, hops = 0, ok = 1, commit = 0;
+        bool moved = false;
+        float rew = 0.0f;
+        if (stepping) {
+            if (nxt != -2) {  // a mover: walk the chain ahead
+                int j = a_idx, hops = 0, ok = 1, commit = 0;
                 for (;;) {
                     ok &= s_win[base + j];
                     const int nj = s_nxt[base + j];
                     ++hops;
-                    if (nj == -1) { commit = ok; break; }        // drains into an empty cell
-                    if (nj == me) { commit = (hops >= 3); break; }  // a cycle through me; 2-swap refused
-                    if (s_nxt[base + nj] == -2) break;            // blocked by a stationary agent
-                    if (hops >= N) break;                          // feeds a cycle it is not part of
+                    if (nj == -1) { commit = ok; break; }              // drains into an empty cell
+                    if (nj == a_idx) { commit = (hops >= 3); break; }  // a cycle through me; 2-swap refused
+                    if (s_nxt[base + nj] == -2) break;                 // blocked by a stationary agent
+                    if (hops >= N) break;                              // feeds a cycle it is not part of
                     j = nj;
                 }
                 if (!commit) a = ACT_NOOP;
             }
-            const int st = s_start[i], tg = s_tgt[i];
-            int carry = s_carry[i];
             if (a == ACT_FORWARD) {
                 if (tg != st) {
-                    s_ax[i] = tg % W;
-                    s_ay[i] = tg / W;
+                    moved = true;
+                    x = tg % W;
+                    y = tg / W;
                     gA[st] = 0;  // clear phase of the incremental _recalc_grid
                     if (carry) gS[st] = 0;
                 }
             } else if (a == ACT_LEFT || a == ACT_RIGHT) {
                 // wraplist [UP, RIGHT, DOWN, LEFT] (:119): RIGHT 0->3->1->2->0, LEFT 0->2->1->3->0
-                const int d = s_dir[i];
                 const int right = (0x1023 >> (4 * d)) & 0xF;  // d: 0->3, 1->2, 2->0, 3->1
                 const int left = (0x0132 >> (4 * d)) & 0xF;   // d: 0->2, 1->3, 2->1, 3->0
-                s_dir[i] = (a == ACT_RIGHT) ? right : left;
+                d = (a == ACT_RIGHT) ? right : left;
             } else if (a == ACT_TOGGLE) {
                 if (!carry) {
-                    const int sid = gS[st];
-                    if (sid) s_carry[i] = sid;
-                } else if (!p.highways[st]) {
-                    s_carry[i] = 0;
-                    if (s_deliv[i] && p.reward_type == REW_TWO_STAGE) s_rew[i] += 0.5f;
-                    s_deliv[i] = 0;
+                    if (shelf_here) carry = shelf_here;
+                } else if (!on_highway(st)) {
+                    carry = 0;
+                    if (deliv && p.reward_type == REW_TWO_STAGE) rew = 0.5f;
+                    deliv = 0;
                 }
             }
-            s_act[i] = (a == ACT_FORWARD && tg != st) ? 1 : 0;  // from here on: "moved" flag
+            s_ax[i] = x; s_ay[i] = y; s_dir[i] = d; s_carry[i] = carry; s_deliv[i] = deliv;
+            s_rew[i] = rew;
         }
-        __syncthreads();
-        for (int i = tid; i < nea; i += T) {  // set phase
-            const int e = i / N;
-            if (s_envi[e * ENVI_W + ENVI_SKIP] || !s_act[i]) continue;
-            int32_t *gA = s_grid + e * 2 * HW, *gS = gA + HW;
-            gA[s_tgt[i]] = (i - e * N) + 1;
-            if (s_carry[i]) gS[s_tgt[i]] = s_carry[i];
+        wave_sync();
+        if (stepping) {  // set phase (also refreshes the loaded flag after a pick-up / drop)
+            gA[moved ? tg : st] = (uint8_t)((a_idx + 1) | (carry ? 0x80 : 0));
+            if (moved && carry) gS[tg] = (CellT)carry;
         }
-        __syncthreads();
-        // ------------------------------------------------------------ grid patch to HBM + P5 goals
-        for (int i = tid; i < nea; i += T) {
-            const int e = i / N;
-            if (s_envi[e * ENVI_W + ENVI_SKIP] || !s_act[i]) continue;
-            const int32_t *gA = s_grid + e * 2 * HW, *gS = gA + HW;
-            int32_t *hA = p.grid + (size_t)(e0 + e) * 2 * HW, *hS = hA + HW;
-            const int st = s_start[i], tg = s_tgt[i];
-            hA[st] = gA[st];
-            hA[tg] = gA[tg];
-            if (s_carry[i]) {
-                hS[st] = gS[st];
-                hS[tg] = gS[tg];
-            }
-        }
-        for (int e = tid; e < ne; e += T) {
-            int32_t *ev = s_envi + e * ENVI_W;
-            if (ev[ENVI_SKIP]) continue;
-            const int32_t *gA = s_grid + e * 2 * HW, *gS = gA + HW;
+        wave_sync();
+        // ------------------------------------------------------------ P5: goals, rewards, termination
+        if (stepping && a_idx == 0) {
             int32_t *q = s_queue + e * Q;
             bool delivered = false;
-            for (int g = 0; g < p.n_goals; ++g) {  // in list order (:904)
-                const int cell = p.goal_cells[g];
+            for (int gi = 0; gi < p.n_goals; ++gi) {  // in list order (:904)
+                const int cell = p.goal_cells[gi];
                 const int sid = gS[cell];
                 if (!sid) continue;
                 int slot = -1;
@@ -350,9 +385,9 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
                 delivered = true;
                 // candidates = shelves not in the queue, id order; one bounded draw (:915-916)
                 Pcg64 rg;
-                rng_load(rg, p.rng, B, e0 + e);
+                rng_load(rg, p.rng, B, ge);
                 const int idx = (int)pcg_bounded(rg, (uint32_t)(p.S - Q - 1));
-                rng_store(rg, p.rng, B, e0 + e);
+                rng_store(rg, p.rng, B, ge);
                 int cand = idx + 1;  // idx-th id (0-based) among ids 1..S that are not queued
                 for (;;) {
                     int c = 0;
@@ -363,15 +398,15 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
                 }
                 q[slot] = cand;
                 if (p.reward_type == REW_GLOBAL) {
-                    for (int k = 0; k < N; ++k) s_rew[e * N + k] += 1.0f;
+                    for (int k = 0; k < N; ++k) s_rew[base + k] += 1.0f;
                 } else {
-                    const int aid = gA[cell];
+                    const int aid = gA[cell] & 0x7f;
                     const int ai = aid > 0 ? aid - 1 : N - 1;  // rewards[-1] when nobody stands there
                     if (p.reward_type == REW_INDIVIDUAL) {
-                        s_rew[e * N + ai] += 1.0f;
+                        s_rew[base + ai] += 1.0f;
                     } else {
-                        s_deliv[e * N + ai] = 1;
-                        s_rew[e * N + ai] += 0.5f;
+                        s_deliv[base + ai] = 1;
+                        s_rew[base + ai] += 0.5f;
                     }
                 }
             }
@@ -380,21 +415,64 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
             const int done = ((p.max_inactivity && ev[ENVI_INACTIVE] >= p.max_inactivity) ||
                               (p.max_steps && ev[ENVI_STEPS] >= p.max_steps)) ? 1 : 0;
             ev[ENVI_DONE] = done;
-            if (done && p.autoreset == AR_SAME_STEP) ev[ENVI_RESET] = 1;
+            if (done && p.autoreset == AR_SAME_STEP) {
+                ev[ENVI_RESET] = 1;
+                s_misc[0] = 1;
+            }
         }
-        __syncthreads();
+        wave_sync();
+        // ------------------------------------------------------------ write-back from the agent lanes
+        // (envs flagged for reset are written by RS instead)
+        if (mine && !ev[ENVI_RESET]) {
+            if (stepping) {
+                p.ax[(size_t)ge * N + a_idx] = x;
+                p.ay[(size_t)ge * N + a_idx] = y;
+                p.adir[(size_t)ge * N + a_idx] = d;
+                p.acarry[(size_t)ge * N + a_idx] = carry;
+                p.adeliv[(size_t)ge * N + a_idx] = s_deliv[i];
+                p.rewards[(size_t)ge * N + a_idx] = s_rew[i];
+                if (moved) {  // patch the exported int32 grid and the shadow at the two cells that changed
+                    int32_t *hA = p.grid + (size_t)ge * 2 * HW, *hS = hA + HW;
+                    hA[st] = gA[st] & 0x7f;
+                    hA[tg] = a_idx + 1;
+                    if (carry) {
+                        const CellT s_at_st = gS[st];
+                        hS[st] = s_at_st;
+                        hS[tg] = carry;
+                        g_shadow[(size_t)ge * HW + st] = s_at_st;
+                        g_shadow[(size_t)ge * HW + tg] = (CellT)carry;
+                    }
+                }
+                if (a_idx == 0) {
+                    p.steps[ge] = ev[ENVI_STEPS];
+                    p.inactive[ge] = ev[ENVI_INACTIVE];
+                    p.terminated[ge] = (uint8_t)ev[ENVI_DONE];
+                    p.truncated[ge] = 0;  // the reference never truncates (:942)
+                    p.need_reset[ge] = (uint8_t)((p.autoreset == AR_NEXT_STEP) ? ev[ENVI_DONE] : 0);
+                }
+            }
+            for (int k = a_idx; k < Q; k += N) {  // queue write-back + requested-shelf bitmap
+                const int sid = s_queue[e * Q + k];
+                if (stepping) p.queue[(size_t)ge * Q + k] = sid;
+                atomicOr(&s_req[e * SW + (sid >> 5)], 1u << (sid & 31));
+            }
+            // self part of the observation, k = 2..7: carrying, one-hot direction, on_highway (:643-647)
+            const uint32_t self = (carry ? 1u : 0u) | (2u << d) | (on_highway(y * W + x) ? 32u : 0u);
+            const int bit = i * L + 2, wd = bit >> 5, sh = bit & 31;
+            atomicOr(&s_obits[wd], self << sh);
+            if (sh > 26) atomicOr(&s_obits[wd + 1], self >> (32 - sh));
+        }
     }
+    lds_barrier();
+    RW_MARK(TL_AGENTS);
 
     // ---------------------------------------------------------------- RS: reset flagged envs (:757-802)
-    for (int e = tid; e < ne; e += T)
-        if (s_envi[e * ENVI_W + ENVI_RESET]) s_misc[0] = 1;
-    __syncthreads();
-    if (s_misc[0]) {  // workgroup-uniform
-        for (int c = tid; c < ne * 2 * HW; c += T) {
-            const int e = c / (2 * HW);
+    if (s_misc[0] != 0) {  // workgroup-uniform; rare
+        for (int c = tid; c < ne * HW; c += T) {
+            const int e = c / HW;
             if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;
-            const int r = c - e * 2 * HW;
-            s_grid[c] = (r < HW) ? 0 : p.shelf_init[r - HW];
+            s_ga[c] = 0;
+            s_gs[c] = (CellT)p.shelf_init[c - e * HW];
         }
         __syncthreads();
         for (int e = tid; e < ne; e += T) {
@@ -404,113 +482,122 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
             rng_load(rg, p.rng, B, e0 + e);
             int32_t *cells = s_tgt + e * N;  // scratch
             pcg_choice_no_replace(rg, HW, N, cells);  // agent cells (:781-786)
-            int32_t *gA = s_grid + e * 2 * HW;
             for (int k = 0; k < N; ++k) {
                 const int c = cells[k];
                 s_ax[e * N + k] = c % W;
                 s_ay[e * N + k] = c / W;
-                gA[c] = k + 1;
+                s_ga[e * HW + c] = (uint8_t)(k + 1);
             }
             for (int k = 0; k < N; ++k) {  // directions (:788)
                 s_dir[e * N + k] = (int)pcg_bounded(rg, 3u);
                 s_carry[e * N + k] = 0;
                 s_deliv[e * N + k] = 0;
-            }
+            }  // s_rew keeps the terminating step's rewards (SAME_STEP); it is still 0 for envs that did not step
             int32_t *q = s_queue + e * Q;  // request queue (:796-800)
             pcg_choice_no_replace(rg, p.S, Q, q);
-            for (int k = 0; k < Q; ++k) q[k] += 1;
+            for (int k = 0; k < SW; ++k) s_req[e * SW + k] = 0u;
+            for (int k = 0; k < Q; ++k) {
+                q[k] += 1;
+                s_req[e * SW + (q[k] >> 5)] |= 1u << (q[k] & 31);
+            }
             rng_store(rg, p.rng, B, e0 + e);
             ev[ENVI_STEPS] = 0;
             ev[ENVI_INACTIVE] = 0;
         }
         __syncthreads();
-        for (int c = tid; c < ne * 2 * HW; c += T) {  // a reset rewrites the env's whole grid in HBM
-            const int e = c / (2 * HW);
-            if (s_envi[e * ENVI_W + ENVI_RESET]) p.grid[(size_t)e0 * 2 * HW + c] = s_grid[c];
+        // write the reset envs back: whole grid (both layers) + shadow, agent SoA, queue, counters, self bits
+        for (int c = tid; c < ne * HW; c += T) {
+            const int e = c / HW;
+            if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;
+            const int cc = c - e * HW;
+            int32_t *hA = p.grid + (size_t)(e0 + e) * 2 * HW;
+            hA[cc] = s_ga[c] & 0x7f;
+            hA[HW + cc] = s_gs[c];
+            g_shadow[(size_t)(e0 + e) * HW + cc] = s_gs[c];
         }
+        for (int i = tid; i < nea; i += T) {
+            const int e = rw_div18(i, mN);
+            if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;
+            const size_t gi = (size_t)e0 * N + i;
+            p.ax[gi] = s_ax[i]; p.ay[gi] = s_ay[i]; p.adir[gi] = s_dir[i];
+            p.acarry[gi] = 0; p.adeliv[gi] = 0;
+            p.rewards[gi] = s_rew[i];
+            const uint32_t self = (2u << s_dir[i]) | (on_highway(s_ay[i] * W + s_ax[i]) ? 32u : 0u);
+            const int bit = i * L + 2, wd = bit >> 5, sh = bit & 31;
+            atomicOr(&s_obits[wd], self << sh);
+            if (sh > 26) atomicOr(&s_obits[wd + 1], self >> (32 - sh));
+        }
+        for (int e = tid; e < ne; e += T) {
+            const int32_t *ev = s_envi + e * ENVI_W;
+            if (!ev[ENVI_RESET]) continue;
+            for (int k = 0; k < Q; ++k) p.queue[(size_t)(e0 + e) * Q + k] = s_queue[e * Q + k];
+            p.steps[e0 + e] = 0;
+            p.inactive[e0 + e] = 0;
+            p.terminated[e0 + e] = (uint8_t)ev[ENVI_DONE];
+            p.truncated[e0 + e] = 0;
+            p.need_reset[e0 + e] = 0;
+        }
+        lds_barrier();
     }
+    RW_MARK(TL_RESET);
 
     // ---------------------------------------------------------------- P7: observation bits (:598-674)
-    for (int i = tid; i < ne * Q; i += T) {
-        const int e = i / Q, sid = s_queue[i];
-        atomicOr(&s_req[e * SW + (sid >> 5)], 1u << (sid & 31));
-    }
-    __syncthreads();
-    // bit k of agent i's string == obs[i][k] for k >= 2 (k = 0,1 are the coordinates)
-    for (int i = tid; i < nea; i += T) {
-        const int c = s_ay[i] * W + s_ax[i];
-        const uint32_t self = (s_carry[i] ? 4u : 0u) | (8u << s_dir[i]) | (p.highways[c] ? 128u : 0u);
-        atomicOr(&s_obits[i * OW], self);
-    }
+    // One contiguous bit string per workgroup: bit (i*L + k) == obs[agent i][k] for k >= 2; the two
+    // coordinate slots k = 0,1 stay 0 here and are filled in as floats during expansion.
     for (int w = tid; w < nea * CELLS; w += T) {
         const int i = w / CELLS, cidx = w - i * CELLS;
-        const int e = i / N;
+        const int e = rw_div18(i, mN);
         const int dy = cidx / WIN - R, dx = cidx % WIN - R;
         const int x = s_ax[i] + dx, y = s_ay[i] + dy;
         uint32_t code = 2u;  // empty / off-map cell: has_agent 0, direction one-hot [1,0,0,0] (:659)
         if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
-            const int32_t *gA = s_grid + e * 2 * HW, *gS = gA + HW;
-            const int c = y * W + x;
-            const int ida = gA[c], ids = gS[c];
+            const int c = e * HW + y * W + x;
+            const int ida = s_ga[c] & 0x7f, ids = s_gs[c];
             if (ida) code = 1u | (2u << s_dir[e * N + ida - 1]);
             if (ids) code |= 32u | (((s_req[e * SW + (ids >> 5)] >> (ids & 31)) & 1u) << 6);
         }
-        const int bit = 8 + 7 * cidx;
+        const int bit = i * L + 8 + 7 * cidx;
         const int wd = bit >> 5, sh = bit & 31;
-        atomicOr(&s_obits[i * OW + wd], code << sh);
-        if (sh > 25) atomicOr(&s_obits[i * OW + wd + 1], code >> (32 - sh));
+        atomicOr(&s_obits[wd], code << sh);
+        if (sh > 25) atomicOr(&s_obits[wd + 1], code >> (32 - sh));
     }
-    __syncthreads();
+    lds_barrier();
+    RW_MARK(TL_OBS_BITS);
 
-    // ---------------------------------------------------------------- obs expansion + coalesced store
+    // ---------------------------------------------------------------- ST: obs, float4 #q == nibble #q
     {
         const int nf = nea * L;
-        float *out = p.obs + (size_t)e0 * N * L;
-        const float nx = p.normalised ? 1.0f : 0.0f;
-        auto elem = [&](int g) -> float {
-            const int i = g / L, k = g - i * L;
-            if (k >= 2) return ((s_obits[i * OW + (k >> 5)] >> (k & 31)) & 1u) ? 1.0f : 0.0f;
-            const int v = (k == 0) ? s_ax[i] : s_ay[i];
-            if (nx != 0.0f) return (float)((double)v / (double)((k == 0 ? W : H) - 1));  // :636-638
-            return (float)v;
-        };
-        if ((((uintptr_t)out) & 15u) == 0) {
-            const int nf4 = nf >> 2;
-            float4 *out4 = reinterpret_cast<float4 *>(out);
-            for (int q4 = tid; q4 < nf4; q4 += T) {
-                float4 v;
-                v.x = elem(4 * q4 + 0);
-                v.y = elem(4 * q4 + 1);
-                v.z = elem(4 * q4 + 2);
-                v.w = elem(4 * q4 + 3);
-                out4[q4] = v;
+        const int nf4 = nf >> 2;
+        float *out = p.obs + (size_t)e0 * N * L;  // 16-byte aligned: e0 is a multiple of 4
+        float4 *out4 = reinterpret_cast<float4 *>(out);
+        for (int q4 = tid; q4 < nf4; q4 += T) {
+            const uint32_t nib = s_obits[q4 >> 3] >> ((q4 & 7) << 2);
+            float4 v;
+            v.x = (nib & 1u) ? 1.0f : 0.0f;
+            v.y = (nib & 2u) ? 1.0f : 0.0f;
+            v.z = (nib & 4u) ? 1.0f : 0.0f;
+            v.w = (nib & 8u) ? 1.0f : 0.0f;
+            const int il = (4 * q4 + 3) / L;  // agent that owns the last element of this float4
+            const int pos = il * L - 4 * q4;  // where its k = 0 slot falls inside the float4
+            if ((unsigned)(pos + 1) <= 4u) {  // the float4 holds x and/or y of agent il
+                const float fx = coordf(0, s_ax[il]), fy = coordf(1, s_ay[il]);
+                if (pos == 0) { v.x = fx; v.y = fy; }
+                else if (pos == 1) { v.y = fx; v.z = fy; }
+                else if (pos == 2) { v.z = fx; v.w = fy; }
+                else if (pos == 3) { v.w = fx; }
+                else { v.x = fy; }
             }
-            for (int g = (nf4 << 2) + tid; g < nf; g += T) out[g] = elem(g);
-        } else {
-            for (int g = tid; g < nf; g += T) out[g] = elem(g);
+            out4[q4] = v;
+        }
+        for (int g = (nf4 << 2) + tid; g < nf; g += T) {  // < 4 leftover floats (partial last workgroup)
+            const int i = g / L, k = g - i * L;
+            out[g] = (k >= 2) ? (((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f)
+                              : coordf(k, k == 0 ? s_ax[i] : s_ay[i]);
         }
     }
-
-    // ---------------------------------------------------------------- ST: write back state
-    if (op != OP_OBS) {
-        copy_out(p.ax + (size_t)e0 * N, s_ax, nea, tid, T);
-        copy_out(p.ay + (size_t)e0 * N, s_ay, nea, tid, T);
-        copy_out(p.adir + (size_t)e0 * N, s_dir, nea, tid, T);
-        copy_out(p.acarry + (size_t)e0 * N, s_carry, nea, tid, T);
-        copy_out(p.adeliv + (size_t)e0 * N, s_deliv, nea, tid, T);
-        copy_out(p.queue + (size_t)e0 * Q, s_queue, ne * Q, tid, T);
-        copy_out(reinterpret_cast<int32_t *>(p.rewards) + (size_t)e0 * N,
-                 reinterpret_cast<const int32_t *>(s_rew), nea, tid, T);
-        for (int e = tid; e < ne; e += T) {
-            const int32_t *ev = s_envi + e * ENVI_W;
-            if (op == OP_RESET && !ev[ENVI_RESET]) continue;  // a masked reset leaves other envs' flags alone
-            p.steps[e0 + e] = ev[ENVI_STEPS];
-            p.inactive[e0 + e] = ev[ENVI_INACTIVE];
-            p.terminated[e0 + e] = (uint8_t)ev[ENVI_DONE];
-            p.truncated[e0 + e] = 0;  // the reference never truncates (:942)
-            p.need_reset[e0 + e] = (uint8_t)((p.autoreset == AR_NEXT_STEP) ? ev[ENVI_DONE] : 0);
-        }
-    }
+    RW_MARK(TL_OBS_STORED);
+    RW_MARK(TL_END);
+#undef RW_MARK
 }
 
 }  // namespace rw

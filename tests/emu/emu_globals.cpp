@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE — storage for the HIP stand-in (see hip/hip_runtime.h).  NOT PRODUCT CODE.
 #include <hip/hip_runtime.h>
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
-thread_local pthread_barrier_t *emu_barrier = nullptr;
+thread_local pthread_barrier_t *emu_barrier = nullptr, *emu_wave_barrier = nullptr;
 namespace rw { alignas(16) int32_t smem[160 * 1024 / 4]; }

@@ -37,9 +37,12 @@ struct alignas(16) int4 { int x, y, z, w; };
 struct alignas(16) float4 { float x, y, z, w; };
 
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
-extern thread_local pthread_barrier_t *emu_barrier;
+extern thread_local pthread_barrier_t *emu_barrier, *emu_wave_barrier;
 namespace rw { extern int32_t smem[]; }
 
+inline unsigned long long wall_clock64() {
+    return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10;
+}
 inline void __syncthreads() { pthread_barrier_wait(emu_barrier); }
 inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
@@ -94,10 +97,15 @@ void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t 
     for (unsigned b = 0; b < grid.x; ++b) {
         pthread_barrier_t bar;
         pthread_barrier_init(&bar, nullptr, block.x);
+        const unsigned n_waves = (block.x + 63) / 64;
+        std::vector<pthread_barrier_t> wbar(n_waves);
+        for (unsigned w = 0; w < n_waves; ++w) pthread_barrier_init(&wbar[w], nullptr, std::min(64u, block.x - w * 64));
+        pthread_barrier_t *wbars = wbar.data();
         std::vector<std::thread> th;
         th.reserve(block.x);
         for (unsigned t = 0; t < block.x; ++t)
             th.emplace_back([=, &bar]() {
+                emu_wave_barrier = wbars + t / 64;
                 threadIdx = dim3(t);
                 blockIdx = dim3(b);
                 blockDim = block;
@@ -107,5 +115,6 @@ void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t 
             });
         for (auto &x : th) x.join();
         pthread_barrier_destroy(&bar);
+        for (auto &wb : wbar) pthread_barrier_destroy(&wb);
     }
 }

@@ -1,0 +1,15 @@
+// TEST INFRASTRUCTURE — host stand-in for robotic-warehouse_amd/csrc/rware_cdna4.h (found first
+// on the emulation build's include path).  Same contracts: LDS-DMA destination = wave base +
+// lane * size; lds_barrier == workgroup barrier; wave_sync == barrier over the 64 threads of a wave.
+#pragma once
+#include <hip/hip_runtime.h>
+namespace rw {
+inline void lds_dma_b128(const void *g_lane, void *lds_wave_base) {
+    memcpy((char *)lds_wave_base + (threadIdx.x & 63u) * 16, g_lane, 16);
+}
+inline void lds_dma_b32(const void *g_lane, void *lds_wave_base) {
+    memcpy((char *)lds_wave_base + (threadIdx.x & 63u) * 4, g_lane, 4);
+}
+inline void lds_barrier() { pthread_barrier_wait(emu_barrier); }
+inline void wave_sync() { pthread_barrier_wait(emu_wave_barrier); }
+}  // namespace rw

@@ -1,0 +1,131 @@
+"""CPU-side tests of the PRODUCT sources (kernel + C-ABI host + Python host layer) compiled for
+host threads (tests/emu): control flow, autoreset modes, masked reset, state injection, geometry
+variants and ragged batches, all diffed against the oracle / the reference's golden vectors.
+The gfx950 build of the same sources is checked by the -m gpu tests."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from engine_backend import EngineBackend, build_emu
+from rware_oracle import OracleVecEnv
+
+import rware_amd
+
+LIB = build_emu()
+pytestmark = pytest.mark.timeout(600)
+
+
+@pytest.mark.parametrize("name,geom", [
+    ("tiny-2ag", (4, 64)),
+    ("small-4ag", (16, 256)),
+    ("tiny-4ag-easy-twostage", (4, 128)),
+    ("small-8ag-global-inact", (4, 64)),
+    ("layoutstr-3ag", (4, 64)),
+    ("small-3ag-normcoord-sr3", (4, 64)),
+    ("tiny-1ag-hard-q0", (4, 64)),
+    ("small-19ag", (4, 64)),
+])
+def test_emulated_engine_matches_reference_golden(name, geom):
+    meta, z = gu.load_fixture(name)
+    be = EngineBackend(meta["E"], library=LIB, envs_per_workgroup=geom[0], threads_per_workgroup=geom[1],
+                       **gu.ctor_kwargs(meta))
+    assert gu.replay(be, meta, z, steps=350) > 0
+    be.env.close()
+
+
+@pytest.mark.parametrize("mode", ["next_step", "same_step", "disabled"])
+@pytest.mark.parametrize("env_id,extra,B,geom", [
+    ("rware-tiny-2ag-v1", {"max_steps": 25}, 7, (4, 64)),           # ragged: 2 workgroups, the last partial
+    ("rware-small-8ag-v1", {"max_steps": 30, "reward_type": 0, "max_inactivity_steps": 9}, 5, (4, 128)),
+    ("rware-medium-6ag-hard-v1", {"max_steps": 20, "reward_type": 2}, 9, (8, 128)),
+    ("rware-large-16ag-v1", {"sensor_range": 2, "max_steps": 15}, 3, (4, 64)),
+])
+def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
+    kw = rware_amd.env_kwargs(env_id)
+    kw.update(extra)
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    env = rware_amd.WarehouseVecEnv(B, autoreset_mode=mode, library=LIB, envs_per_workgroup=geom[0],
+                                    threads_per_workgroup=geom[1], **kw)
+    orc = OracleVecEnv(B, **kw)
+    obs, _ = env.reset(seed=99)
+    assert np.array_equal(obs, orc.reset(seed=99))
+    rng = np.random.default_rng(3)
+    for t in range(70):
+        a = rng.choice(5, size=(B, kw["n_agents"]), p=[0.1, 0.55, 0.1, 0.1, 0.15]).astype(np.int32)
+        obs, rew, term, trunc, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, mode)
+        assert np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+        assert np.array_equal(obs, o2), t
+        st, so = env.get_state(), orc.get_state()
+        for k in so:
+            assert np.array_equal(st[k], so[k]), (k, t)
+    env.close()
+
+
+def test_masked_reset_and_reseed():
+    kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
+    kw["reward_type"] = 1
+    B = 6
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **kw)
+    orc = OracleVecEnv(B, **kw)
+    env.reset(seed=5)
+    orc.reset(seed=5)
+    a = np.random.default_rng(0).integers(0, 5, size=(B, 2))
+    for _ in range(5):
+        env.step(a)
+        orc.step_autoreset(a, "next_step")
+    mask = np.array([1, 0, 0, 1, 0, 1], np.uint8)
+    obs, _ = env.reset(mask=mask)                       # continue the streams of envs 0, 3, 5
+    assert np.array_equal(obs, orc.reset(mask=mask))
+    obs, _ = env.reset(seed=[11, 12, 13, 14, 15, 16], mask=mask)   # reseed just those
+    for e in np.nonzero(mask)[0]:
+        from rware_oracle import seed_state
+        orc.rng[e] = seed_state(11 + int(e))
+    assert np.array_equal(obs, orc.reset(mask=mask))
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    env.close()
+
+
+def test_host_layer_errors_and_views():
+    kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
+    env = rware_amd.WarehouseVecEnv(4, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **kw)
+    obs, info = env.reset(seed=0)
+    assert obs.shape == (4, 2, 71) and obs.dtype == np.float32 and info == {}
+    with pytest.raises(ValueError):
+        env.step(np.full((4, 2), 5))
+    with pytest.raises(AssertionError):
+        env.step(np.zeros((4, 3), int))
+    o, r, term, trunc, info = env.step([[rware_amd.Action.FORWARD, rware_amd.Action.NOOP]] * 4)
+    assert r.shape == (4, 2) and term.dtype == bool and not trunc.any() and info == {}
+    assert env.shelf_xy().shape == (4, env.n_shelves, 2)
+    with pytest.raises(NotImplementedError):
+        rware_amd.WarehouseVecEnv(2, library=LIB, **dict(kw, msg_bits=1))
+    with pytest.raises(NotImplementedError):
+        rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.IMAGE, **kw)
+    with pytest.raises(rware_amd._capi.EngineError):
+        rware_amd.WarehouseVecEnv(2, library=LIB, envs_per_workgroup=6, **kw)   # not a multiple of 4
+    env.close()
+
+
+def test_sharded_env_equals_unsharded():
+    """env-batch sharding (one engine per shard, global seeds) is invisible in the results."""
+    kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
+    one = rware_amd.WarehouseVecEnv(10, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **kw)
+    two = rware_amd.WarehouseVecEnv(10, library=LIB, devices=[0, 0, 0], envs_per_workgroup=4,
+                                    threads_per_workgroup=64, **kw)
+    assert len(two.engines) == 3
+    o1, _ = one.reset(seed=123)
+    o2, _ = two.reset(seed=123)
+    assert np.array_equal(o1, o2)
+    rng = np.random.default_rng(1)
+    for _ in range(30):
+        a = rng.integers(0, 5, size=(10, 2))
+        r1, r2 = one.step(a), two.step(a)
+        for x, y in zip(r1[:4], r2[:4]):
+            assert np.array_equal(x, y)
+    s1, s2 = one.get_state(), two.get_state()
+    for k in s1:
+        assert np.array_equal(s1[k], s2[k]), k
+    one.close(); two.close()

@@ -214,7 +214,7 @@ def test_two_deliveries_in_one_step_draw_in_goal_order(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("cols,height,rows", [(1, 1, 1), (3, 8, 1), (3, 8, 3), (5, 3, 2), (7, 4, 4)])
+@pytest.mark.parametrize("cols,height,rows", [(1, 2, 2), (3, 8, 1), (3, 8, 3), (5, 3, 2), (7, 4, 4)])
 def test_grid_size_formula(backend, cols, height, rows):
     env = make(backend, 1, cols=cols, height=height, rows=rows, queue=1)
     assert tuple(env.grid_size) == ((height + 1) * rows + 2, 3 * cols + 1)   # README / warehouse.py:297-300
