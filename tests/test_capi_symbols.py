@@ -1,0 +1,74 @@
+"""The C-ABI library loads and exports every entry point include/rware_hip.h declares; the pure
+host entry points behave; without a HIP device construction fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rware_amd
+from rware_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rware_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rw_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ("rw_create", "rw_destroy", "rw_reset", "rw_step", "rw_step_device", "rw_step_many_device",
+                 "rw_sync", "rw_get_buffer", "rw_read", "rw_write", "rw_recalc_grid", "rw_last_error"):
+        assert must in names
+    assert sorted(_capi.EXPORTS) == names, "python binding and header disagree"
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} missing from {_capi.DEFAULT_LIBRARY}"
+    assert lib.rw_abi_version() == _capi.RW_ABI_VERSION
+
+
+@pytest.mark.parametrize("seed", [0, 1, 7, 123456789, 2**32 - 1, 2**32 + 5, 2**63])
+def test_rw_seed_state_matches_numpy(seed):
+    st = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed))).bit_generator.state
+    s, inc, m = st["state"]["state"], st["state"]["inc"], (1 << 64) - 1
+    want = np.array([s >> 64, s & m, inc >> 64, inc & m, 0, 0], dtype=np.uint64)
+    assert np.array_equal(_capi.seed_state(seed), want)
+
+
+def test_bad_config_is_rejected_before_touching_the_device():
+    lib = _capi.load()
+    cfg = _capi.RwConfig()
+    h = C.c_void_p()
+    assert lib.rw_create(C.byref(cfg), C.byref(h)) == _capi.RW_ERR_INVALID_ARG  # abi_version 0
+    assert b"abi_version" in lib.rw_last_error(None)
+    assert lib.rw_create(None, C.byref(h)) == _capi.RW_ERR_INVALID_ARG
+    assert lib.rw_step(None, None) == _capi.RW_ERR_INVALID_ARG
+    assert lib.rw_destroy(None) == _capi.RW_OK
+
+
+def _gpu_present():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_gpu_present(), reason="a HIP device is visible")
+def test_no_device_means_loud_failure_not_a_cpu_path():
+    with pytest.raises(_capi.EngineError) as ei:
+        rware_amd.make_vec("rware-tiny-2ag-v1", 4)
+    assert ei.value.code == _capi.RW_ERR_NO_DEVICE
+
+
+def test_missing_library_is_a_loud_error(tmp_path):
+    with pytest.raises(RuntimeError, match="not found"):
+        _capi.load(str(tmp_path / "librware_hip.so"))

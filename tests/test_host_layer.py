@@ -1,0 +1,82 @@
+"""Host-side mirror of the reference interface: layout, observation length, registry ids/kwargs.
+Cross-checked against the oracle's independent restatement and, where /root/reference exists,
+against the reference itself."""
+import numpy as np
+import pytest
+
+import ref_runner as rr
+import rware_oracle as orc
+
+import rware_amd
+from rware_amd.layout import layout_from_params, layout_from_str, obs_length
+
+
+@pytest.mark.parametrize("cols,rows,height", [(1, 1, 8), (3, 1, 8), (3, 2, 8), (5, 2, 8), (5, 3, 8), (3, 3, 3), (7, 4, 2), (9, 1, 1)])
+def test_layout_from_params_matches_oracle_restatement(cols, rows, height):
+    lay = layout_from_params(cols, rows, height)
+    hw, goals = orc.layout_from_params(cols, rows, height)
+    assert lay.grid_size == ((height + 1) * rows + 2, 3 * cols + 1)        # warehouse.py:297-300
+    assert np.array_equal(lay.highways, hw) and list(lay.goals) == goals
+    assert lay.highways[-1].all() and lay.highways[:, 0].all()             # delivery row, left highway
+    assert all(lay.highways[y, x] for x, y in lay.goals)
+
+
+def test_layout_from_str():
+    s = """
+        .x.x.
+        .x.x.
+        ..g..
+    """
+    lay = layout_from_str(s)
+    hw, goals = orc.layout_from_str(s)
+    assert lay.grid_size == (3, 5) and np.array_equal(lay.highways, hw) and list(lay.goals) == goals == [(2, 2)]
+    assert lay.n_shelves == 4
+    with pytest.raises(AssertionError):
+        layout_from_str("..\n...")
+    with pytest.raises(AssertionError):
+        layout_from_str("....")
+
+
+def test_obs_length_formula():
+    assert obs_length(1) == 71 and obs_length(2) == 183 and obs_length(3) == 351   # 8 + 7(2r+1)^2
+    assert obs_length(1, msg_bits=2) == 71 + 2 * 9
+
+
+def test_registry_ids_and_kwargs():
+    ids = rware_amd.all_ids()
+    assert len(ids) == 2 * 228 and len(set(ids)) == len(ids)
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    assert kw == rware_amd.env_kwargs("rware-small-4ag-v2")
+    assert (kw["shelf_rows"], kw["shelf_columns"], kw["n_agents"], kw["request_queue_size"]) == (2, 3, 4, 4)
+    assert rware_amd.env_kwargs("rware-medium-6ag-hard-v1")["request_queue_size"] == 3
+    assert rware_amd.env_kwargs("rware-tiny-1ag-hard-v2")["request_queue_size"] == 0
+    assert rware_amd.env_kwargs("rware-large-19ag-easy-v2")["request_queue_size"] == 38
+    for bad in ("rware-small-0ag-v1", "rware-small-20ag-v1", "rware-huge-2ag-v1", "rware-small-4ag-v3"):
+        with pytest.raises(KeyError):
+            rware_amd.env_kwargs(bad)
+
+
+@pytest.mark.skipif(not rr.reference_available(), reason="/root/reference not present")
+def test_registry_kwargs_equal_the_references_own():
+    for env_id in rware_amd.all_ids(("v2",)):
+        ref = rr.registry_kwargs(env_id)
+        ours = rware_amd.env_kwargs(env_id)
+        ref["reward_type"] = ref["reward_type"].value
+        ours["reward_type"] = ours["reward_type"].value
+        assert ref == ours, env_id
+
+
+@pytest.mark.skipif(not rr.reference_available(), reason="/root/reference not present")
+@pytest.mark.parametrize("env_id", ["rware-tiny-2ag-v2", "rware-small-4ag-v2", "rware-medium-6ag-hard-v2", "rware-large-16ag-v2"])
+def test_layout_equals_the_references_own(env_id):
+    env = rr.make_reference_env(env_id)
+    kw = rware_amd.env_kwargs(env_id)
+    lay = layout_from_params(kw["shelf_columns"], kw["shelf_rows"], kw["column_height"])
+    assert lay.grid_size == tuple(env.grid_size)
+    assert np.array_equal(lay.highways, env.highways) and list(lay.goals) == list(env.goals)
+
+
+def test_enums_are_value_compatible():
+    assert [a.value for a in rware_amd.Action] == [0, 1, 2, 3, 4]
+    assert [d.name for d in rware_amd.Direction] == ["UP", "DOWN", "LEFT", "RIGHT"]
+    assert rware_amd.RewardType.TWO_STAGE.value == 2 and rware_amd.ObservationType.FLATTENED.value == 1
