@@ -178,7 +178,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": "rw::rware_step_kernel<1>", "kernel_ms_per_launch": kernel_ms,
+                "kernel": "rw::rware_step_kernel<1, unsigned char>", "kernel_ms_per_launch": kernel_ms,
                 "algorithmic_bytes_per_launch": per_launch,
             },
         }
