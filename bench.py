@@ -173,6 +173,7 @@ def main():
                 "parallelism": f"env-shard x{world} (no collective)",
                 "submit": f"rw_step_many_device x{args.many}" if args.many else "rw_step_device per step",
                 "envs_per_workgroup": int(info.envs_per_workgroup), "threads_per_workgroup": int(info.threads_per_workgroup),
+                "kernel_specialised": bool(info.specialised),
                 "device": info.device_name.decode(), "arch": info.arch_name.decode(),
             },
             "roofline": {

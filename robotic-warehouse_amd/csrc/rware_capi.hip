@@ -38,6 +38,8 @@ struct rw_engine {
     uint32_t *d_highway_bits = nullptr;
     int32_t *d_shelf_init = nullptr;
     uint8_t *d_mask = nullptr;
+    void (*kernel)(const rw::Params, const int) = nullptr;  // the step kernel instance this engine launches
+    bool specialised = false;
     void *slab = nullptr;      // the single device allocation behind every buffer below
     size_t shadow_off = 0;
     void *d_shadow = nullptr;  // compact shelf layer (uint8 when S <= 255, else uint16), the kernel's read path
@@ -70,26 +72,32 @@ int fail(rw_engine *eng, int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
-template <int R, typename CellT>
-void launch_rc(rw_engine *eng, const rw::Params &p, int op) {
-    hipLaunchKernelGGL((rw::rware_step_kernel<R, CellT>), dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
-                       eng->stream, p, op);
-}
+using step_kernel_t = void (*)(const rw::Params, const int);
+
 template <int R>
-void launch_r(rw_engine *eng, const rw::Params &p, int op) {
-    if (eng->wide) launch_rc<R, uint16_t>(eng, p, op);
-    else launch_rc<R, uint8_t>(eng, p, op);
+step_kernel_t generic_kernel(bool wide) {
+    return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg>
+                : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg>;
 }
 
+// Specialised builds for the BASELINE.json tasks at their default launch geometry:
+//   {H, W, N, Q, S, R}  ->  kernel with those shapes (and E, T) folded in at compile time.
+struct StaticEntry {
+    int H, W, N, Q, S, R, E, T;
+    step_kernel_t fn;
+};
+#define RW_STATIC(H, W, N, Q, S, R, E, T) \
+    {H, W, N, Q, S, R, E, T, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>>}
+const StaticEntry kStatic[] = {
+    RW_STATIC(11, 10, 2, 2, 32, 1, 16, 256),    // rware-tiny-2ag
+    RW_STATIC(20, 10, 4, 4, 80, 1, 16, 256),    // rware-small-4ag (headline)
+    RW_STATIC(20, 16, 6, 3, 144, 1, 16, 256),   // rware-medium-6ag-hard
+    RW_STATIC(29, 16, 16, 16, 224, 2, 8, 256),  // rware-large-16ag, sensor_range = 2
+};
+#undef RW_STATIC
+
 int launch(rw_engine *eng, const rw::Params &p, int op) {
-    switch (eng->cfg.sensor_range) {
-        case 1: launch_r<1>(eng, p, op); break;
-        case 2: launch_r<2>(eng, p, op); break;
-        case 3: launch_r<3>(eng, p, op); break;
-        case 4: launch_r<4>(eng, p, op); break;
-        case 5: launch_r<5>(eng, p, op); break;
-        default: return fail(eng, RW_ERR_UNSUPPORTED, "sensor_range %d not in 1..5", eng->cfg.sensor_range);
-    }
+    hipLaunchKernelGGL(eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes, eng->stream, p, op);
     RW_HIP(eng, hipGetLastError());
     return RW_OK;
 }
@@ -107,16 +115,6 @@ int rebuild_shadow(rw_engine *eng) {
                            (const int32_t *)eng->buf[RW_BUF_GRID].ptr, (uint8_t *)eng->d_shadow, B, HW);
     RW_HIP(eng, hipGetLastError());
     return RW_OK;
-}
-
-template <int R, typename CellT>
-hipError_t raise_lds_limit_rc(size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(rw::rware_step_kernel<R, CellT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-template <int R>
-hipError_t raise_lds_limit(size_t bytes, bool wide) {
-    return wide ? raise_lds_limit_rc<R, uint16_t>(bytes) : raise_lds_limit_rc<R, uint8_t>(bytes);
 }
 
 size_t elem_size(int kind) {
@@ -277,6 +275,24 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             return bail(RW_ERR_INVALID_ARG);
         }
     }
+    switch (R) {
+        case 1: eng->kernel = generic_kernel<1>(eng->wide); break;
+        case 2: eng->kernel = generic_kernel<2>(eng->wide); break;
+        case 3: eng->kernel = generic_kernel<3>(eng->wide); break;
+        case 4: eng->kernel = generic_kernel<4>(eng->wide); break;
+        default: eng->kernel = generic_kernel<5>(eng->wide); break;
+    }
+    for (const StaticEntry &se : kStatic) {
+        const bool shape = se.H == H && se.W == W && se.N == N && se.Q == Q && se.S == S && se.R == R;
+        const bool geom_default = cfg->envs_per_workgroup == 0 && cfg->threads_per_workgroup == 0;
+        const bool geom_same = E == se.E && T == se.T;
+        if (shape && (geom_default || geom_same) && B % se.E == 0) {
+            E = se.E;
+            T = se.T;
+            eng->kernel = se.fn;
+            eng->specialised = true;
+        }
+    }
     eng->E = E;
     eng->T = T;
     eng->n_wg = (B + E - 1) / E;
@@ -286,14 +302,8 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         return bail(RW_ERR_INVALID_ARG);
     }
     if (eng->lds_bytes > 64 * 1024) {
-        hipError_t lds_err = hipSuccess;
-        switch (R) {
-            case 1: lds_err = raise_lds_limit<1>(eng->lds_bytes, eng->wide); break;
-            case 2: lds_err = raise_lds_limit<2>(eng->lds_bytes, eng->wide); break;
-            case 3: lds_err = raise_lds_limit<3>(eng->lds_bytes, eng->wide); break;
-            case 4: lds_err = raise_lds_limit<4>(eng->lds_bytes, eng->wide); break;
-            default: lds_err = raise_lds_limit<5>(eng->lds_bytes, eng->wide); break;
-        }
+        hipError_t lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(eng->kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->lds_bytes);
         RW_HIP_C(lds_err);
     }
 
@@ -579,6 +589,7 @@ int rw_get_info(const rw_engine *eng, rw_info *out) {
     out->lds_bytes = (int32_t)eng->lds_bytes;
     out->device_id = eng->cfg.device_id;
     out->compute_units = eng->prop.multiProcessorCount;
+    out->specialised = eng->specialised ? 1 : 0;
     // A = 8HW + 4N + 40N + 4Q + 16 + 4NL + 4N + 4
     out->algorithmic_bytes_per_env_step =
         8LL * p.HW + 4LL * p.N + 40LL * p.N + 4LL * p.Q + 16 + 4LL * p.N * eng->L + 4LL * p.N + 4;

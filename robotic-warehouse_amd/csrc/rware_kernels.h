@@ -127,6 +127,19 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
     return l;
 }
 
+// Config policy of the kernel.  DynamicCfg reads every shape from Params at run time (any layout,
+// any N/Q, any launch geometry).  StaticCfg bakes the shapes of one registered task and one launch
+// geometry in as constants, so the LDS carve-up, the index arithmetic, the divisions and the loop
+// trip counts all fold at compile time and the kernel needs a fraction of the scalar registers
+// (no kernarg re-loads on the critical path).  A field == 0 means "take it from Params".
+struct DynamicCfg {
+    static constexpr int kH = 0, kW = 0, kN = 0, kQ = 0, kS = 0, kE = 0, kT = 0;
+};
+template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_>
+struct StaticCfg {
+    static constexpr int kH = H_, kW = W_, kN = N_, kQ = Q_, kS = S_, kE = E_, kT = T_;
+};
+
 // Asynchronous flat dword copy HBM -> LDS through the LDS-DMA path.  dwordx4 pieces (1 KiB per wave
 // instruction) when the source is 16-byte aligned, dword pieces otherwise; `lds_dst` is 16-byte
 // aligned.  Nothing is waited for here.
@@ -169,20 +182,22 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
     }
 }
 
-template <int R, typename CellT>
+template <int R, typename CellT, typename Cfg>
 __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const int op) {
     constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L = 8 + 7 * CELLS, OW = (L + 31) / 32;
     extern __shared__ __align__(16) int32_t smem[];
 
-    const int tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x, T = Cfg::kT ? Cfg::kT : (int)blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
-    const int E = p.envs_per_wg;
+    const int E = Cfg::kE ? Cfg::kE : p.envs_per_wg;
     const int e0 = blockIdx.x * E;
-    const int ne = min(E, p.B - e0);
+    const int ne = Cfg::kE ? E : min(E, p.B - e0);  // the static kernels are only launched with B % E == 0
     if (ne <= 0) return;
-    const int N = p.N, Q = p.Q, HW = p.HW, W = p.W, H = p.H, SW = p.SW, B = p.B;
+    const int N = Cfg::kN ? Cfg::kN : p.N, Q = Cfg::kN ? Cfg::kQ : p.Q;
+    const int H = Cfg::kH ? Cfg::kH : p.H, W = Cfg::kW ? Cfg::kW : p.W, HW = H * W;
+    const int S = Cfg::kN ? Cfg::kS : p.S, SW = (S + 32) / 32, B = p.B;
     const int nea = ne * N;
-    const uint32_t mN = p.magic_n;
+    const uint32_t mN = Cfg::kN ? rw_magic18(Cfg::kN) : p.magic_n;
     // optional per-workgroup phase stamps (100 MHz wall clock); one scalar branch per mark when off
 #define RW_MARK(k) do { if (p.timeline && tid == 0) p.timeline[(size_t)blockIdx.x * TL_MARKS + (k)] = wall_clock64(); } while (0)
     RW_MARK(TL_START);
@@ -232,7 +247,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
     dma_in(s_deliv, p.adeliv + (size_t)e0 * N, nea, tid, T);
     dma_in(s_queue, p.queue + (size_t)e0 * Q, ne * Q, tid, T);
     if (op == OP_STEP) dma_in(s_act, p.actions + (size_t)e0 * N, nea, tid, T);
-    dma_in(smem + lo.hw, reinterpret_cast<const int32_t *>(p.highway_bits), p.HWW, tid, T);
+    dma_in(smem + lo.hw, reinterpret_cast<const int32_t *>(p.highway_bits), (HW + 31) / 32, tid, T);
     RW_MARK(TL_DMA_ISSUED);
     lds_barrier();  // orders the s_misc clear above before the flag writes below
     for (int e = tid; e < ne; e += T) {
@@ -254,7 +269,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
     // ---------------------------------------------------------------- AG: per-agent phases, wave-local
     // Lane -> (env group g, agent a): all N agents of an env sit in one wavefront, so the sub-phases
     // below exchange data through LDS under wave_sync() only.
-    const int G = p.groups_per_wave;
+    const int G = Cfg::kN ? 64 / Cfg::kN : p.groups_per_wave;
     for (int eb = wave * G; eb < ne; eb += nw * G) {  // wave-uniform
         const int g = rw_div18(lane, mN), a_idx = lane - g * N;
         const bool mine = (g < G) && (eb + g < ne);
@@ -386,7 +401,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
                 // candidates = shelves not in the queue, id order; one bounded draw (:915-916)
                 Pcg64 rg;
                 rng_load(rg, p.rng, B, ge);
-                const int idx = (int)pcg_bounded(rg, (uint32_t)(p.S - Q - 1));
+                const int idx = (int)pcg_bounded(rg, (uint32_t)(S - Q - 1));
                 rng_store(rg, p.rng, B, ge);
                 int cand = idx + 1;  // idx-th id (0-based) among ids 1..S that are not queued
                 for (;;) {
@@ -494,7 +509,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
                 s_deliv[e * N + k] = 0;
             }  // s_rew keeps the terminating step's rewards (SAME_STEP); it is still 0 for envs that did not step
             int32_t *q = s_queue + e * Q;  // request queue (:796-800)
-            pcg_choice_no_replace(rg, p.S, Q, q);
+            pcg_choice_no_replace(rg, S, Q, q);
             for (int k = 0; k < SW; ++k) s_req[e * SW + k] = 0u;
             for (int k = 0; k < Q; ++k) {
                 q[k] += 1;
