@@ -1,0 +1,11 @@
+export TMPDIR=/tmp
+R=$PWD
+timeout 900 python -m pytest tests -m gpu -x -q > $R/gpurun_out/pytest_gpuB.log 2>&1; echo "pytest rc=$?"; tail -3 $R/gpurun_out/pytest_gpuB.log
+b() { timeout 120 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline "$@" 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["roofline"]["kernel_ms_per_launch"]*1000,2),"us", round(d["value"]/1e9,3),"G agent-steps/s frac",round(d["roofline"]["frac"],3), "spec", d["config"]["kernel_specialised"])'; }
+echo "small-4ag static:   $(b)"
+echo "small-4ag generic:  $(b --envs-per-wg 8 --threads-per-wg 128)"
+echo "tiny-2ag 4096:      $(b --env-id rware-tiny-2ag-v1 --batch 4096)"
+echo "tiny-2ag 16384:     $(b --env-id rware-tiny-2ag-v1 --batch 16384)"
+echo "medium-6ag-hard 8192: $(b --env-id rware-medium-6ag-hard-v1 --batch 8192)"
+echo "medium-6ag-hard 16384: $(b --env-id rware-medium-6ag-hard-v1 --batch 16384)"
+python profiles/tools/timeline_probe.py rware-small-4ag-v1 16384 2>&1 | grep -v amdgpu.ids | tee $R/gpurun_out/timeline_v5b.log

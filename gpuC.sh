@@ -1,0 +1,6 @@
+export TMPDIR=/tmp
+R=$PWD
+b() { timeout 120 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline "$@" 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["roofline"]["kernel_ms_per_launch"]*1000,2),"us", round(d["value"]/1e9,3),"G agent-steps/s frac",round(d["roofline"]["frac"],3), "spec", d["config"]["kernel_specialised"])'; }
+echo "small-4ag static:   $(b)"
+echo "small-4ag generic:  $(b --envs-per-wg 8 --threads-per-wg 128)"
+python profiles/tools/timeline_probe.py rware-small-4ag-v1 16384 2>&1 | grep -v amdgpu.ids | tee $R/gpurun_out/timeline_v5c.log

@@ -347,7 +347,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     const int HWW = (HW + 31) / 32;
     RW_HIP_C(hipMalloc(&eng->d_highway_bits, sizeof(uint32_t) * HWW));
     RW_HIP_C(hipMalloc(&eng->d_shelf_init, sizeof(int32_t) * HW));
-    RW_HIP_C(hipMalloc(&eng->d_mask, szB));
+    RW_HIP_C(hipMalloc(&eng->d_mask, szB + 64));
     RW_HIP_C(hipMalloc(&eng->d_status, sizeof(int32_t)));
     std::vector<int32_t> shelf_init(HW, 0);
     std::vector<uint32_t> hw_bits(HWW, 0u);
@@ -439,8 +439,10 @@ int rw_reset(rw_engine *eng, const uint64_t *seeds, const uint8_t *mask) {
     if (mask) {
         RW_HIP(eng, hipMemcpyAsync(eng->d_mask, mask, (size_t)B, hipMemcpyHostToDevice, eng->stream));
         RW_HIP(eng, hipStreamSynchronize(eng->stream));  // `mask` is caller-owned pageable memory
-        p.reset_mask = eng->d_mask;
+    } else {
+        RW_HIP(eng, hipMemsetAsync(eng->d_mask, 1, (size_t)B, eng->stream));
     }
+    p.reset_mask = eng->d_mask;
     return launch(eng, p, rw::OP_RESET);
 }
 

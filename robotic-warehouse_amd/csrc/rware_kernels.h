@@ -36,8 +36,8 @@
 // one sink or one cycle, so with nxt(i) = the agent standing on i's target cell:
 //   - i stationary (target == start, incl. wall-clamped FORWARD and cancelled moves): commits.
 //   - depth(i) = longest chain of movers following i (atomicMax walk, <= N hops).
-//   - win(i)   = i holds the largest (depth, then LOWEST id) among movers with the same target:
-//                one LDS atomicMax per mover on a per-cell claim word, then one read.
+//   - win(i)   = i holds the largest (depth, then LOWEST id) among movers with the same target
+//                (a scan over the env's N agents; contiguous LDS reads).
 //   - walk i -> nxt(i) -> ...: reaches an empty cell  => commit iff every agent on the walk wins;
 //                              reaches a stationary agent => fail;
 //                              returns to i after len hops => commit iff len >= 3 (cycle);
@@ -91,7 +91,11 @@ enum : int { TL_START = 0, TL_ZEROED, TL_DMA_ISSUED, TL_ENV_LOADED, TL_LOADED, T
 
 // LDS carve-up, in dwords.  Every sub-array starts on a 16-byte boundary.
 struct LdsLayout {
-    int gs, ga, claim, ax, ay, dir, carry, deliv, act, tgt, nxt, depth, win, rew, queue, req, hw, obits, envi, misc, total;
+    // DMA destinations, contiguous in exactly this order (the static builds fill them with ONE linear
+    // LDS-DMA stream): shelf layer, agent SoA, actions, queue, highway bitmap, per-env counters/flags
+    int gs, ax, ay, dir, carry, deliv, act, queue, hw, dsteps, dinact, dflag, dma_end;
+    int ga, zero_end;  // cleared every launch
+    int tgt, nxt, depth, win, rew, fx, fy, req, obits, envi, misc, total;
 };
 enum : int { ENVI_STEPS = 0, ENVI_INACTIVE = 1, ENVI_RESET = 2, ENVI_DONE = 3, ENVI_SKIP = 4, ENVI_W = 8 };
 
@@ -102,27 +106,33 @@ RW_HD int rw_div18(int x, uint32_t magic) { return (int)(((uint32_t)x * magic) >
 RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int cell_bytes) {
     LdsLayout l;
     int o = 0;
-    l.gs = o;    o += rw_up4((E * HW * cell_bytes + 3) / 4 + 1);  // shelf layer, CellT per cell (+ DMA round-up)
-    l.ga = o;    o += rw_up4((E * HW + 3) / 4);                   // agent layer, 1 byte per cell: id | 0x80 if loaded
-    l.claim = o; o += rw_up4(E * HW);                             // per-cell claim word of the collision resolution
     const int en = rw_up4(E * N);
-    l.ax = o;    o += en;
-    l.ay = o;    o += en;
-    l.dir = o;   o += en;
-    l.carry = o; o += en;
-    l.deliv = o; o += en;
-    l.act = o;   o += en;
-    l.tgt = o;   o += en;
-    l.nxt = o;   o += en;
-    l.depth = o; o += en;
-    l.win = o;   o += en;
-    l.rew = o;   o += en;
-    l.queue = o; o += rw_up4(E * Q);
-    l.req = o;   o += rw_up4(E * SW);
-    l.hw = o;    o += rw_up4((HW + 31) / 32);
-    l.obits = o; o += rw_up4(E * N * OW + 1);  // one contiguous string of E*N*L bits (+1 spill word)
-    l.envi = o;  o += rw_up4(E * ENVI_W);
-    l.misc = o;  o += 4;
+    l.gs = o;     o += rw_up4((E * HW * cell_bytes + 3) / 4);  // shelf layer, CellT per cell
+    l.ax = o;     o += en;
+    l.ay = o;     o += en;
+    l.dir = o;    o += en;
+    l.carry = o;  o += en;
+    l.deliv = o;  o += en;
+    l.act = o;    o += en;
+    l.queue = o;  o += rw_up4(E * Q);
+    l.hw = o;     o += rw_up4((HW + 31) / 32);
+    l.dsteps = o; o += rw_up4(E);
+    l.dinact = o; o += rw_up4(E);
+    l.dflag = o;  o += rw_up4((E + 3) / 4);                    // bytes
+    l.dma_end = o;
+    l.ga = o;     o += rw_up4((E * HW + 3) / 4);               // agent layer, 1 byte per cell: id | 0x80 if loaded
+    l.zero_end = o;
+    l.tgt = o;    o += en;
+    l.nxt = o;    o += en;
+    l.depth = o;  o += en;
+    l.win = o;    o += en;
+    l.rew = o;    o += en;
+    l.fx = o;     o += en;
+    l.fy = o;     o += en;
+    l.req = o;    o += rw_up4(E * SW);
+    l.obits = o;  o += rw_up4(E * N * OW + 1);  // one contiguous string of E*N*L bits (+1 spill word)
+    l.envi = o;   o += rw_up4(E * ENVI_W);
+    l.misc = o;   o += 4;
     l.total = o;
     return l;
 }
@@ -205,11 +215,11 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
     const LdsLayout lo = make_lds_layout(E, N, Q, HW, SW, OW, (int)sizeof(CellT));
     CellT *s_gs = reinterpret_cast<CellT *>(smem + lo.gs);
     uint8_t *s_ga = reinterpret_cast<uint8_t *>(smem + lo.ga);
-    int32_t *s_claim = smem + lo.claim;
     int32_t *s_ax = smem + lo.ax, *s_ay = smem + lo.ay, *s_dir = smem + lo.dir;
     int32_t *s_carry = smem + lo.carry, *s_deliv = smem + lo.deliv, *s_act = smem + lo.act;
     int32_t *s_tgt = smem + lo.tgt, *s_nxt = smem + lo.nxt, *s_depth = smem + lo.depth, *s_win = smem + lo.win;
     float *s_rew = reinterpret_cast<float *>(smem + lo.rew);
+    float *s_fx = reinterpret_cast<float *>(smem + lo.fx), *s_fy = reinterpret_cast<float *>(smem + lo.fy);
     int32_t *s_queue = smem + lo.queue;
     uint32_t *s_req = reinterpret_cast<uint32_t *>(smem + lo.req);
     const uint32_t *s_hw = reinterpret_cast<const uint32_t *>(smem + lo.hw);
@@ -224,52 +234,93 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
     };
 
     // ---------------------------------------------------------------- P0: stage the env chunk
-    // scratch is cleared first so that no LDS write has to be ordered behind the in-flight DMA
-    {
-        int4 *z = reinterpret_cast<int4 *>(smem + lo.ga);  // agent layer + claim words are adjacent
-        const int nz = (lo.ax - lo.ga) >> 2;
+    auto clear_scratch = [&]() {  // agent layer, depth, obs bit string, request bitmap
+        int4 *z = reinterpret_cast<int4 *>(smem + lo.ga);
+        const int nz = (lo.zero_end - lo.ga) >> 2;
         for (int i = tid; i < nz; i += T) z[i] = int4{0, 0, 0, 0};
-    }
-    for (int i = tid; i < nea; i += T) {
-        s_depth[i] = 0;
-        s_rew[i] = 0.0f;
-    }
-    for (int i = tid; i < nea * OW + 1; i += T) s_obits[i] = 0u;
-    for (int i = tid; i < ne * SW; i += T) s_req[i] = 0u;
-    if (tid == 0) s_misc[0] = 0;
+        for (int i = tid; i < nea; i += T) s_depth[i] = 0;
+        for (int i = tid; i < nea * OW + 1; i += T) s_obits[i] = 0u;
+        for (int i = tid; i < ne * SW; i += T) s_req[i] = 0u;
+        if (tid == 0) s_misc[0] = 0;
+    };
+    const uint8_t *flag_src = (op == OP_RESET) ? p.reset_mask : p.need_reset;  // OP_RESET: all-ones when no mask was given
+    clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
     RW_MARK(TL_ZEROED);
-    dma_in(smem + lo.gs, reinterpret_cast<const int32_t *>(g_shadow + (size_t)e0 * HW),
-           (ne * HW * (int)sizeof(CellT) + 3) >> 2, tid, T);
-    dma_in(s_ax, p.ax + (size_t)e0 * N, nea, tid, T);
-    dma_in(s_ay, p.ay + (size_t)e0 * N, nea, tid, T);
-    dma_in(s_dir, p.adir + (size_t)e0 * N, nea, tid, T);
-    dma_in(s_carry, p.acarry + (size_t)e0 * N, nea, tid, T);
-    dma_in(s_deliv, p.adeliv + (size_t)e0 * N, nea, tid, T);
-    dma_in(s_queue, p.queue + (size_t)e0 * Q, ne * Q, tid, T);
-    if (op == OP_STEP) dma_in(s_act, p.actions + (size_t)e0 * N, nea, tid, T);
-    dma_in(smem + lo.hw, reinterpret_cast<const int32_t *>(p.highway_bits), (HW + 31) / 32, tid, T);
-    RW_MARK(TL_DMA_ISSUED);
-    lds_barrier();  // orders the s_misc clear above before the flag writes below
-    for (int e = tid; e < ne; e += T) {
-        int32_t *ev = s_envi + e * ENVI_W;
-        int rs = 0;
-        if (op == OP_STEP) rs = (p.autoreset == AR_NEXT_STEP) ? (int)p.need_reset[e0 + e] : 0;
-        else if (op == OP_RESET) rs = p.reset_mask ? (int)p.reset_mask[e0 + e] : 1;
-        ev[ENVI_STEPS] = p.steps[e0 + e];
-        ev[ENVI_INACTIVE] = p.inactive[e0 + e];
-        ev[ENVI_RESET] = rs;
-        ev[ENVI_SKIP] = rs;  // an env that resets in this call does not step
-        ev[ENVI_DONE] = 0;
-        if (rs) s_misc[0] = 1;
+    if constexpr (Cfg::kE != 0) {
+        // Static build: every DMA destination is contiguous in LDS and every source chunk is a whole
+        // number of 16-byte pieces, so the chunk is ONE linear stream — thread t moves LDS piece t;
+        // its HBM source is picked from the segment table (all pointers fetched in one scalar batch).
+        static_assert((Cfg::kE * Cfg::kN) % 4 == 0 && (Cfg::kE * Cfg::kQ) % 4 == 0 && Cfg::kE % 4 == 0, "chunk not 16-byte granular");
+        static_assert((Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0, "shelf chunk not 16-byte granular");
+        const char *src[12] = {
+            reinterpret_cast<const char *>(g_shadow + (size_t)e0 * HW),
+            reinterpret_cast<const char *>(p.ax + (size_t)e0 * N), reinterpret_cast<const char *>(p.ay + (size_t)e0 * N),
+            reinterpret_cast<const char *>(p.adir + (size_t)e0 * N), reinterpret_cast<const char *>(p.acarry + (size_t)e0 * N),
+            reinterpret_cast<const char *>(p.adeliv + (size_t)e0 * N),
+            reinterpret_cast<const char *>((op == OP_STEP ? p.actions : p.ax) + (size_t)e0 * N),
+            reinterpret_cast<const char *>(p.queue + (size_t)e0 * Q), reinterpret_cast<const char *>(p.highway_bits),
+            reinterpret_cast<const char *>(p.steps + e0), reinterpret_cast<const char *>(p.inactive + e0),
+            reinterpret_cast<const char *>(flag_src + e0)};
+        const int seg[13] = {lo.gs, lo.ax, lo.ay, lo.dir, lo.carry, lo.deliv, lo.act, lo.queue, lo.hw,
+                             lo.dsteps, lo.dinact, lo.dflag, lo.dma_end};  // dword offsets, all multiples of 4
+        const int pieces = (lo.dma_end - lo.gs) >> 2;
+        for (int b = wave * 64; b < pieces; b += nw * 64) {  // wave-uniform
+            const int t = b + lane;
+            const char *g = src[0] + (size_t)t * 16;
+#pragma unroll
+            for (int k = 1; k < 12; ++k)
+                if (t >= ((seg[k] - seg[0]) >> 2)) g = src[k] + (size_t)(t - ((seg[k] - seg[0]) >> 2)) * 16;
+            if (t < pieces) lds_dma_b128(g, smem + lo.gs + 4 * b);
+        }
+        // (rounding pieces at the tail of hw / dflag read a few bytes past the logical end of their
+        //  source; both live inside the engine's slab, whose sub-buffers are padded)
+        RW_MARK(TL_DMA_ISSUED);
+        RW_MARK(TL_ENV_LOADED);
+        __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
+        const uint8_t *s_dflag = reinterpret_cast<const uint8_t *>(smem + lo.dflag);
+        for (int e = tid; e < ne; e += T) {
+            int32_t *ev = s_envi + e * ENVI_W;
+            const int rs = (op == OP_OBS) ? 0 : (int)s_dflag[e];
+            ev[ENVI_STEPS] = smem[lo.dsteps + e];
+            ev[ENVI_INACTIVE] = smem[lo.dinact + e];
+            ev[ENVI_RESET] = rs;
+            ev[ENVI_SKIP] = rs;
+            ev[ENVI_DONE] = 0;
+            if (rs) s_misc[0] = 1;
+        }
+        lds_barrier();
+    } else {
+        dma_in(smem + lo.gs, reinterpret_cast<const int32_t *>(g_shadow + (size_t)e0 * HW),
+               (ne * HW * (int)sizeof(CellT) + 3) >> 2, tid, T);
+        dma_in(s_ax, p.ax + (size_t)e0 * N, nea, tid, T);
+        dma_in(s_ay, p.ay + (size_t)e0 * N, nea, tid, T);
+        dma_in(s_dir, p.adir + (size_t)e0 * N, nea, tid, T);
+        dma_in(s_carry, p.acarry + (size_t)e0 * N, nea, tid, T);
+        dma_in(s_deliv, p.adeliv + (size_t)e0 * N, nea, tid, T);
+        dma_in(s_queue, p.queue + (size_t)e0 * Q, ne * Q, tid, T);
+        if (op == OP_STEP) dma_in(s_act, p.actions + (size_t)e0 * N, nea, tid, T);
+        dma_in(smem + lo.hw, reinterpret_cast<const int32_t *>(p.highway_bits), (HW + 31) / 32, tid, T);
+        RW_MARK(TL_DMA_ISSUED);
+        lds_barrier();  // orders the s_misc clear above before the flag writes below
+        for (int e = tid; e < ne; e += T) {
+            int32_t *ev = s_envi + e * ENVI_W;
+            const int rs = (op == OP_OBS) ? 0 : (int)flag_src[e0 + e];
+            ev[ENVI_STEPS] = p.steps[e0 + e];
+            ev[ENVI_INACTIVE] = p.inactive[e0 + e];
+            ev[ENVI_RESET] = rs;
+            ev[ENVI_SKIP] = rs;  // an env that resets in this call does not step
+            ev[ENVI_DONE] = 0;
+            if (rs) s_misc[0] = 1;
+        }
+        RW_MARK(TL_ENV_LOADED);
+        __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
     }
-    RW_MARK(TL_ENV_LOADED);
-    __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
     RW_MARK(TL_LOADED);
 
     // ---------------------------------------------------------------- AG: per-agent phases, wave-local
     // Lane -> (env group g, agent a): all N agents of an env sit in one wavefront, so the sub-phases
     // below exchange data through LDS under wave_sync() only.
-    const int G = Cfg::kN ? 64 / Cfg::kN : p.groups_per_wave;
+    const int G = Cfg::kN ? 64 / (Cfg::kN ? Cfg::kN : 1) : p.groups_per_wave;
     for (int eb = wave * G; eb < ne; eb += nw * G) {  // wave-uniform
         const int g = rw_div18(lane, mN), a_idx = lane - g * N;
         const bool mine = (g < G) && (eb + g < ne);
@@ -277,7 +328,6 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
         const int base = e * N, i = base + (mine ? a_idx : 0);
         CellT *gS = s_gs + e * HW;
         uint8_t *gA = s_ga + e * HW;
-        int32_t *claim = s_claim + e * HW;
         int32_t *ev = s_envi + e * ENVI_W;
         const int ge = e0 + e;  // global env index
         const bool stepping = (op == OP_STEP) && mine && !ev[ENVI_SKIP];
@@ -313,7 +363,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
             }
             // successor on the chain: agent index on the target cell, -1 empty, -2 == i is stationary
             nxt = (tg == st) ? -2 : ((ag_tg & 0x7f) - 1);
-            s_tgt[i] = tg;
+            s_tgt[i] = (nxt == -2) ? -1 : tg;  // contested-cell key: only movers compete
             s_nxt[i] = nxt;
         }
         wave_sync();
@@ -328,13 +378,17 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
         }
         wave_sync();
         // ------------------------------------------------------------ P2b: winner per contested cell
-        int prio = 0;
-        if (stepping && nxt != -2) {  // larger depth wins, then the LOWER agent id
-            prio = (s_depth[i] << 8) | (255 - a_idx);
-            atomicMax(&claim[tg], prio);
+        if (stepping) {  // larger follower depth wins, then the LOWER agent id
+            int w = 1;
+            if (nxt != -2) {
+                const int dme = s_depth[i];
+                for (int k = 0; k < N; ++k) {
+                    const int tk = s_tgt[base + k], dk = s_depth[base + k];
+                    if (tk == tg && k != a_idx && (dk > dme || (dk == dme && k < a_idx))) w = 0;
+                }
+            }
+            s_win[i] = w;
         }
-        wave_sync();
-        if (stepping) s_win[i] = (nxt == -2) ? 1 : (claim[tg] == prio ? 1 : 0);
         wave_sync();
         // ------------------------------------------------------------ P2c + P3: commit, apply (:871-899)
         bool moved = false;
@@ -377,7 +431,11 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
                 }
             }
             s_ax[i] = x; s_ay[i] = y; s_dir[i] = d; s_carry[i] = carry; s_deliv[i] = deliv;
+        }
+        if (mine) {  // every agent of the chunk: reward slot and float coordinates for the observation
             s_rew[i] = rew;
+            s_fx[i] = coordf(0, x);
+            s_fy[i] = coordf(1, y);
         }
         wave_sync();
         if (stepping) {  // set phase (also refreshes the loaded flag after a pick-up / drop)
@@ -537,6 +595,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
             p.ax[gi] = s_ax[i]; p.ay[gi] = s_ay[i]; p.adir[gi] = s_dir[i];
             p.acarry[gi] = 0; p.adeliv[gi] = 0;
             p.rewards[gi] = s_rew[i];
+            s_fx[i] = coordf(0, s_ax[i]);
+            s_fy[i] = coordf(1, s_ay[i]);
             const uint32_t self = (2u << s_dir[i]) | (on_highway(s_ay[i] * W + s_ax[i]) ? 32u : 0u);
             const int bit = i * L + 2, wd = bit >> 5, sh = bit & 31;
             atomicOr(&s_obits[wd], self << sh);
@@ -559,22 +619,40 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
     // ---------------------------------------------------------------- P7: observation bits (:598-674)
     // One contiguous bit string per workgroup: bit (i*L + k) == obs[agent i][k] for k >= 2; the two
     // coordinate slots k = 0,1 stay 0 here and are filled in as floats during expansion.
-    for (int w = tid; w < nea * CELLS; w += T) {
-        const int i = w / CELLS, cidx = w - i * CELLS;
-        const int e = rw_div18(i, mN);
-        const int dy = cidx / WIN - R, dx = cidx % WIN - R;
-        const int x = s_ax[i] + dx, y = s_ay[i] + dy;
-        uint32_t code = 2u;  // empty / off-map cell: has_agent 0, direction one-hot [1,0,0,0] (:659)
-        if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
-            const int c = e * HW + y * W + x;
-            const int ida = s_ga[c] & 0x7f, ids = s_gs[c];
-            if (ida) code = 1u | (2u << s_dir[e * N + ida - 1]);
-            if (ids) code |= 32u | (((s_req[e * SW + (ids >> 5)] >> (ids & 31)) & 1u) << 6);
+    {
+        constexpr int KC = 4;  // codes gathered per thread before any LDS atomic: the reads of all KC items overlap
+        const int total = nea * CELLS;
+        for (int w0 = tid; w0 < total; w0 += KC * T) {
+            uint32_t code[KC];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int w = w0 + k * T;
+                code[k] = 2u;  // empty / off-map cell: has_agent 0, direction one-hot [1,0,0,0] (:659)
+                if (w < total) {
+                    const int i = w / CELLS, cidx = w - i * CELLS;
+                    const int e = rw_div18(i, mN);
+                    const int dy = cidx / WIN - R, dx = cidx % WIN - R;
+                    const int x = s_ax[i] + dx, y = s_ay[i] + dy;
+                    if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+                        const int c = e * HW + y * W + x;
+                        const int ida = s_ga[c] & 0x7f, ids = s_gs[c];
+                        if (ida) code[k] = 1u | (2u << s_dir[e * N + ida - 1]);
+                        if (ids) code[k] |= 32u | (((s_req[e * SW + (ids >> 5)] >> (ids & 31)) & 1u) << 6);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int w = w0 + k * T;
+                if (w < total) {
+                    const int i = w / CELLS, cidx = w - i * CELLS;
+                    const int bit = i * L + 8 + 7 * cidx;
+                    const int wd = bit >> 5, sh = bit & 31;
+                    atomicOr(&s_obits[wd], code[k] << sh);
+                    if (sh > 25) atomicOr(&s_obits[wd + 1], code[k] >> (32 - sh));
+                }
+            }
         }
-        const int bit = i * L + 8 + 7 * cidx;
-        const int wd = bit >> 5, sh = bit & 31;
-        atomicOr(&s_obits[wd], code << sh);
-        if (sh > 25) atomicOr(&s_obits[wd + 1], code >> (32 - sh));
     }
     lds_barrier();
     RW_MARK(TL_OBS_BITS);
@@ -585,29 +663,23 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
         const int nf4 = nf >> 2;
         float *out = p.obs + (size_t)e0 * N * L;  // 16-byte aligned: e0 is a multiple of 4
         float4 *out4 = reinterpret_cast<float4 *>(out);
+#pragma unroll 8
         for (int q4 = tid; q4 < nf4; q4 += T) {
             const uint32_t nib = s_obits[q4 >> 3] >> ((q4 & 7) << 2);
-            float4 v;
-            v.x = (nib & 1u) ? 1.0f : 0.0f;
-            v.y = (nib & 2u) ? 1.0f : 0.0f;
-            v.z = (nib & 4u) ? 1.0f : 0.0f;
-            v.w = (nib & 8u) ? 1.0f : 0.0f;
             const int il = (4 * q4 + 3) / L;  // agent that owns the last element of this float4
-            const int pos = il * L - 4 * q4;  // where its k = 0 slot falls inside the float4
-            if ((unsigned)(pos + 1) <= 4u) {  // the float4 holds x and/or y of agent il
-                const float fx = coordf(0, s_ax[il]), fy = coordf(1, s_ay[il]);
-                if (pos == 0) { v.x = fx; v.y = fy; }
-                else if (pos == 1) { v.y = fx; v.z = fy; }
-                else if (pos == 2) { v.z = fx; v.w = fy; }
-                else if (pos == 3) { v.w = fx; }
-                else { v.x = fy; }
-            }
+            const int pos = il * L - 4 * q4;  // slot of that agent's x inside the float4 (its y is pos + 1)
+            const float fx = s_fx[il], fy = s_fy[il];
+            float4 v;
+            v.x = (pos == 0) ? fx : (pos == -1) ? fy : ((nib & 1u) ? 1.0f : 0.0f);
+            v.y = (pos == 1) ? fx : (pos == 0) ? fy : ((nib & 2u) ? 1.0f : 0.0f);
+            v.z = (pos == 2) ? fx : (pos == 1) ? fy : ((nib & 4u) ? 1.0f : 0.0f);
+            v.w = (pos == 3) ? fx : (pos == 2) ? fy : ((nib & 8u) ? 1.0f : 0.0f);
             out4[q4] = v;
         }
         for (int g = (nf4 << 2) + tid; g < nf; g += T) {  // < 4 leftover floats (partial last workgroup)
             const int i = g / L, k = g - i * L;
             out[g] = (k >= 2) ? (((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f)
-                              : coordf(k, k == 0 ? s_ax[i] : s_ay[i]);
+                              : (k == 0 ? s_fx[i] : s_fy[i]);
         }
     }
     RW_MARK(TL_OBS_STORED);
