@@ -72,7 +72,9 @@ def main():
     ap.add_argument("--env-id", default=ENV_ID)
     ap.add_argument("--envs-per-wg", type=int, default=0)
     ap.add_argument("--threads-per-wg", type=int, default=0)
-    ap.add_argument("--many", type=int, default=0, help="submit steps in chunks of this many via rw_step_many_device")
+    ap.add_argument("--many", type=int, default=0,
+                    help="fused rollout: submit steps in chunks of this many through rw_step_many_device (one launch per chunk, "
+                         "env chunk resident in LDS across the steps; open-loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -171,7 +173,8 @@ def main():
                 "envs_per_gpu": B, "n_agents": N, "obs_length": int(info.obs_length),
                 "grid": [int(info.grid_h), int(info.grid_w)],
                 "parallelism": f"env-shard x{world} (no collective)",
-                "submit": f"rw_step_many_device x{args.many}" if args.many else "rw_step_device per step",
+                "submit": f"rw_step_many_device x{args.many} (fused rollout, one launch per chunk)" if args.many
+                          else "rw_step_device per step (one launch per step, closed-loop capable)",
                 "envs_per_workgroup": int(info.envs_per_workgroup), "threads_per_workgroup": int(info.threads_per_workgroup),
                 "kernel_specialised": bool(info.specialised),
                 "device": info.device_name.decode(), "arch": info.arch_name.decode(),

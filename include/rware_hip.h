@@ -132,12 +132,20 @@ int rw_reset(rw_engine *eng, const uint64_t *seeds, const uint8_t *mask);
 int rw_step(rw_engine *eng, const int32_t *actions_host);
 int rw_step_device(rw_engine *eng, const int32_t *actions_dev);
 
-/* T consecutive steps from a device-resident action tape int32 [T][B][N]; one launch per step,
- * no host round trip in between (rollout API).  If `obs_tape` /
+/* T consecutive steps from a device-resident action tape int32 [T][B][N] in ONE kernel launch: each
+ * workgroup keeps its env chunk in LDS across the T steps, so per step only the actions are read and
+ * obs / rewards / terminated written (rollout API; open-loop by construction —
+ * the tape must exist before the launch).  Results are identical to T rw_step_device calls.  If `obs_tape` /
  * `reward_tape` / `terminated_tape` are non-NULL device pointers they receive every step's
  * outputs ([T][B][N][L] f32, [T][B][N] f32, [T][B] u8); otherwise only the last step's remain. */
 int rw_step_many_device(rw_engine *eng, const int32_t *actions_dev, int32_t n_steps,
                         float *obs_tape, float *reward_tape, uint8_t *terminated_tape);
+
+/* raw device memory for action / output tapes (callers without a GPU array library) */
+int rw_device_malloc(rw_engine *eng, size_t bytes, void **dev_ptr);
+int rw_device_free(rw_engine *eng, void *dev_ptr);
+int rw_copy_to_device(rw_engine *eng, void *dev_dst, const void *host_src, size_t bytes);
+int rw_copy_to_host(rw_engine *eng, void *host_dst, const void *dev_src, size_t bytes);
 
 /* recompute RW_BUF_OBS from the current state (after rw_write of state buffers) */
 int rw_refresh_obs(rw_engine *eng);

@@ -51,7 +51,8 @@ EXPORTS = (
     "rw_create", "rw_destroy", "rw_last_error", "rw_reset", "rw_step", "rw_step_device",
     "rw_step_many_device", "rw_refresh_obs", "rw_sync", "rw_get_buffer", "rw_read", "rw_write",
     "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
-    "rw_abi_version", "rw_debug_timeline",
+    "rw_abi_version", "rw_debug_timeline", "rw_device_malloc", "rw_device_free", "rw_copy_to_device",
+    "rw_copy_to_host",
 )
 
 _libs = {}
@@ -111,6 +112,10 @@ def load(path: str | None = None):
     lib.rw_event_elapsed_ms.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
     lib.rw_abi_version.argtypes = []
     lib.rw_debug_timeline.argtypes = [vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.rw_device_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.rw_device_free.argtypes = [vp, vp]
+    lib.rw_copy_to_device.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.rw_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t]
     for name in EXPORTS:
         if name != "rw_last_error":
             getattr(lib, name).restype = C.c_int
@@ -207,6 +212,37 @@ class Engine:
         self._check(self.lib.rw_step_many_device(self._h, C.c_void_p(int(dev_ptr)), int(n_steps),
                                                  C.c_void_p(int(obs_tape)), C.c_void_p(int(reward_tape)),
                                                  C.c_void_p(int(terminated_tape))))
+
+    def rollout_host(self, actions, want_obs=True):
+        """`T` fused steps (one launch) from a host action tape (T, B, N); returns host tapes
+        (obs (T,B,N,L) or None, rewards (T,B,N), terminated (T,B))."""
+        a = np.ascontiguousarray(actions, dtype=np.int32).reshape(-1, self.B, self.N)
+        T = a.shape[0]
+        obs = np.empty((T, self.B, self.N, self.L), np.float32) if want_obs else None
+        rew = np.empty((T, self.B, self.N), np.float32)
+        term = np.empty((T, self.B), np.uint8)
+        ptrs = []
+
+        def dev(nbytes):
+            p = C.c_void_p()
+            self._check(self.lib.rw_device_malloc(self._h, nbytes, C.byref(p)))
+            ptrs.append(p)
+            return p
+
+        try:
+            d_a = dev(a.nbytes)
+            self._check(self.lib.rw_copy_to_device(self._h, d_a, a.ctypes.data, a.nbytes))
+            d_o = dev(obs.nbytes) if want_obs else C.c_void_p(0)
+            d_r, d_t = dev(rew.nbytes), dev(term.nbytes)
+            self._check(self.lib.rw_step_many_device(self._h, d_a, T, d_o, d_r, d_t))
+            if want_obs:
+                self._check(self.lib.rw_copy_to_host(self._h, obs.ctypes.data, d_o, obs.nbytes))
+            self._check(self.lib.rw_copy_to_host(self._h, rew.ctypes.data, d_r, rew.nbytes))
+            self._check(self.lib.rw_copy_to_host(self._h, term.ctypes.data, d_t, term.nbytes))
+        finally:
+            for p in ptrs:
+                self.lib.rw_device_free(self._h, p)
+        return obs, rew, term
 
     def refresh_obs(self):
         self._check(self.lib.rw_refresh_obs(self._h))

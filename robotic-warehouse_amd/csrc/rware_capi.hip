@@ -39,6 +39,7 @@ struct rw_engine {
     int32_t *d_shelf_init = nullptr;
     uint8_t *d_mask = nullptr;
     void (*kernel)(const rw::Params, const int) = nullptr;  // the step kernel instance this engine launches
+    void (*kernel_rollout)(const rw::Params, const int) = nullptr;  // its fused multi-step (rollout) sibling
     bool specialised = false;
     void *slab = nullptr;      // the single device allocation behind every buffer below
     size_t shadow_off = 0;
@@ -74,20 +75,21 @@ int fail(rw_engine *eng, int code, const char *fmt, ...) {
 
 using step_kernel_t = void (*)(const rw::Params, const int);
 
-template <int R>
+template <int R, bool kRollout>
 step_kernel_t generic_kernel(bool wide) {
-    return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg>
-                : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg>;
+    return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg, kRollout>
+                : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg, kRollout>;
 }
 
 // Specialised builds for the BASELINE.json tasks at their default launch geometry:
 //   {H, W, N, Q, S, R}  ->  kernel with those shapes (and E, T) folded in at compile time.
 struct StaticEntry {
     int H, W, N, Q, S, R, E, T;
-    step_kernel_t fn;
+    step_kernel_t fn, fn_rollout;
 };
-#define RW_STATIC(H, W, N, Q, S, R, E, T) \
-    {H, W, N, Q, S, R, E, T, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>>}
+#define RW_STATIC(H, W, N, Q, S, R, E, T)                                                                   \
+    {H, W, N, Q, S, R, E, T, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true>}
 const StaticEntry kStatic[] = {
     RW_STATIC(11, 10, 2, 2, 32, 1, 16, 256),    // rware-tiny-2ag
     RW_STATIC(20, 10, 4, 4, 80, 1, 16, 256),    // rware-small-4ag (headline)
@@ -96,8 +98,8 @@ const StaticEntry kStatic[] = {
 };
 #undef RW_STATIC
 
-int launch(rw_engine *eng, const rw::Params &p, int op) {
-    hipLaunchKernelGGL(eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes, eng->stream, p, op);
+int launch(rw_engine *eng, const rw::Params &p, int op, bool rollout = false) {
+    hipLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes, eng->stream, p, op);
     RW_HIP(eng, hipGetLastError());
     return RW_OK;
 }
@@ -276,11 +278,11 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         }
     }
     switch (R) {
-        case 1: eng->kernel = generic_kernel<1>(eng->wide); break;
-        case 2: eng->kernel = generic_kernel<2>(eng->wide); break;
-        case 3: eng->kernel = generic_kernel<3>(eng->wide); break;
-        case 4: eng->kernel = generic_kernel<4>(eng->wide); break;
-        default: eng->kernel = generic_kernel<5>(eng->wide); break;
+        case 1: eng->kernel = generic_kernel<1, false>(eng->wide); eng->kernel_rollout = generic_kernel<1, true>(eng->wide); break;
+        case 2: eng->kernel = generic_kernel<2, false>(eng->wide); eng->kernel_rollout = generic_kernel<2, true>(eng->wide); break;
+        case 3: eng->kernel = generic_kernel<3, false>(eng->wide); eng->kernel_rollout = generic_kernel<3, true>(eng->wide); break;
+        case 4: eng->kernel = generic_kernel<4, false>(eng->wide); eng->kernel_rollout = generic_kernel<4, true>(eng->wide); break;
+        default: eng->kernel = generic_kernel<5, false>(eng->wide); eng->kernel_rollout = generic_kernel<5, true>(eng->wide); break;
     }
     for (const StaticEntry &se : kStatic) {
         const bool shape = se.H == H && se.W == W && se.N == N && se.Q == Q && se.S == S && se.R == R;
@@ -290,6 +292,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             E = se.E;
             T = se.T;
             eng->kernel = se.fn;
+            eng->kernel_rollout = se.fn_rollout;
             eng->specialised = true;
         }
     }
@@ -304,6 +307,9 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     if (eng->lds_bytes > 64 * 1024) {
         hipError_t lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(eng->kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->lds_bytes);
+        if (lds_err == hipSuccess)
+            lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(eng->kernel_rollout),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->lds_bytes);
         RW_HIP_C(lds_err);
     }
 
@@ -397,6 +403,8 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.truncated = (uint8_t *)eng->buf[RW_BUF_TRUNCATED].ptr;
     p.status = eng->d_status;
     p.timeline = nullptr;
+    p.n_steps = 1;
+    p.act_stride = p.obs_stride = p.rew_stride = p.term_stride = 0;
     *out = eng;
     return RW_OK;
 }
@@ -467,16 +475,16 @@ int rw_step_many_device(rw_engine *eng, const int32_t *actions_dev, int32_t n_st
     if (!eng || !actions_dev || n_steps < 0) return RW_ERR_INVALID_ARG;
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
     const size_t BN = (size_t)eng->prm.B * eng->prm.N;
-    for (int t = 0; t < n_steps; ++t) {
-        rw::Params p = eng->prm;
-        p.actions = actions_dev + (size_t)t * BN;
-        if (obs_tape) p.obs = obs_tape + (size_t)t * BN * eng->L;
-        if (reward_tape) p.rewards = reward_tape + (size_t)t * BN;
-        if (terminated_tape) p.terminated = terminated_tape + (size_t)t * eng->prm.B;
-        const int rc = launch(eng, p, rw::OP_STEP);
-        if (rc != RW_OK) return rc;
-    }
-    return RW_OK;
+    if (n_steps == 0) return RW_OK;
+    // ONE launch: the kernel keeps each workgroup's env chunk in LDS across the n_steps steps
+    rw::Params p = eng->prm;
+    p.actions = actions_dev;
+    p.n_steps = n_steps;
+    p.act_stride = (int64_t)BN;
+    if (obs_tape) { p.obs = obs_tape; p.obs_stride = (int64_t)(BN * eng->L); }
+    if (reward_tape) { p.rewards = reward_tape; p.rew_stride = (int64_t)BN; }
+    if (terminated_tape) { p.terminated = terminated_tape; p.term_stride = (int64_t)eng->prm.B; }
+    return launch(eng, p, rw::OP_STEP, /*rollout=*/true);
 }
 
 int rw_debug_timeline(rw_engine *eng, const int32_t *actions_dev, uint64_t *host_out, int32_t *n_workgroups, int32_t *n_marks) {
@@ -501,6 +509,37 @@ int rw_debug_timeline(rw_engine *eng, const int32_t *actions_dev, uint64_t *host
     }
     (void)hipFree(d);
     return rc;
+}
+
+int rw_device_malloc(rw_engine *eng, size_t bytes, void **dev_ptr) {
+    if (!eng || !dev_ptr) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    RW_HIP(eng, hipMalloc(dev_ptr, bytes ? bytes : 16));
+    return RW_OK;
+}
+
+int rw_device_free(rw_engine *eng, void *dev_ptr) {
+    if (!eng) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    RW_HIP(eng, hipStreamSynchronize(eng->stream));
+    if (dev_ptr) RW_HIP(eng, hipFree(dev_ptr));
+    return RW_OK;
+}
+
+int rw_copy_to_device(rw_engine *eng, void *dev_dst, const void *host_src, size_t bytes) {
+    if (!eng || (bytes && (!dev_dst || !host_src))) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    if (bytes) RW_HIP(eng, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, eng->stream));
+    RW_HIP(eng, hipStreamSynchronize(eng->stream));
+    return RW_OK;
+}
+
+int rw_copy_to_host(rw_engine *eng, void *host_dst, const void *dev_src, size_t bytes) {
+    if (!eng || (bytes && (!host_dst || !dev_src))) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    if (bytes) RW_HIP(eng, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, eng->stream));
+    RW_HIP(eng, hipStreamSynchronize(eng->stream));
+    return RW_OK;
 }
 
 int rw_refresh_obs(rw_engine *eng) {

@@ -85,6 +85,11 @@ struct Params {
     uint8_t *terminated, *truncated;  // [B]
     int32_t *status;            // [1] sticky error bits
     uint64_t *timeline;         // nullptr, or [n_wg][TL_MARKS] wall-clock stamps (rw_debug_timeline)
+    // fused rollout (rw_step_many_device): n_steps consecutive steps in ONE launch; the env chunk stays
+    // in LDS between steps, only actions are read and obs/rewards/terminated written per step.
+    // Strides are in elements per step (0 == every step writes the same buffer).
+    int32_t n_steps;
+    int64_t act_stride, obs_stride, rew_stride, term_stride;
 };
 enum : int { TL_START = 0, TL_ZEROED, TL_DMA_ISSUED, TL_ENV_LOADED, TL_LOADED, TL_AGENTS, TL_RESET, TL_OBS_BITS,
              TL_OBS_STORED, TL_END, TL_MARKS = 12 };
@@ -192,13 +197,15 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
     }
 }
 
-template <int R, typename CellT, typename Cfg>
+template <int R, typename CellT, typename Cfg, bool kRollout>
 __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const int op) {
     constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L = 8 + 7 * CELLS, OW = (L + 31) / 32;
     extern __shared__ __align__(16) int32_t smem[];
 
-    const int tid = threadIdx.x, T = Cfg::kT ? Cfg::kT : (int)blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+    int tid = threadIdx.x;
+    const int T = Cfg::kT ? Cfg::kT : (int)blockDim.x;
+    int lane = tid & 63, wave = tid >> 6;
+    const int nw = T >> 6;
     const int E = Cfg::kE ? Cfg::kE : p.envs_per_wg;
     const int e0 = blockIdx.x * E;
     const int ne = Cfg::kE ? E : min(E, p.B - e0);  // the static kernels are only launched with B % E == 0
@@ -317,6 +324,35 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
     }
     RW_MARK(TL_LOADED);
 
+    // kRollout == false is the single-step kernel (rw_step / rw_reset / rw_refresh_obs): no loop at all.
+    const int n_steps = (kRollout && op == OP_STEP) ? p.n_steps : 1;
+    for (int t = 0; t < n_steps; ++t) {  // fused rollout: one iteration per env step
+    if (kRollout) {
+        // Re-derive the thread coordinates inside the loop from an opaque copy: otherwise LICM hoists every
+        // tid-derived address of the unrolled phases out of the step loop and keeps them live across it
+        // (200+ VGPRs, half the occupancy).
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+        wave = tid >> 6;
+    }
+    const int32_t *act_t = p.actions + (size_t)t * p.act_stride;
+    float *obs_t = p.obs + (size_t)t * p.obs_stride;
+    float *rew_t = p.rewards + (size_t)t * p.rew_stride;
+    uint8_t *term_t = p.terminated + (size_t)t * p.term_stride;
+    if (t > 0) {  // the chunk is already in LDS: recycle the scratch, roll the autoreset flags forward
+        lds_barrier();  // the previous step's expansion has finished reading the bit string
+        clear_scratch();
+        lds_barrier();
+        for (int e = tid; e < ne; e += T) {
+            int32_t *ev = s_envi + e * ENVI_W;
+            const int rs = (p.autoreset == AR_NEXT_STEP) ? ev[ENVI_DONE] : 0;
+            ev[ENVI_RESET] = rs;
+            ev[ENVI_SKIP] = rs;
+            ev[ENVI_DONE] = 0;
+            if (rs) s_misc[0] = 1;
+        }
+        lds_barrier();
+    }
     // ---------------------------------------------------------------- AG: per-agent phases, wave-local
     // Lane -> (env group g, agent a): all N agents of an env sit in one wavefront, so the sub-phases
     // below exchange data through LDS under wave_sync() only.
@@ -335,7 +371,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
         int x = 0, y = 0, d = 0, carry = 0, deliv = 0, a = ACT_NOOP;
         if (mine) {
             x = s_ax[i]; y = s_ay[i]; d = s_dir[i]; carry = s_carry[i]; deliv = s_deliv[i];
-            if (stepping) a = s_act[i];
+            if (stepping) a = (t == 0) ? s_act[i] : act_t[(size_t)ge * N + a_idx];
         }
         const int st = y * W + x;
         if (mine && !ev[ENVI_RESET]) gA[st] = (uint8_t)((a_idx + 1) | (carry ? 0x80 : 0));
@@ -503,7 +539,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
                 p.adir[(size_t)ge * N + a_idx] = d;
                 p.acarry[(size_t)ge * N + a_idx] = carry;
                 p.adeliv[(size_t)ge * N + a_idx] = s_deliv[i];
-                p.rewards[(size_t)ge * N + a_idx] = s_rew[i];
+                rew_t[(size_t)ge * N + a_idx] = s_rew[i];
                 if (moved) {  // patch the exported int32 grid and the shadow at the two cells that changed
                     int32_t *hA = p.grid + (size_t)ge * 2 * HW, *hS = hA + HW;
                     hA[st] = gA[st] & 0x7f;
@@ -519,7 +555,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
                 if (a_idx == 0) {
                     p.steps[ge] = ev[ENVI_STEPS];
                     p.inactive[ge] = ev[ENVI_INACTIVE];
-                    p.terminated[ge] = (uint8_t)ev[ENVI_DONE];
+                    term_t[ge] = (uint8_t)ev[ENVI_DONE];
                     p.truncated[ge] = 0;  // the reference never truncates (:942)
                     p.need_reset[ge] = (uint8_t)((p.autoreset == AR_NEXT_STEP) ? ev[ENVI_DONE] : 0);
                 }
@@ -594,7 +630,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
             const size_t gi = (size_t)e0 * N + i;
             p.ax[gi] = s_ax[i]; p.ay[gi] = s_ay[i]; p.adir[gi] = s_dir[i];
             p.acarry[gi] = 0; p.adeliv[gi] = 0;
-            p.rewards[gi] = s_rew[i];
+            rew_t[gi] = s_rew[i];
             s_fx[i] = coordf(0, s_ax[i]);
             s_fy[i] = coordf(1, s_ay[i]);
             const uint32_t self = (2u << s_dir[i]) | (on_highway(s_ay[i] * W + s_ax[i]) ? 32u : 0u);
@@ -608,7 +644,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
             for (int k = 0; k < Q; ++k) p.queue[(size_t)(e0 + e) * Q + k] = s_queue[e * Q + k];
             p.steps[e0 + e] = 0;
             p.inactive[e0 + e] = 0;
-            p.terminated[e0 + e] = (uint8_t)ev[ENVI_DONE];
+            term_t[e0 + e] = (uint8_t)ev[ENVI_DONE];
             p.truncated[e0 + e] = 0;
             p.need_reset[e0 + e] = 0;
         }
@@ -661,7 +697,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
     {
         const int nf = nea * L;
         const int nf4 = nf >> 2;
-        float *out = p.obs + (size_t)e0 * N * L;  // 16-byte aligned: e0 is a multiple of 4
+        float *out = obs_t + (size_t)e0 * N * L;  // 16-byte aligned: e0 is a multiple of 4
         float4 *out4 = reinterpret_cast<float4 *>(out);
 #pragma unroll 8
         for (int q4 = tid; q4 < nf4; q4 += T) {
@@ -683,6 +719,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
         }
     }
     RW_MARK(TL_OBS_STORED);
+    }  // fused-rollout step loop
     RW_MARK(TL_END);
 #undef RW_MARK
 }

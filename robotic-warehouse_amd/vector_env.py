@@ -194,6 +194,19 @@ class WarehouseVecEnv(_VectorEnvBase):
         trunc = self._gather("truncated").astype(bool)
         return obs, rew, term, trunc, {}
 
+    def rollout(self, actions, want_obs=True):
+        """Open-loop rollout: `actions` (T, B, N) -> (obs (T,B,N,L), rewards (T,B,N), terminated (T,B)).
+        One fused kernel launch per shard (`rw_step_many_device`): the env chunk stays in LDS across
+        the T steps.  Bit-identical to T calls of step() with the same actions."""
+        a = np.asarray(actions)
+        if a.ndim != 3 or a.shape[1:] != (self.num_envs, self.n_agents):
+            raise AssertionError(f"expected (T, {self.num_envs}, {self.n_agents}) actions, got {a.shape}")
+        if a.size and (a.min() < 0 or a.max() > 4):
+            raise ValueError("invalid Action in tape")
+        parts = [eng.rollout_host(a[:, lo:hi], want_obs) for eng, (lo, hi) in zip(self.engines, self._bounds)]
+        cat = lambda k: parts[0][k] if len(parts) == 1 else np.concatenate([p[k] for p in parts], axis=1)
+        return (cat(0) if want_obs else None), cat(1), cat(2).astype(bool)
+
     def sync(self):
         """Wait for enqueued work; raises ValueError if a device-side action was out of range."""
         for eng in self.engines:

@@ -129,3 +129,35 @@ def test_sharded_env_equals_unsharded():
     for k in s1:
         assert np.array_equal(s1[k], s2[k]), k
     one.close(); two.close()
+
+
+@pytest.mark.parametrize("env_id,extra,B,geom,mode", [
+    ("rware-small-4ag-v1", {"max_steps": 13}, 32, (0, 0), "next_step"),        # specialised kernel
+    ("rware-tiny-2ag-v1", {"max_steps": 9}, 7, (4, 64), "same_step"),          # generic, ragged batch
+    ("rware-medium-6ag-hard-v1", {"max_steps": 11, "reward_type": 0}, 16, (0, 0), "next_step"),
+    ("rware-large-16ag-v1", {"sensor_range": 2, "max_steps": 10}, 5, (4, 128), "disabled"),
+])
+def test_fused_rollout_equals_stepwise_oracle(env_id, extra, B, geom, mode):
+    """rw_step_many_device (one launch, env chunk resident in LDS across steps) == T single steps."""
+    kw = rware_amd.env_kwargs(env_id)
+    kw.update(extra)
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, autoreset_mode=mode, envs_per_workgroup=geom[0],
+                                    threads_per_workgroup=geom[1], **kw)
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=3)[0], orc.reset(seed=3))
+    T = 37
+    acts = np.random.default_rng(0).choice(5, size=(T, B, kw["n_agents"]), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+    obs, rew, term = env.rollout(acts)
+    for t in range(T):
+        o2, r2, d2 = orc.step_autoreset(acts[t], mode)
+        assert np.array_equal(obs[t], o2) and np.array_equal(rew[t], r2) and np.array_equal(term[t], d2.astype(bool)), t
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    # and the stepwise path continues from the fused one
+    a = acts[0]
+    o, r, d, _, _ = env.step(a)
+    o2, r2, d2 = orc.step_autoreset(a, mode)
+    assert np.array_equal(o, o2) and np.array_equal(r, r2)
+    env.close()

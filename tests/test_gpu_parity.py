@@ -150,3 +150,30 @@ def test_full_size_headline_batch_properties():
     for k in so:
         assert np.array_equal(st[k][sub], so[k]), k
     env.close()
+
+
+@pytest.mark.parametrize("env_id,extra,B,mode", [
+    ("rware-small-4ag-v1", {}, 4096, "next_step"),
+    ("rware-tiny-2ag-v1", {"max_steps": 50}, 1000, "same_step"),
+    ("rware-medium-6ag-hard-v1", {"reward_type": 0, "max_steps": 70}, 2048, "next_step"),
+    ("rware-large-16ag-v1", {"sensor_range": 2}, 256, "next_step"),
+])
+def test_fused_rollout_matches_oracle(env_id, extra, B, mode):
+    """rw_step_many_device: T steps in one launch with the env chunk resident in LDS == T oracle steps."""
+    kw = rware_amd.env_kwargs(env_id)
+    kw.update(extra)
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    env = rware_amd.WarehouseVecEnv(B, autoreset_mode=mode, **kw)
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=77)[0], orc.reset(seed=77))
+    T = 530 if not extra.get("max_steps") else 160
+    acts = np.random.default_rng(9).choice(5, size=(T, B, kw["n_agents"]), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+    obs, rew, term = env.rollout(acts)
+    for t in range(T):
+        o2, r2, d2 = orc.step_autoreset(acts[t], mode)
+        assert np.array_equal(rew[t], r2) and np.array_equal(term[t], d2.astype(bool)), t
+        assert np.array_equal(obs[t], o2), t
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    env.close()
