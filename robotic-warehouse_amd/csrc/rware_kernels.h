@@ -135,7 +135,7 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
     l.fx = o;     o += en;
     l.fy = o;     o += en;
     l.req = o;    o += rw_up4(E * SW);
-    l.obits = o;  o += rw_up4(E * N * OW + 1);  // one contiguous string of E*N*L bits (+1 spill word)
+    l.obits = o;  o += rw_up4(E * N * OW + 4);  // one contiguous string of E*N*L bits (+ spill words)
     l.envi = o;   o += rw_up4(E * ENVI_W);
     l.misc = o;   o += 4;
     l.total = o;
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
         const int nz = (lo.zero_end - lo.ga) >> 2;
         for (int i = tid; i < nz; i += T) z[i] = int4{0, 0, 0, 0};
         for (int i = tid; i < nea; i += T) s_depth[i] = 0;
-        for (int i = tid; i < nea * OW + 1; i += T) s_obits[i] = 0u;
+        for (int i = tid; i < nea * OW + 4; i += T) s_obits[i] = 0u;
         for (int i = tid; i < ne * SW; i += T) s_req[i] = 0u;
         if (tid == 0) s_misc[0] = 0;
     };
@@ -655,39 +655,48 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
     // ---------------------------------------------------------------- P7: observation bits (:598-674)
     // One contiguous bit string per workgroup: bit (i*L + k) == obs[agent i][k] for k >= 2; the two
     // coordinate slots k = 0,1 stay 0 here and are filled in as floats during expansion.
-    {
-        constexpr int KC = 4;  // codes gathered per thread before any LDS atomic: the reads of all KC items overlap
-        const int total = nea * CELLS;
-        for (int w0 = tid; w0 < total; w0 += KC * T) {
-            uint32_t code[KC];
+    // one thread per (agent, window row): the agent's position is read once, the row's WIN cells are
+    // gathered with independent LDS reads, and the row's 7*WIN bits go out in one or two LDS atomics
+    for (int w = tid; w < nea * WIN; w += T) {
+        const int i = w / WIN, row = w - i * WIN;
+        const int e = rw_div18(i, mN);
+        const int ax = s_ax[i], y = s_ay[i] + row - R;
+        const bool row_ok = (unsigned)y < (unsigned)H;
+        const int rowbase = e * HW + y * W;
+        int ida[WIN], ids[WIN];
 #pragma unroll
-            for (int k = 0; k < KC; ++k) {
-                const int w = w0 + k * T;
-                code[k] = 2u;  // empty / off-map cell: has_agent 0, direction one-hot [1,0,0,0] (:659)
-                if (w < total) {
-                    const int i = w / CELLS, cidx = w - i * CELLS;
-                    const int e = rw_div18(i, mN);
-                    const int dy = cidx / WIN - R, dx = cidx % WIN - R;
-                    const int x = s_ax[i] + dx, y = s_ay[i] + dy;
-                    if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
-                        const int c = e * HW + y * W + x;
-                        const int ida = s_ga[c] & 0x7f, ids = s_gs[c];
-                        if (ida) code[k] = 1u | (2u << s_dir[e * N + ida - 1]);
-                        if (ids) code[k] |= 32u | (((s_req[e * SW + (ids >> 5)] >> (ids & 31)) & 1u) << 6);
-                    }
-                }
-            }
+        for (int k = 0; k < WIN; ++k) {
+            const int x = ax + k - R;
+            const bool ok = row_ok && (unsigned)x < (unsigned)W;
+            ida[k] = ok ? (s_ga[rowbase + x] & 0x7f) : 0;
+            ids[k] = ok ? (int)s_gs[rowbase + x] : 0;
+        }
+        uint64_t bits = 0;  // 7 * WIN <= 77 bits for R <= 5: R <= 4 fits 64; R == 5 handled by the split below
+        uint32_t hi = 0;    // bits 64.. of the row (only R == 5)
 #pragma unroll
-            for (int k = 0; k < KC; ++k) {
-                const int w = w0 + k * T;
-                if (w < total) {
-                    const int i = w / CELLS, cidx = w - i * CELLS;
-                    const int bit = i * L + 8 + 7 * cidx;
-                    const int wd = bit >> 5, sh = bit & 31;
-                    atomicOr(&s_obits[wd], code[k] << sh);
-                    if (sh > 25) atomicOr(&s_obits[wd + 1], code[k] >> (32 - sh));
-                }
-            }
+        for (int k = 0; k < WIN; ++k) {
+            uint32_t code = 2u;  // empty / off-map cell: has_agent 0, direction one-hot [1,0,0,0] (:659)
+            if (ida[k]) code = 1u | (2u << s_dir[e * N + ida[k] - 1]);
+            if (ids[k]) code |= 32u | (((s_req[e * SW + (ids[k] >> 5)] >> (ids[k] & 31)) & 1u) << 6);
+            if (7 * k < 64) bits |= (uint64_t)code << (7 * k);
+            if (7 * k + 7 > 64) hi |= (7 * k >= 64) ? (code << (7 * k - 64)) : (code >> (64 - 7 * k));
+        }
+        const int bit = i * L + 8 + 7 * WIN * row;
+        const int wd = bit >> 5, sh = bit & 31;
+        // the row occupies bits [sh, sh + 7*WIN) of the window starting at word wd
+        const uint32_t lo32 = (uint32_t)bits, mid32 = (uint32_t)(bits >> 32);
+        atomicOr(&s_obits[wd], lo32 << sh);
+        if (sh + 7 * WIN > 32) {
+            const uint32_t w1 = (sh ? (lo32 >> (32 - sh)) : 0u) | (mid32 << sh);
+            atomicOr(&s_obits[wd + 1], w1);
+        }
+        if (sh + 7 * WIN > 64) {
+            const uint32_t w2 = (sh ? (mid32 >> (32 - sh)) : 0u) | (hi << sh);
+            atomicOr(&s_obits[wd + 2], w2);
+        }
+        if (7 * WIN > 64 && sh + 7 * WIN > 96) {
+            const uint32_t w3 = sh ? (hi >> (32 - sh)) : 0u;
+            atomicOr(&s_obits[wd + 3], w3);
         }
     }
     lds_barrier();
@@ -699,18 +708,39 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
         const int nf4 = nf >> 2;
         float *out = obs_t + (size_t)e0 * N * L;  // 16-byte aligned: e0 is a multiple of 4
         float4 *out4 = reinterpret_cast<float4 *>(out);
+        auto expand = [&](int q4) -> float4 {  // float4 #q4 of the chunk == nibble #q4 of the bit string
+            const uint32_t nib = s_obits[q4 >> 3] >> ((q4 & 7) << 2);
+            float4 v;
+            v.x = (nib & 1u) ? 1.0f : 0.0f;
+            v.y = (nib & 2u) ? 1.0f : 0.0f;
+            v.z = (nib & 4u) ? 1.0f : 0.0f;
+            v.w = (nib & 8u) ? 1.0f : 0.0f;
+            return v;
+        };
+        // bulk pass: every float4 that holds no coordinate slot (all but ~2 in 18)
 #pragma unroll 8
         for (int q4 = tid; q4 < nf4; q4 += T) {
-            const uint32_t nib = s_obits[q4 >> 3] >> ((q4 & 7) << 2);
             const int il = (4 * q4 + 3) / L;  // agent that owns the last element of this float4
             const int pos = il * L - 4 * q4;  // slot of that agent's x inside the float4 (its y is pos + 1)
-            const float fx = s_fx[il], fy = s_fy[il];
-            float4 v;
-            v.x = (pos == 0) ? fx : (pos == -1) ? fy : ((nib & 1u) ? 1.0f : 0.0f);
-            v.y = (pos == 1) ? fx : (pos == 0) ? fy : ((nib & 2u) ? 1.0f : 0.0f);
-            v.z = (pos == 2) ? fx : (pos == 1) ? fy : ((nib & 4u) ? 1.0f : 0.0f);
-            v.w = (pos == 3) ? fx : (pos == 2) ? fy : ((nib & 8u) ? 1.0f : 0.0f);
-            out4[q4] = v;
+            if ((unsigned)(pos + 1) > 4u) out4[q4] = expand(q4);
+        }
+        // coordinate pass: per agent, the one or two float4s that hold its x (element i*L) and y (i*L + 1)
+        for (int i = tid; i < nea; i += T) {
+            const int g = i * L, q4 = g >> 2, pos = g & 3;
+            const float fx = s_fx[i], fy = s_fy[i];
+            if (q4 < nf4) {
+                float4 v = expand(q4);
+                if (pos == 0) { v.x = fx; v.y = fy; }
+                else if (pos == 1) { v.y = fx; v.z = fy; }
+                else if (pos == 2) { v.z = fx; v.w = fy; }
+                else { v.w = fx; }
+                out4[q4] = v;
+            }
+            if (pos == 3 && q4 + 1 < nf4) {
+                float4 v = expand(q4 + 1);
+                v.x = fy;
+                out4[q4 + 1] = v;
+            }
         }
         for (int g = (nf4 << 2) + tid; g < nf; g += T) {  // < 4 leftover floats (partial last workgroup)
             const int i = g / L, k = g - i * L;
