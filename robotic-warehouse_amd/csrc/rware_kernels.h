@@ -100,7 +100,7 @@ struct LdsLayout {
     // LDS-DMA stream): shelf layer, agent SoA, actions, queue, highway bitmap, per-env counters/flags
     int gs, ax, ay, dir, carry, deliv, act, queue, hw, dsteps, dinact, dflag, dma_end;
     int ga, zero_end;  // cleared every launch
-    int tgt, nxt, depth, win, rew, fx, fy, req, obits, envi, misc, total;
+    int tgt, nxt, depth, win, rew, mv, fx, fy, req, obits, envi, misc, total;
 };
 enum : int { ENVI_STEPS = 0, ENVI_INACTIVE = 1, ENVI_RESET = 2, ENVI_DONE = 3, ENVI_SKIP = 4, ENVI_W = 8 };
 
@@ -132,6 +132,7 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
     l.depth = o;  o += en;
     l.win = o;    o += en;
     l.rew = o;    o += en;
+    l.mv = o;     o += en;
     l.fx = o;     o += en;
     l.fy = o;     o += en;
     l.req = o;    o += rw_up4(E * SW);
@@ -226,6 +227,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
     int32_t *s_carry = smem + lo.carry, *s_deliv = smem + lo.deliv, *s_act = smem + lo.act;
     int32_t *s_tgt = smem + lo.tgt, *s_nxt = smem + lo.nxt, *s_depth = smem + lo.depth, *s_win = smem + lo.win;
     float *s_rew = reinterpret_cast<float *>(smem + lo.rew);
+    int32_t *s_mv = smem + lo.mv;
     float *s_fx = reinterpret_cast<float *>(smem + lo.fx), *s_fy = reinterpret_cast<float *>(smem + lo.fy);
     int32_t *s_queue = smem + lo.queue;
     uint32_t *s_req = reinterpret_cast<uint32_t *>(smem + lo.req);
@@ -468,11 +470,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
             }
             s_ax[i] = x; s_ay[i] = y; s_dir[i] = d; s_carry[i] = carry; s_deliv[i] = deliv;
         }
-        if (mine) {  // every agent of the chunk: reward slot and float coordinates for the observation
-            s_rew[i] = rew;
-            s_fx[i] = coordf(0, x);
-            s_fy[i] = coordf(1, y);
-        }
+        if (mine) s_rew[i] = rew;  // every agent of the chunk gets its reward slot
         wave_sync();
         if (stepping) {  // set phase (also refreshes the loaded flag after a pick-up / drop)
             gA[moved ? tg : st] = (uint8_t)((a_idx + 1) | (carry ? 0x80 : 0));
@@ -530,47 +528,13 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
             }
         }
         wave_sync();
-        // ------------------------------------------------------------ write-back from the agent lanes
-        // (envs flagged for reset are written by RS instead)
-        if (mine && !ev[ENVI_RESET]) {
-            if (stepping) {
-                p.ax[(size_t)ge * N + a_idx] = x;
-                p.ay[(size_t)ge * N + a_idx] = y;
-                p.adir[(size_t)ge * N + a_idx] = d;
-                p.acarry[(size_t)ge * N + a_idx] = carry;
-                p.adeliv[(size_t)ge * N + a_idx] = s_deliv[i];
-                rew_t[(size_t)ge * N + a_idx] = s_rew[i];
-                if (moved) {  // patch the exported int32 grid and the shadow at the two cells that changed
-                    int32_t *hA = p.grid + (size_t)ge * 2 * HW, *hS = hA + HW;
-                    hA[st] = gA[st] & 0x7f;
-                    hA[tg] = a_idx + 1;
-                    if (carry) {
-                        const CellT s_at_st = gS[st];
-                        hS[st] = s_at_st;
-                        hS[tg] = carry;
-                        g_shadow[(size_t)ge * HW + st] = s_at_st;
-                        g_shadow[(size_t)ge * HW + tg] = (CellT)carry;
-                    }
-                }
-                if (a_idx == 0) {
-                    p.steps[ge] = ev[ENVI_STEPS];
-                    p.inactive[ge] = ev[ENVI_INACTIVE];
-                    term_t[ge] = (uint8_t)ev[ENVI_DONE];
-                    p.truncated[ge] = 0;  // the reference never truncates (:942)
-                    p.need_reset[ge] = (uint8_t)((p.autoreset == AR_NEXT_STEP) ? ev[ENVI_DONE] : 0);
-                }
-            }
-            for (int k = a_idx; k < Q; k += N) {  // queue write-back + requested-shelf bitmap
+        // ------------------------------------------------------------ hand-off to the write-back roles
+        if (mine) s_mv[i] = (stepping && moved) ? (st | (tg << 16)) : -1;  // which two cells changed
+        if (mine && !ev[ENVI_RESET])  // requested-shelf bitmap of the (post-step) queue; RS builds it for reset envs
+            for (int k = a_idx; k < Q; k += N) {
                 const int sid = s_queue[e * Q + k];
-                if (stepping) p.queue[(size_t)ge * Q + k] = sid;
                 atomicOr(&s_req[e * SW + (sid >> 5)], 1u << (sid & 31));
             }
-            // self part of the observation, k = 2..7: carrying, one-hot direction, on_highway (:643-647)
-            const uint32_t self = (carry ? 1u : 0u) | (2u << d) | (on_highway(y * W + x) ? 32u : 0u);
-            const int bit = i * L + 2, wd = bit >> 5, sh = bit & 31;
-            atomicOr(&s_obits[wd], self << sh);
-            if (sh > 26) atomicOr(&s_obits[wd + 1], self >> (32 - sh));
-        }
     }
     lds_barrier();
     RW_MARK(TL_AGENTS);
@@ -651,6 +615,69 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params p, const i
         lds_barrier();
     }
     RW_MARK(TL_RESET);
+
+    // ---------------------------------------------------------------- WB: write-back, one role per wavefront
+    // The agent wave only resolved the step; the HBM write-back and the self part of the observation are
+    // four independent jobs, spread over the workgroup's wavefronts (envs flagged for reset were written by RS).
+    for (int role = wave; role < 4; role += nw) {  // wave-uniform
+        if (role == 0) {  // per-env counters and flags, request queue
+            if (op == OP_STEP)
+                for (int e = lane; e < ne; e += 64) {
+                    const int32_t *ev = s_envi + e * ENVI_W;
+                    if (ev[ENVI_RESET]) continue;
+                    const int ge = e0 + e;
+                    p.steps[ge] = ev[ENVI_STEPS];
+                    p.inactive[ge] = ev[ENVI_INACTIVE];
+                    term_t[ge] = (uint8_t)ev[ENVI_DONE];
+                    p.truncated[ge] = 0;  // the reference never truncates (:942)
+                    p.need_reset[ge] = (uint8_t)((p.autoreset == AR_NEXT_STEP) ? ev[ENVI_DONE] : 0);
+                    for (int k = 0; k < Q; ++k) p.queue[(size_t)ge * Q + k] = s_queue[e * Q + k];
+                }
+        } else if (role == 1) {  // agent SoA and rewards: the chunk is contiguous in every [B][N] array
+            if (op == OP_STEP)
+                for (int i = lane; i < nea; i += 64) {
+                    if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
+                    const size_t gi = (size_t)e0 * N + i;
+                    p.ax[gi] = s_ax[i];
+                    p.ay[gi] = s_ay[i];
+                    p.adir[gi] = s_dir[i];
+                    p.acarry[gi] = s_carry[i];
+                    p.adeliv[gi] = s_deliv[i];
+                    rew_t[gi] = s_rew[i];
+                }
+        } else if (role == 2) {  // patch the exported int32 grid and the shadow at the two cells a mover changed
+            if (op == OP_STEP)
+                for (int i = lane; i < nea; i += 64) {
+                    const int mv = s_mv[i];
+                    if (mv < 0) continue;
+                    const int e = rw_div18(i, mN);
+                    if (s_envi[e * ENVI_W + ENVI_RESET]) continue;
+                    const int st = mv & 0xffff, tg = mv >> 16, carry = s_carry[i];
+                    const size_t ge = (size_t)(e0 + e);
+                    int32_t *hA = p.grid + ge * 2 * HW, *hS = hA + HW;
+                    hA[st] = s_ga[e * HW + st] & 0x7f;
+                    hA[tg] = (i - e * N) + 1;
+                    if (carry) {
+                        const CellT s_at_st = s_gs[e * HW + st];
+                        hS[st] = s_at_st;
+                        hS[tg] = carry;
+                        g_shadow[ge * HW + st] = s_at_st;
+                        g_shadow[ge * HW + tg] = (CellT)carry;
+                    }
+                }
+        } else {  // self part of the observation, k = 2..7 (:643-647), and the float coordinates k = 0,1
+            for (int i = lane; i < nea; i += 64) {
+                if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
+                const int x = s_ax[i], y = s_ay[i];
+                s_fx[i] = coordf(0, x);
+                s_fy[i] = coordf(1, y);
+                const uint32_t self = (s_carry[i] ? 1u : 0u) | (2u << s_dir[i]) | (on_highway(y * W + x) ? 32u : 0u);
+                const int bit = i * L + 2, wd = bit >> 5, sh = bit & 31;
+                atomicOr(&s_obits[wd], self << sh);
+                if (sh > 26) atomicOr(&s_obits[wd + 1], self >> (32 - sh));
+            }
+        }
+    }
 
     // ---------------------------------------------------------------- P7: observation bits (:598-674)
     // One contiguous bit string per workgroup: bit (i*L + k) == obs[agent i][k] for k >= 2; the two
