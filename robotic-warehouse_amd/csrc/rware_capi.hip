@@ -38,8 +38,10 @@ struct rw_engine {
     uint32_t *d_highway_bits = nullptr;
     int32_t *d_shelf_init = nullptr;
     uint8_t *d_mask = nullptr;
-    void (*kernel)(const rw::Params, const int) = nullptr;  // the step kernel instance this engine launches
-    void (*kernel_rollout)(const rw::Params, const int) = nullptr;  // its fused multi-step (rollout) sibling
+    void (*kernel)(const rw::Params *, const rw::LaunchArgs) = nullptr;  // the step kernel instance this engine launches
+    void (*kernel_rollout)(const rw::Params *, const rw::LaunchArgs) = nullptr;  // its fused multi-step (rollout) sibling
+    rw::Params *d_prm = nullptr;  // device copy of `prm` (constant for the engine's lifetime)
+    rw::LaunchArgs la{};          // per-launch defaults: the engine's own output buffers
     bool specialised = false;
     void *slab = nullptr;      // the single device allocation behind every buffer below
     size_t shadow_off = 0;
@@ -73,7 +75,7 @@ int fail(rw_engine *eng, int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
-using step_kernel_t = void (*)(const rw::Params, const int);
+using step_kernel_t = void (*)(const rw::Params *, const rw::LaunchArgs);
 
 template <int R, bool kRollout>
 step_kernel_t generic_kernel(bool wide) {
@@ -98,8 +100,10 @@ const StaticEntry kStatic[] = {
 };
 #undef RW_STATIC
 
-int launch(rw_engine *eng, const rw::Params &p, int op, bool rollout = false) {
-    hipLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes, eng->stream, p, op);
+int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false) {
+    la.op = op;
+    hipLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
+                       eng->stream, (const rw::Params *)eng->d_prm, la);
     RW_HIP(eng, hipGetLastError());
     return RW_OK;
 }
@@ -395,16 +399,26 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.shelf_shadow = eng->d_shadow;
     p.rng = (uint64_t *)eng->buf[RW_BUF_RNG].ptr;
     p.need_reset = (uint8_t *)eng->buf[RW_BUF_NEED_RESET].ptr;
-    p.actions = (const int32_t *)eng->buf[RW_BUF_ACTIONS].ptr;
-    p.reset_mask = nullptr;
-    p.obs = (float *)eng->buf[RW_BUF_OBS].ptr;
-    p.rewards = (float *)eng->buf[RW_BUF_REWARDS].ptr;
-    p.terminated = (uint8_t *)eng->buf[RW_BUF_TERMINATED].ptr;
     p.truncated = (uint8_t *)eng->buf[RW_BUF_TRUNCATED].ptr;
     p.status = eng->d_status;
-    p.timeline = nullptr;
-    p.n_steps = 1;
-    p.act_stride = p.obs_stride = p.rew_stride = p.term_stride = 0;
+    rw::LaunchArgs &la = eng->la;
+    la.actions = (const int32_t *)eng->buf[RW_BUF_ACTIONS].ptr;
+    la.reset_mask = eng->d_mask;
+    la.obs = (float *)eng->buf[RW_BUF_OBS].ptr;
+    la.rewards = (float *)eng->buf[RW_BUF_REWARDS].ptr;
+    la.terminated = (uint8_t *)eng->buf[RW_BUF_TERMINATED].ptr;
+    la.timeline = nullptr;
+    la.op = rw::OP_STEP;
+    la.n_steps = 1;
+    la.act_stride = la.obs_stride = la.rew_stride = la.term_stride = 0;
+    // the constant block goes to device memory once; launches pass only a pointer to it
+    if (hipMalloc(&eng->d_prm, sizeof(rw::Params)) != hipSuccess ||
+        hipMemcpy(eng->d_prm, &eng->prm, sizeof(rw::Params), hipMemcpyHostToDevice) != hipSuccess) {
+        fail(eng, RW_ERR_HIP, "uploading the parameter block failed");
+        g_create_error = eng->err;
+        rw_destroy(eng);
+        return RW_ERR_HIP;
+    }
     *out = eng;
     return RW_OK;
 }
@@ -417,6 +431,7 @@ int rw_destroy(rw_engine *eng) {
     if (eng->d_highway_bits) (void)hipFree(eng->d_highway_bits);
     if (eng->d_shelf_init) (void)hipFree(eng->d_shelf_init);
     if (eng->d_mask) (void)hipFree(eng->d_mask);
+    if (eng->d_prm) (void)hipFree(eng->d_prm);
     if (eng->d_status) (void)hipFree(eng->d_status);
     for (auto &ev : eng->events)
         if (ev) (void)hipEventDestroy(ev);
@@ -443,23 +458,21 @@ int rw_reset(rw_engine *eng, const uint64_t *seeds, const uint8_t *mask) {
         RW_HIP(eng, hipMemcpyAsync(eng->buf[RW_BUF_RNG].ptr, h.data(), h.size() * 8, hipMemcpyHostToDevice, eng->stream));
         RW_HIP(eng, hipStreamSynchronize(eng->stream));
     }
-    rw::Params p = eng->prm;
     if (mask) {
         RW_HIP(eng, hipMemcpyAsync(eng->d_mask, mask, (size_t)B, hipMemcpyHostToDevice, eng->stream));
         RW_HIP(eng, hipStreamSynchronize(eng->stream));  // `mask` is caller-owned pageable memory
     } else {
         RW_HIP(eng, hipMemsetAsync(eng->d_mask, 1, (size_t)B, eng->stream));
     }
-    p.reset_mask = eng->d_mask;
-    return launch(eng, p, rw::OP_RESET);
+    return launch(eng, eng->la, rw::OP_RESET);
 }
 
 int rw_step_device(rw_engine *eng, const int32_t *actions_dev) {
     if (!eng || !actions_dev) return RW_ERR_INVALID_ARG;
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
-    rw::Params p = eng->prm;
-    p.actions = actions_dev;
-    return launch(eng, p, rw::OP_STEP);
+    rw::LaunchArgs la = eng->la;
+    la.actions = actions_dev;
+    return launch(eng, la, rw::OP_STEP);
 }
 
 int rw_step(rw_engine *eng, const int32_t *actions_host) {
@@ -467,7 +480,7 @@ int rw_step(rw_engine *eng, const int32_t *actions_host) {
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
     RW_HIP(eng, hipMemcpyAsync(eng->buf[RW_BUF_ACTIONS].ptr, actions_host, eng->buf[RW_BUF_ACTIONS].bytes,
                                hipMemcpyHostToDevice, eng->stream));
-    return launch(eng, eng->prm, rw::OP_STEP);
+    return launch(eng, eng->la, rw::OP_STEP);
 }
 
 int rw_step_many_device(rw_engine *eng, const int32_t *actions_dev, int32_t n_steps, float *obs_tape,
@@ -477,14 +490,14 @@ int rw_step_many_device(rw_engine *eng, const int32_t *actions_dev, int32_t n_st
     const size_t BN = (size_t)eng->prm.B * eng->prm.N;
     if (n_steps == 0) return RW_OK;
     // ONE launch: the kernel keeps each workgroup's env chunk in LDS across the n_steps steps
-    rw::Params p = eng->prm;
-    p.actions = actions_dev;
-    p.n_steps = n_steps;
-    p.act_stride = (int64_t)BN;
-    if (obs_tape) { p.obs = obs_tape; p.obs_stride = (int64_t)(BN * eng->L); }
-    if (reward_tape) { p.rewards = reward_tape; p.rew_stride = (int64_t)BN; }
-    if (terminated_tape) { p.terminated = terminated_tape; p.term_stride = (int64_t)eng->prm.B; }
-    return launch(eng, p, rw::OP_STEP, /*rollout=*/true);
+    rw::LaunchArgs la = eng->la;
+    la.actions = actions_dev;
+    la.n_steps = n_steps;
+    la.act_stride = (int64_t)BN;
+    if (obs_tape) { la.obs = obs_tape; la.obs_stride = (int64_t)(BN * eng->L); }
+    if (reward_tape) { la.rewards = reward_tape; la.rew_stride = (int64_t)BN; }
+    if (terminated_tape) { la.terminated = terminated_tape; la.term_stride = (int64_t)eng->prm.B; }
+    return launch(eng, la, rw::OP_STEP, /*rollout=*/true);
 }
 
 int rw_debug_timeline(rw_engine *eng, const int32_t *actions_dev, uint64_t *host_out, int32_t *n_workgroups, int32_t *n_marks) {
@@ -498,10 +511,10 @@ int rw_debug_timeline(rw_engine *eng, const int32_t *actions_dev, uint64_t *host
     uint64_t *d = nullptr;
     RW_HIP(eng, hipMalloc(&d, bytes));
     RW_HIP(eng, hipMemsetAsync(d, 0, bytes, eng->stream));
-    rw::Params p = eng->prm;
-    p.actions = actions_dev;
-    p.timeline = d;
-    int rc = launch(eng, p, rw::OP_STEP);
+    rw::LaunchArgs la = eng->la;
+    la.actions = actions_dev;
+    la.timeline = d;
+    int rc = launch(eng, la, rw::OP_STEP);
     if (rc == RW_OK) {
         hipError_t e1 = hipMemcpyAsync(host_out, d, bytes, hipMemcpyDeviceToHost, eng->stream);
         hipError_t e2 = hipStreamSynchronize(eng->stream);
@@ -545,7 +558,7 @@ int rw_copy_to_host(rw_engine *eng, void *host_dst, const void *dev_src, size_t 
 int rw_refresh_obs(rw_engine *eng) {
     if (!eng) return RW_ERR_INVALID_ARG;
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
-    return launch(eng, eng->prm, rw::OP_OBS);
+    return launch(eng, eng->la, rw::OP_OBS);
 }
 
 int rw_sync(rw_engine *eng) {

@@ -88,6 +88,7 @@ template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { return hipM
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
 
