@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="envs per GPU (headline: 16384)")
     ap.add_argument("--env-id", default=ENV_ID)
+    ap.add_argument("--sensor-range", type=int, default=0, help="override sensor_range (BASELINE config 5 uses 2)")
     ap.add_argument("--envs-per-wg", type=int, default=0)
     ap.add_argument("--threads-per-wg", type=int, default=0)
     ap.add_argument("--many", type=int, default=0,
@@ -97,6 +98,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     kw = rware_amd.env_kwargs(args.env_id)
+    if args.sensor_range:
+        kw["sensor_range"] = args.sensor_range
     B, N = args.batch, kw["n_agents"]
     env = rware_amd.WarehouseVecEnv(B, devices=[local_rank], envs_per_workgroup=args.envs_per_wg,
                                     threads_per_workgroup=args.threads_per_wg, **kw)
@@ -182,7 +185,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": "rw::rware_step_kernel<1, unsigned char>", "kernel_ms_per_launch": kernel_ms,
+                "kernel": "rw::rware_step_kernel", "kernel_ms_per_launch": kernel_ms,
                 "algorithmic_bytes_per_launch": per_launch,
             },
         }

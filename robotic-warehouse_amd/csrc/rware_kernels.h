@@ -338,6 +338,10 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
 
     // kRollout == false is the single-step kernel (rw_step / rw_reset / rw_refresh_obs): no loop at all.
     const int n_steps = (kRollout && op == OP_STEP) ? la.n_steps : 1;
+    // Rollout: when every agent lane owns exactly one (env, agent) for the whole launch, the NEXT step's
+    // action is fetched into a register one step ahead, so its HBM latency hides under the current step.
+    const bool act_prefetch = kRollout && (ne <= nw * (Cfg::kN ? 64 / (Cfg::kN ? Cfg::kN : 1) : p.groups_per_wave));
+    int a_pref = ACT_NOOP;
     for (int t = 0; t < n_steps; ++t) {  // fused rollout: one iteration per env step
     if (kRollout) {
         // Re-derive the thread coordinates inside the loop from an opaque copy: otherwise LICM hoists every
@@ -383,7 +387,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         int x = 0, y = 0, d = 0, carry = 0, deliv = 0, a = ACT_NOOP;
         if (mine) {
             x = s_ax[i]; y = s_ay[i]; d = s_dir[i]; carry = s_carry[i]; deliv = s_deliv[i];
-            if (stepping) a = (t == 0) ? s_act[i] : act_t[(size_t)ge * N + a_idx];
+            if (stepping) a = (t == 0) ? s_act[i] : (act_prefetch ? a_pref : act_t[(size_t)ge * N + a_idx]);
+            if (act_prefetch && t + 1 < n_steps) a_pref = (act_t + la.act_stride)[(size_t)ge * N + a_idx];
         }
         const int st = y * W + x;
         if (mine && !ev[ENVI_RESET]) gA[st] = (uint8_t)((a_idx + 1) | (carry ? 0x80 : 0));

@@ -161,3 +161,23 @@ def test_fused_rollout_equals_stepwise_oracle(env_id, extra, B, geom, mode):
     o2, r2, d2 = orc.step_autoreset(a, mode)
     assert np.array_equal(o, o2) and np.array_equal(r, r2)
     env.close()
+
+
+@pytest.mark.parametrize("sensor_range", [4, 5])
+def test_wide_sensor_ranges(sensor_range):
+    """r = 4 (63-bit window rows) and r = 5 (77-bit rows, the multi-word path of the row gather)."""
+    kw = rware_amd.env_kwargs("rware-tiny-3ag-v1")
+    kw.update(sensor_range=sensor_range, max_steps=12)
+    kw["reward_type"] = kw["reward_type"].value
+    B = 5
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **kw)
+    orc = OracleVecEnv(B, **kw)
+    assert env.obs_length == 8 + 7 * (2 * sensor_range + 1) ** 2
+    assert np.array_equal(env.reset(seed=1)[0], orc.reset(seed=1))
+    rng = np.random.default_rng(2)
+    for t in range(30):
+        a = rng.integers(0, 5, size=(B, 3))
+        o, r, d, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(o, o2) and np.array_equal(r, r2), t
+    env.close()
