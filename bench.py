@@ -77,6 +77,7 @@ def main():
                     help="fused rollout: submit steps in chunks of this many through rw_step_many_device (one launch per chunk, "
                          "env chunk resident in LDS across the steps; open-loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-rollout measurement (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -141,10 +142,34 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = eng.event_elapsed_ms(0, 1) / max(args.steps, 1)  # avg per launch on the engine's stream
+
+    # Extra (reported beside the headline, never as `value`): the same K steps through the fused rollout
+    # API, rw_step_many_device — one launch per 64 steps, env chunk resident in LDS (open-loop).
+    fused_elapsed = None
+    if not args.many and not args.no_fused_extra:
+        chunk = 64
+        def run_fused(n, t_start):
+            t = t_start
+            while t < t_start + n:
+                c = min(chunk, t_start + n - t, TAPE_STEPS - (t % TAPE_STEPS))
+                eng.step_many_device(base + (t % TAPE_STEPS) * stride, c)
+                t += c
+        run_fused(min(args.warmup, 64), 0)
+        eng.sync()
+        torch.cuda.synchronize()
+        barrier()
+        tf = time.perf_counter()
+        run_fused(args.steps, args.warmup)
+        eng.sync()
+        torch.cuda.synchronize()
+        barrier()
+        fused_elapsed = time.perf_counter() - tf
+
     if dist is not None:
-        tt = torch.tensor([elapsed, kernel_ms], device=f"cuda:{local_rank}", dtype=torch.float64)
+        tt = torch.tensor([elapsed, kernel_ms, fused_elapsed or 0.0], device=f"cuda:{local_rank}", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(tt[0]), float(tt[1])
+        fused_elapsed = float(tt[2]) or None
 
     if rank == 0:
         a_bytes = int(info.algorithmic_bytes_per_env_step)
@@ -189,6 +214,13 @@ def main():
                 "algorithmic_bytes_per_launch": per_launch,
             },
         }
+        if fused_elapsed:
+            out["fused_rollout"] = {
+                "value": world * B * N * args.steps / fused_elapsed, "unit": "agent-steps/s",
+                "ms_per_step": fused_elapsed / args.steps * 1e3,
+                "submit": "rw_step_many_device x64: one launch per 64 steps, env chunk resident in LDS across steps "
+                          "(open-loop rollout from the same device action tape; identical results)",
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -22,18 +22,6 @@ __device__ __forceinline__ void lds_dma_b32(const void *g_lane, void *lds_wave_b
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
 }
-// Pins kernel arguments into SGPRs at the point of the call.  The kernarg segment is rewritten by
-// the host for every launch, so it is cold in the scalar cache and in L2; left alone, the compiler
-// sinks each s_load next to its first use and the kernel pays that cold miss many times over on its
-// critical path.  Touching the arguments up front turns them into one scalar-load batch.
-template <typename T>
-__device__ __forceinline__ void pin_sgpr1(const T &v) {
-    asm volatile("" ::"s"(v));
-}
-template <typename... Ts>
-__device__ __forceinline__ void pin_sgpr(const Ts &...v) {
-    (pin_sgpr1(v), ...);
-}
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }

@@ -10,7 +10,6 @@ inline void lds_dma_b128(const void *g_lane, void *lds_wave_base) {
 inline void lds_dma_b32(const void *g_lane, void *lds_wave_base) {
     memcpy((char *)lds_wave_base + (threadIdx.x & 63u) * 4, g_lane, 4);
 }
-template <typename... Ts> inline void pin_sgpr(const Ts &...) {}
 inline void lds_barrier() { pthread_barrier_wait(emu_barrier); }
 inline void wave_sync() { pthread_barrier_wait(emu_wave_barrier); }
 }  // namespace rw
