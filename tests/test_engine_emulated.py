@@ -181,3 +181,24 @@ def test_wide_sensor_ranges(sensor_range):
         o2, r2, d2 = orc.step_autoreset(a, "next_step")
         assert np.array_equal(o, o2) and np.array_equal(r, r2), t
     env.close()
+
+
+def test_wide_shelf_ids_use_the_uint16_shadow():
+    """More than 255 shelves (the reference's __main__ smoke layout, 29x28): shelf shadow is uint16."""
+    kw = dict(shelf_columns=9, column_height=8, shelf_rows=3, n_agents=10, sensor_range=1, request_queue_size=5,
+              max_inactivity_steps=None, max_steps=14, reward_type=0)
+    B = 4
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=128, **kw)
+    assert env.n_shelves > 255
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=8)[0], orc.reset(seed=8))
+    rng = np.random.default_rng(5)
+    for t in range(35):
+        a = rng.choice(5, size=(B, 10), p=[.1, .5, .1, .1, .2])
+        o, r, d, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(o, o2) and np.array_equal(r, r2) and np.array_equal(d, d2.astype(bool)), t
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    env.close()

@@ -38,6 +38,8 @@ CASES = [
     ("rware-large-16ag-v1", {"sensor_range": 2}, 512, 200, (0, 0)),
     ("rware-small-19ag-v1", {"reward_type": 0, "max_inactivity_steps": 50}, 256, 200, (4, 128)),
     ("rware-tiny-4ag-easy-v1", {"reward_type": 2, "max_steps": 60}, 512, 200, (16, 256)),
+    # > 255 shelves -> uint16 shelf shadow; 29 x 28 grid, 10 agents (the reference's __main__ smoke layout)
+    ("rware-large-10ag-v1", {"shelf_columns": 9, "max_steps": 80, "sensor_range": 2}, 192, 200, (0, 0)),
 ]
 
 
