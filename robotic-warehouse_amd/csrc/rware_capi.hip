@@ -97,6 +97,11 @@ const StaticEntry kStatic[] = {
     RW_STATIC(20, 10, 4, 4, 80, 1, 16, 256),    // rware-small-4ag (headline)
     RW_STATIC(20, 16, 6, 3, 144, 1, 16, 256),   // rware-medium-6ag-hard
     RW_STATIC(29, 16, 16, 16, 224, 2, 8, 256),  // rware-large-16ag, sensor_range = 2
+    // size-static builds (N == 0: any agent count / queue length): every other registered id, sensor_range 1
+    RW_STATIC(11, 10, 0, 0, 32, 1, 16, 256),    // rware-tiny-*
+    RW_STATIC(20, 10, 0, 0, 80, 1, 16, 256),    // rware-small-*
+    RW_STATIC(20, 16, 0, 0, 144, 1, 16, 256),   // rware-medium-*
+    RW_STATIC(29, 16, 0, 0, 224, 1, 16, 256),   // rware-large-*
 };
 #undef RW_STATIC
 
@@ -289,7 +294,8 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         default: eng->kernel = generic_kernel<5, false>(eng->wide); eng->kernel_rollout = generic_kernel<5, true>(eng->wide); break;
     }
     for (const StaticEntry &se : kStatic) {
-        const bool shape = se.H == H && se.W == W && se.N == N && se.Q == Q && se.S == S && se.R == R;
+        if (eng->specialised) break;  // exact matches are listed first
+        const bool shape = se.H == H && se.W == W && se.S == S && se.R == R && (se.N == 0 || (se.N == N && se.Q == Q));
         const bool geom_default = cfg->envs_per_workgroup == 0 && cfg->threads_per_workgroup == 0;
         const bool geom_same = E == se.E && T == se.T;
         if (shape && (geom_default || geom_same) && B % se.E == 0) {

@@ -155,7 +155,9 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
 // any N/Q, any launch geometry).  StaticCfg bakes the shapes of one registered task and one launch
 // geometry in as constants, so the LDS carve-up, the index arithmetic, the divisions and the loop
 // trip counts all fold at compile time and the kernel needs a fraction of the scalar registers
-// (no kernarg re-loads on the critical path).  A field == 0 means "take it from Params".
+// (no kernarg re-loads on the critical path).  A field == 0 means "take it from Params"; StaticCfg with
+// N_ == 0 is a "size-static" build: grid shape and geometry folded in, agent count / queue length read
+// at run time — one such build covers every registered id of a warehouse size.
 struct DynamicCfg {
     static constexpr int kH = 0, kW = 0, kN = 0, kQ = 0, kS = 0, kE = 0, kT = 0;
 };
@@ -223,7 +225,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     if (ne <= 0) return;
     const int N = Cfg::kN ? Cfg::kN : p.N, Q = Cfg::kN ? Cfg::kQ : p.Q;
     const int H = Cfg::kH ? Cfg::kH : p.H, W = Cfg::kW ? Cfg::kW : p.W, HW = H * W;
-    const int S = Cfg::kN ? Cfg::kS : p.S, SW = (S + 32) / 32, B = p.B;
+    const int S = Cfg::kS ? Cfg::kS : p.S, SW = (S + 32) / 32, B = p.B;
     const int nea = ne * N;
     const uint32_t mN = Cfg::kN ? rw_magic18(Cfg::kN) : p.magic_n;
     // optional per-workgroup phase stamps (100 MHz wall clock); one scalar branch per mark when off
