@@ -164,6 +164,17 @@ int rw_write(rw_engine *eng, int kind, const void *host_src, size_t bytes);
  * current agent positions.  This is how the reference's own tests inject state. */
 int rw_recalc_grid(rw_engine *eng, const int32_t *shelf_xy, int32_t n_shelves);
 
+/* -- snapshot / restore (checkpointing the batched env state) ------------ */
+/* A snapshot is a device-resident copy of everything reset()/step() evolve: grid, shelf shadow, agent
+ * SoA, queue, counters, PCG64 streams, pending-autoreset flags.  Saving and restoring are device-to-
+ * device copies on the engine's stream (tens of microseconds); restore also refreshes RW_BUF_OBS, so
+ * the engine continues bit-identically from the saved point. */
+typedef struct rw_snapshot rw_snapshot;
+int rw_snapshot_create(rw_engine *eng, rw_snapshot **out);
+int rw_snapshot_save(rw_engine *eng, rw_snapshot *snap);
+int rw_snapshot_restore(rw_engine *eng, const rw_snapshot *snap);
+int rw_snapshot_destroy(rw_engine *eng, rw_snapshot *snap);
+
 /* -- introspection ---------------------------------------------------------------------- */
 typedef struct rw_info {
     int32_t num_envs, grid_h, grid_w, n_agents, request_queue_size, n_shelves, obs_length;

@@ -52,7 +52,7 @@ EXPORTS = (
     "rw_step_many_device", "rw_refresh_obs", "rw_sync", "rw_get_buffer", "rw_read", "rw_write",
     "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
     "rw_abi_version", "rw_debug_timeline", "rw_device_malloc", "rw_device_free", "rw_copy_to_device",
-    "rw_copy_to_host",
+    "rw_copy_to_host", "rw_snapshot_create", "rw_snapshot_save", "rw_snapshot_restore", "rw_snapshot_destroy",
 )
 
 _libs = {}
@@ -116,6 +116,10 @@ def load(path: str | None = None):
     lib.rw_device_free.argtypes = [vp, vp]
     lib.rw_copy_to_device.argtypes = [vp, vp, vp, C.c_size_t]
     lib.rw_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.rw_snapshot_create.argtypes = [vp, C.POINTER(vp)]
+    lib.rw_snapshot_save.argtypes = [vp, vp]
+    lib.rw_snapshot_restore.argtypes = [vp, vp]
+    lib.rw_snapshot_destroy.argtypes = [vp, vp]
     for name in EXPORTS:
         if name != "rw_last_error":
             getattr(lib, name).restype = C.c_int
@@ -243,6 +247,21 @@ class Engine:
             for p in ptrs:
                 self.lib.rw_device_free(self._h, p)
         return obs, rew, term
+
+    def snapshot(self, into=None):
+        """Device-resident copy of the whole env state (see rw_snapshot_*); returns an opaque handle."""
+        h = into
+        if h is None:
+            h = C.c_void_p()
+            self._check(self.lib.rw_snapshot_create(self._h, C.byref(h)))
+        self._check(self.lib.rw_snapshot_save(self._h, h))
+        return h
+
+    def restore(self, handle):
+        self._check(self.lib.rw_snapshot_restore(self._h, handle))
+
+    def free_snapshot(self, handle):
+        self._check(self.lib.rw_snapshot_destroy(self._h, handle))
 
     def refresh_obs(self):
         self._check(self.lib.rw_refresh_obs(self._h))

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rware_hip.h"
@@ -558,6 +559,74 @@ int rw_copy_to_host(rw_engine *eng, void *host_dst, const void *dev_src, size_t 
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
     if (bytes) RW_HIP(eng, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, eng->stream));
     RW_HIP(eng, hipStreamSynchronize(eng->stream));
+    return RW_OK;
+}
+
+}  // extern "C"
+
+struct rw_snapshot {
+    void *mem = nullptr;
+    size_t bytes = 0;
+};
+
+namespace {
+// the state that reset()/step() evolve: (device pointer, size) pieces in a fixed order
+std::vector<std::pair<void *, size_t>> state_pieces(rw_engine *eng) {
+    static const int kinds[] = {RW_BUF_GRID, RW_BUF_AGENT_X, RW_BUF_AGENT_Y, RW_BUF_AGENT_DIR, RW_BUF_AGENT_CARRY,
+                                RW_BUF_AGENT_DELIVERED, RW_BUF_QUEUE, RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_RNG,
+                                RW_BUF_NEED_RESET};
+    std::vector<std::pair<void *, size_t>> v;
+    for (int k : kinds) v.emplace_back(eng->buf[k].ptr, eng->buf[k].bytes);
+    v.emplace_back(eng->d_shadow, (size_t)eng->prm.B * eng->prm.HW * (eng->wide ? 2 : 1));
+    return v;
+}
+}  // namespace
+
+extern "C" {
+
+int rw_snapshot_create(rw_engine *eng, rw_snapshot **out) {
+    if (!eng || !out) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    rw_snapshot *s = new (std::nothrow) rw_snapshot();
+    if (!s) return fail(eng, RW_ERR_HIP, "out of host memory");
+    for (auto &pc : state_pieces(eng)) s->bytes += (pc.second + 255) & ~(size_t)255;
+    if (hipMalloc(&s->mem, s->bytes) != hipSuccess) {
+        delete s;
+        return fail(eng, RW_ERR_HIP, "hipMalloc of a %zu-byte snapshot failed", s->bytes);
+    }
+    *out = s;
+    return RW_OK;
+}
+
+int rw_snapshot_save(rw_engine *eng, rw_snapshot *snap) {
+    if (!eng || !snap || !snap->mem) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    size_t off = 0;
+    for (auto &pc : state_pieces(eng)) {
+        if (pc.second) RW_HIP(eng, hipMemcpyAsync((char *)snap->mem + off, pc.first, pc.second, hipMemcpyDeviceToDevice, eng->stream));
+        off += (pc.second + 255) & ~(size_t)255;
+    }
+    return RW_OK;
+}
+
+int rw_snapshot_restore(rw_engine *eng, const rw_snapshot *snap) {
+    if (!eng || !snap || !snap->mem) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    size_t off = 0;
+    for (auto &pc : state_pieces(eng)) {
+        if (pc.second) RW_HIP(eng, hipMemcpyAsync(pc.first, (const char *)snap->mem + off, pc.second, hipMemcpyDeviceToDevice, eng->stream));
+        off += (pc.second + 255) & ~(size_t)255;
+    }
+    return launch(eng, eng->la, rw::OP_OBS);
+}
+
+int rw_snapshot_destroy(rw_engine *eng, rw_snapshot *snap) {
+    if (!eng) return RW_ERR_INVALID_ARG;
+    if (!snap) return RW_OK;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    RW_HIP(eng, hipStreamSynchronize(eng->stream));
+    if (snap->mem) (void)hipFree(snap->mem);
+    delete snap;
     return RW_OK;
 }
 

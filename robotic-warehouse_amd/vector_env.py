@@ -207,6 +207,21 @@ class WarehouseVecEnv(_VectorEnvBase):
         cat = lambda k: parts[0][k] if len(parts) == 1 else np.concatenate([p[k] for p in parts], axis=1)
         return (cat(0) if want_obs else None), cat(1), cat(2).astype(bool)
 
+    def snapshot(self):
+        """Checkpoint the batched state on the device (grid, agents, queue, counters, RNG streams).
+        Returns an opaque token for restore(); free it with free_snapshot()."""
+        return [eng.snapshot() for eng in self.engines]
+
+    def restore(self, token):
+        """Roll every env back to a snapshot(); the engine then continues bit-identically."""
+        for eng, h in zip(self.engines, token):
+            eng.restore(h)
+        return self._observations()
+
+    def free_snapshot(self, token):
+        for eng, h in zip(self.engines, token):
+            eng.free_snapshot(h)
+
     def sync(self):
         """Wait for enqueued work; raises ValueError if a device-side action was out of range."""
         for eng in self.engines:

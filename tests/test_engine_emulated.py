@@ -202,3 +202,29 @@ def test_wide_shelf_ids_use_the_uint16_shadow():
     for k in so:
         assert np.array_equal(st[k], so[k]), k
     env.close()
+
+
+def test_snapshot_restore_replays_bit_identically():
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    kw["reward_type"] = 0
+    kw["max_steps"] = 11
+    B = 8
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, **kw)
+    env.reset(seed=21)
+    rng = np.random.default_rng(6)
+    acts = rng.choice(5, size=(30, B, 4), p=[.1, .55, .1, .1, .15])
+    for t in range(7):
+        env.step(acts[t])
+    snap = env.snapshot()
+    saved = env.get_state()
+    first = [env.step(acts[t]) for t in range(7, 30)]
+    obs = env.restore(snap)
+    back = env.get_state()
+    for k in saved:
+        assert np.array_equal(saved[k], back[k]), k
+    second = [env.step(acts[t]) for t in range(7, 30)]
+    for a, b in zip(first, second):
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y)
+    env.free_snapshot(snap)
+    env.close()

@@ -179,3 +179,23 @@ def test_fused_rollout_matches_oracle(env_id, extra, B, mode):
     for k in so:
         assert np.array_equal(st[k], so[k]), k
     env.close()
+
+
+def test_snapshot_restore_on_device():
+    B = 2048
+    env = rware_amd.make_vec("rware-small-4ag-v1", B, max_steps=40)
+    env.reset(seed=5)
+    acts = np.random.default_rng(1).choice(5, size=(90, B, 4), p=[.1, .55, .1, .1, .15])
+    for t in range(30):
+        env.step(acts[t])
+    snap, saved = env.snapshot(), env.get_state()
+    first = env.rollout(acts[30:])
+    env.restore(snap)
+    back = env.get_state()
+    for k in saved:
+        assert np.array_equal(saved[k], back[k]), k
+    second = env.rollout(acts[30:])
+    for x, y in zip(first, second):
+        assert np.array_equal(x, y)
+    env.free_snapshot(snap)
+    env.close()
