@@ -50,6 +50,13 @@ enum rw_direction { RW_UP = 0, RW_DOWN = 1, RW_DIR_LEFT = 2, RW_DIR_RIGHT = 3 };
 /* rware/warehouse.py:46-49 */
 enum rw_reward_type { RW_REWARD_GLOBAL = 0, RW_REWARD_INDIVIDUAL = 1, RW_REWARD_TWO_STAGE = 2 };
 
+/* rware/warehouse.py:52-56.  DICT is not accelerated (Python-object output). */
+enum rw_observation_type { RW_OBS_FLATTENED = 1, RW_OBS_IMAGE = 2, RW_OBS_IMAGE_DICT = 3 };
+/* rware/warehouse.py:59-70.  AGENT_DIRECTION (3) and AGENT_LOAD (4) are rejected: the reference writes
+ * them with transposed indices (`layer[ag.x, ag.y]`, :552/:558), an IndexError on non-square grids. */
+enum rw_image_layer { RW_LAYER_SHELVES = 0, RW_LAYER_REQUESTS = 1, RW_LAYER_AGENTS = 2, RW_LAYER_GOALS = 5,
+                      RW_LAYER_ACCESSIBLE = 6 };
+
 /* What a step does with an env whose episode ended (Gymnasium vector-env autoreset modes).
  * The reference env itself never resets (the caller calls reset()); DISABLED reproduces that. */
 enum rw_autoreset {
@@ -64,7 +71,8 @@ enum rw_autoreset {
  * (:82-93), env.request_queue (:263), env._cur_steps/_cur_inactive_steps (:249-250),
  * env.np_random.bit_generator.state, and the step() return tuple (:944-946). */
 enum rw_buffer_kind {
-    RW_BUF_OBS = 0,          /* float32 [B][N][L]  FLATTENED observation (:598-674)               */
+    RW_BUF_OBS = 0,          /* float32 [B][N][L]  FLATTENED observation (:598-674), or, for the IMAGE
+                                                   types, [B][N][C][2r+1][2r+1] (:527-596)        */
     RW_BUF_REWARDS = 1,      /* float32 [B][N]                                                    */
     RW_BUF_TERMINATED = 2,   /* uint8   [B]        `done` (:935-941)                              */
     RW_BUF_TRUNCATED = 3,    /* uint8   [B]        always 0 (:942)                                */
@@ -81,7 +89,9 @@ enum rw_buffer_kind {
                                                    has_uint32, uinteger (numpy PCG64 state)       */
     RW_BUF_NEED_RESET = 14,  /* uint8   [B]        NEXT_STEP autoreset: env resets on next step   */
     RW_BUF_ACTIONS = 15,     /* int32   [B][N]     staging buffer used by rw_step (host actions)  */
-    RW_BUF_KIND_COUNT = 16
+    RW_BUF_FEATURES = 16,    /* float32 [B][N][6]  IMAGE_DICT features: one-hot direction, on_highway,
+                                                   carrying (:727-742); unused otherwise          */
+    RW_BUF_KIND_COUNT = 17
 };
 
 /* Mirrors the constructor of rware.warehouse.Warehouse (rware/warehouse.py:146-170).  The
@@ -103,6 +113,10 @@ typedef struct rw_config {
     int32_t device_id;            /* HIP device ordinal                                          */
     int32_t envs_per_workgroup;   /* 0 == engine default; otherwise a multiple of 4              */
     int32_t threads_per_workgroup;/* 0 == engine default; otherwise a multiple of 64             */
+    int32_t observation_type;     /* rw_observation_type; 0 is read as FLATTENED                 */
+    int32_t image_directional;    /* image_observation_directional (:167)                        */
+    int32_t n_image_layers;       /* 0 == the reference default list (:160-166)                  */
+    int32_t image_layers[8];      /* rw_image_layer values, channel order                        */
     const uint8_t *highways;      /* host, [H*W], 1 == highway (no shelf spawns, no unloading)   */
     const int32_t *goals_xy;      /* host, [n_goals][2] = (x, y), list order == reward order     */
     void *stream;                 /* hipStream_t to enqueue on; NULL == engine creates its own   */

@@ -566,6 +566,62 @@ int orc_obs(const orc_cfg *c, int B, const orc_state *s, float *obs) {
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* IMAGE / IMAGE_DICT observation  (warehouse.py:527-596, :722-742)                      */
+/* ------------------------------------------------------------------------------------ */
+/* layers: ImageLayer values (:59-70) SHELVES 0, REQUESTS 1, AGENTS 2, GOALS 5, ACCESSIBLE 6.
+ * AGENT_DIRECTION 3 / AGENT_LOAD 4 index `layer[ag.x, ag.y]` (:552, :558) — transposed, an
+ * IndexError on the non-square registered grids — and are not restated.
+ * out: float32 [B][N][n_layers][WIN][WIN]; features (may be NULL): float32 [B][N][6] =
+ * one-hot direction, on_highway, carrying (:730-738). */
+int orc_obs_image(const orc_cfg *c, int B, const orc_state *s, const int32_t *layers, int n_layers,
+                  int directional, float *out, float *features) {
+    const int H = c->H, W = c->W, N = c->N, R = c->R, HW = H * W, WIN = 2 * R + 1;
+    for (int l = 0; l < n_layers; ++l)
+        if (layers[l] == 3 || layers[l] == 4 || layers[l] < 0 || layers[l] > 6) return -4;
+    for (int e = 0; e < B; ++e) {
+        env_view v = view(c, s, e);
+        const int32_t *gA = v.grid, *gS = v.grid + HW;
+        for (int i = 0; i < N; ++i) {
+            float *o = out + ((size_t)e * N + i) * n_layers * WIN * WIN;
+            for (int l = 0; l < n_layers; ++l)
+                for (int r = 0; r < WIN; ++r)
+                    for (int cc = 0; cc < WIN; ++cc) {
+                        /* (r, cc) indexes the ROTATED image; (wr, wc) the north-up window it came from */
+                        int wr = r, wc = cc;
+                        if (directional) { /* np.rot90(obs, k, axes=(1,2)) :584-595 */
+                            if (v.adir[i] == D_DOWN) { wr = WIN - 1 - r; wc = WIN - 1 - cc; }      /* k = 2 */
+                            else if (v.adir[i] == D_LEFT) { wr = WIN - 1 - cc; wc = r; }           /* k = 3 */
+                            else if (v.adir[i] == D_RIGHT) { wr = cc; wc = WIN - 1 - r; }          /* k = 1 */
+                        }
+                        const int y = v.ay[i] - R + wr, x = v.ax[i] - R + wc;
+                        float val = 0.0f; /* np.pad(..., mode="constant") :573 */
+                        if (x >= 0 && x < W && y >= 0 && y < H) {
+                            const int cell = y * W + x;
+                            switch (layers[l]) {
+                                case 0: val = gS[cell] > 0 ? 1.0f : 0.0f; break;
+                                case 1: val = (gS[cell] && in_queue(v.queue, c->Q, gS[cell]) >= 0) ? 1.0f : 0.0f; break;
+                                case 2: val = gA[cell] > 0 ? 1.0f : 0.0f; break;
+                                case 5:
+                                    for (int g = 0; g < c->n_goals; ++g)
+                                        if (c->goals[2 * g] == x && c->goals[2 * g + 1] == y) val = 1.0f;
+                                    break;
+                                default: val = gA[cell] > 0 ? 0.0f : 1.0f; break; /* ACCESSIBLE */
+                            }
+                        }
+                        o[(l * WIN + r) * WIN + cc] = val;
+                    }
+            if (features) {
+                float *f = features + ((size_t)e * N + i) * 6;
+                for (int d = 0; d < 4; ++d) f[d] = v.adir[i] == d ? 1.0f : 0.0f;
+                f[4] = c->highways[v.ay[i] * W + v.ax[i]] ? 1.0f : 0.0f;
+                f[5] = v.acarry[i] ? 1.0f : 0.0f;
+            }
+        }
+    }
+    return 0;
+}
+
 /* rebuild grid from explicit shelf positions + agents, exactly as _recalc_grid :749-755
  * (shelf_xy: [S][2] (x,y) in id order; later ids overwrite earlier ones) — for the
  * state-injection tests that mirror the reference's own tests. */

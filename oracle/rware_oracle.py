@@ -56,7 +56,7 @@ def lib():
         _lib.orc_rng_bounded.restype = C.c_uint32
         _lib.orc_rng_choice.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib.orc_rng_choice.restype = None
-        for f in ("orc_reset", "orc_step", "orc_obs", "orc_recalc_grid"):
+        for f in ("orc_reset", "orc_step", "orc_obs", "orc_recalc_grid", "orc_obs_image"):
             getattr(_lib, f).restype = C.c_int
     return _lib
 
@@ -109,8 +109,13 @@ class OracleVecEnv:
 
     def __init__(self, num_envs, shelf_columns=3, column_height=8, shelf_rows=1, n_agents=2,
                  msg_bits=0, sensor_range=1, request_queue_size=2, max_inactivity_steps=None,
-                 max_steps=500, reward_type=1, layout=None, normalised_coordinates=False, **_):
+                 max_steps=500, reward_type=1, layout=None, normalised_coordinates=False, observation_type=1,
+                 image_observation_layers=None, image_observation_directional=True, **_):
         assert msg_bits == 0
+        self.observation_type = int(getattr(observation_type, "value", observation_type))  # 1 FLATTENED 2 IMAGE 3 IMAGE_DICT
+        assert self.observation_type in (1, 2, 3)
+        self.image_layers = tuple(int(getattr(l, "value", l)) for l in (image_observation_layers or self.DEFAULT_IMAGE_LAYERS))
+        self.image_directional = bool(image_observation_directional)
         reward_type = int(getattr(reward_type, "value", reward_type))
         self.hw, self.goals = (
             layout_from_str(layout) if layout else layout_from_params(shelf_columns, shelf_rows, column_height)
@@ -207,10 +212,32 @@ class OracleVecEnv:
         return self.obs(), rew, done
 
     def obs(self):
+        """Observation in the configured type: FLATTENED (B,N,L); IMAGE (B,N,C,WIN,WIN); IMAGE_DICT (image, features)."""
+        if self.observation_type == 2:
+            return self.obs_image(self.image_layers, self.image_directional)
+        if self.observation_type == 3:
+            return self.obs_image(self.image_layers, self.image_directional, with_features=True)
         out = np.zeros((self.B, self.N, self.L), np.float32)
         st = self._state()
         lib().orc_obs(C.byref(self.cfg), self.B, C.byref(st), out.ctypes.data_as(C.c_void_p))
         return out
+
+    DEFAULT_IMAGE_LAYERS = (0, 1, 2, 5, 6)  # SHELVES, REQUESTS, AGENTS, GOALS, ACCESSIBLE (warehouse.py:160-166)
+
+    def obs_image(self, layers=DEFAULT_IMAGE_LAYERS, directional=True, with_features=False):
+        """IMAGE observation (B, N, C, WIN, WIN) [+ features (B, N, 6) for IMAGE_DICT]."""
+        ly = np.ascontiguousarray(np.asarray([int(getattr(l, "value", l)) for l in layers], np.int32))
+        win = 2 * self.R + 1
+        out = np.zeros((self.B, self.N, len(ly), win, win), np.float32)
+        feat = np.zeros((self.B, self.N, 6), np.float32) if with_features else None
+        st = self._state()
+        rc = lib().orc_obs_image(C.byref(self.cfg), self.B, C.byref(st), ly.ctypes.data_as(C.c_void_p), len(ly),
+                                 int(bool(directional)), out.ctypes.data_as(C.c_void_p),
+                                 None if feat is None else feat.ctypes.data_as(C.c_void_p))
+        if rc == -4:
+            raise NotImplementedError("AGENT_DIRECTION / AGENT_LOAD image layers are not restated (transposed indexing)")
+        assert rc == 0
+        return (out, feat) if with_features else out
 
     def recalc_grid(self, shelf_xy):
         """shelf_xy: (B, S, 2) int32 (x, y) per shelf id, exactly `_recalc_grid` (:749-755)."""

@@ -4,13 +4,13 @@ semitable/robotic-warehouse: reset / step / FLATTENED observation of `rware.ware
 The directory is named `robotic-warehouse_amd` (not an identifier); import it as `rware_amd`
 (the shim module at the repository root) or via importlib.
 """
-from .enums import Action, Direction, ObservationType, RewardType
+from .enums import DEFAULT_IMAGE_LAYERS, Action, Direction, ImageLayer, ObservationType, RewardType
 from .layout import Layout, layout_from_params, layout_from_str, obs_length
 from .registry import all_ids, env_kwargs, make_vec, register_gymnasium
 from .vector_env import STATE_FIELDS, WarehouseVecEnv
 
 __all__ = [
-    "Action", "Direction", "ObservationType", "RewardType", "Layout", "layout_from_params",
+    "Action", "Direction", "ImageLayer", "DEFAULT_IMAGE_LAYERS", "ObservationType", "RewardType", "Layout", "layout_from_params",
     "layout_from_str", "obs_length", "all_ids", "env_kwargs", "make_vec", "register_gymnasium",
     "WarehouseVecEnv", "STATE_FIELDS",
 ]

@@ -19,11 +19,11 @@ RW_OK, RW_ERR_INVALID_ARG, RW_ERR_INVALID_ACTION, RW_ERR_HIP, RW_ERR_UNSUPPORTED
 BUF = {
     "obs": 0, "rewards": 1, "terminated": 2, "truncated": 3, "grid": 4, "agent_x": 5, "agent_y": 6,
     "agent_dir": 7, "agent_carry": 8, "agent_delivered": 9, "queue": 10, "steps": 11, "inactive": 12,
-    "rng": 13, "need_reset": 14, "actions": 15,
+    "rng": 13, "need_reset": 14, "actions": 15, "features": 16,
 }
 BUF_DTYPE = {
     "obs": np.float32, "rewards": np.float32, "terminated": np.uint8, "truncated": np.uint8,
-    "rng": np.uint64, "need_reset": np.uint8,
+    "rng": np.uint64, "need_reset": np.uint8, "features": np.float32,
 }
 
 AUTORESET = {"disabled": 0, None: 0, "next_step": 1, "same_step": 2}
@@ -34,7 +34,8 @@ class RwConfig(C.Structure):
         "abi_version", "num_envs", "grid_h", "grid_w", "n_agents", "sensor_range",
         "request_queue_size", "max_inactivity_steps", "max_steps", "reward_type",
         "normalised_coordinates", "autoreset_mode", "n_goals", "device_id",
-        "envs_per_workgroup", "threads_per_workgroup")] + [
+        "envs_per_workgroup", "threads_per_workgroup", "observation_type", "image_directional",
+        "n_image_layers")] + [("image_layers", C.c_int32 * 8),
         ("highways", C.c_void_p), ("goals_xy", C.c_void_p), ("stream", C.c_void_p)]
 
 
@@ -153,7 +154,8 @@ class Engine:
     def __init__(self, *, num_envs, layout, n_agents, sensor_range, request_queue_size,
                  max_inactivity_steps, max_steps, reward_type, normalised_coordinates=False,
                  autoreset_mode="next_step", device_id=0, envs_per_workgroup=0,
-                 threads_per_workgroup=0, stream=None, library=None):
+                 threads_per_workgroup=0, stream=None, library=None, observation_type=1,
+                 image_layers=(), image_directional=True):
         self.lib = load(library)
         self._h = C.c_void_p()
         hw = np.ascontiguousarray(layout.highways, dtype=np.uint8)
@@ -163,6 +165,8 @@ class Engine:
             int(sensor_range), int(request_queue_size), int(max_inactivity_steps or 0), int(max_steps or 0),
             int(reward_type), int(bool(normalised_coordinates)), AUTORESET[autoreset_mode], len(layout.goals),
             int(device_id), int(envs_per_workgroup), int(threads_per_workgroup),
+            int(observation_type), int(bool(image_directional)), len(image_layers),
+            (C.c_int32 * 8)(*[int(l) for l in image_layers]),
             hw.ctypes.data, goals.ctypes.data, C.c_void_p(stream or 0))
         rc = self.lib.rw_create(C.byref(cfg), C.byref(self._h))
         if rc != RW_OK:
@@ -172,8 +176,11 @@ class Engine:
         i = self.info
         self.B, self.N, self.Q, self.L, self.S = i.num_envs, i.n_agents, i.request_queue_size, i.obs_length, i.n_shelves
         self.H, self.W = i.grid_h, i.grid_w
+        win = 2 * int(sensor_range) + 1
+        obs_shape = (self.B, self.N, self.L) if int(observation_type) == 1 else (self.B, self.N, self.L // (win * win), win, win)
         self.shapes = {
-            "obs": (self.B, self.N, self.L), "rewards": (self.B, self.N), "terminated": (self.B,),
+            "features": (self.B, self.N, 6),
+            "obs": obs_shape, "rewards": (self.B, self.N), "terminated": (self.B,),
             "truncated": (self.B,), "grid": (self.B, 2, self.H, self.W), "agent_x": (self.B, self.N),
             "agent_y": (self.B, self.N), "agent_dir": (self.B, self.N), "agent_carry": (self.B, self.N),
             "agent_delivered": (self.B, self.N), "queue": (self.B, self.Q), "steps": (self.B,),
@@ -222,7 +229,7 @@ class Engine:
         (obs (T,B,N,L) or None, rewards (T,B,N), terminated (T,B))."""
         a = np.ascontiguousarray(actions, dtype=np.int32).reshape(-1, self.B, self.N)
         T = a.shape[0]
-        obs = np.empty((T, self.B, self.N, self.L), np.float32) if want_obs else None
+        obs = np.empty((T,) + self.shapes["obs"], np.float32) if want_obs else None
         rew = np.empty((T, self.B, self.N), np.float32)
         term = np.empty((T, self.B), np.uint8)
         ptrs = []

@@ -48,6 +48,7 @@ struct rw_engine {
     size_t shadow_off = 0;
     void *d_shadow = nullptr;  // compact shelf layer (uint8 when S <= 255, else uint16), the kernel's read path
     bool wide = false;
+    bool image = false;        // IMAGE / IMAGE_DICT observation kernels
     int32_t *d_status = nullptr;
     hipEvent_t events[8]{};
     std::vector<uint8_t> h_highways;
@@ -79,7 +80,10 @@ int fail(rw_engine *eng, int code, const char *fmt, ...) {
 using step_kernel_t = void (*)(const rw::Params *, const rw::LaunchArgs);
 
 template <int R, bool kRollout>
-step_kernel_t generic_kernel(bool wide) {
+step_kernel_t generic_kernel(bool wide, bool image) {
+    if (image)
+        return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg, kRollout, rw::OBS_IMAGE>
+                    : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg, kRollout, rw::OBS_IMAGE>;
     return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg, kRollout>
                 : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg, kRollout>;
 }
@@ -131,7 +135,7 @@ int rebuild_shadow(rw_engine *eng) {
 
 size_t elem_size(int kind) {
     switch (kind) {
-        case RW_BUF_OBS: case RW_BUF_REWARDS: return 4;
+        case RW_BUF_OBS: case RW_BUF_REWARDS: case RW_BUF_FEATURES: return 4;
         case RW_BUF_TERMINATED: case RW_BUF_TRUNCATED: case RW_BUF_NEED_RESET: return 1;
         case RW_BUF_RNG: return 8;
         default: return 4;
@@ -207,6 +211,24 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         return fail(nullptr, RW_ERR_UNSUPPORTED, "sensor_range %d not in 1..5", cfg->sensor_range);
     if (cfg->reward_type < 0 || cfg->reward_type > 2 || cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2)
         return fail(nullptr, RW_ERR_INVALID_ARG, "bad reward_type/autoreset_mode");
+    const int obs_type = cfg->observation_type ? cfg->observation_type : RW_OBS_FLATTENED;
+    if (obs_type != RW_OBS_FLATTENED && obs_type != RW_OBS_IMAGE && obs_type != RW_OBS_IMAGE_DICT)
+        return fail(nullptr, RW_ERR_UNSUPPORTED, "observation_type %d is not accelerated (FLATTENED, IMAGE, IMAGE_DICT are)", obs_type);
+    int n_layers = cfg->n_image_layers;
+    int layers[8] = {RW_LAYER_SHELVES, RW_LAYER_REQUESTS, RW_LAYER_AGENTS, RW_LAYER_GOALS, RW_LAYER_ACCESSIBLE, 0, 0, 0};
+    if (n_layers == 0) n_layers = 5;  // the reference default (rware/warehouse.py:160-166)
+    else {
+        if (n_layers < 0 || n_layers > 8) return fail(nullptr, RW_ERR_INVALID_ARG, "n_image_layers %d not in 1..8", n_layers);
+        for (int l = 0; l < n_layers; ++l) {
+            layers[l] = cfg->image_layers[l];
+            const int v = layers[l];
+            if (v == 3 || v == 4)
+                return fail(nullptr, RW_ERR_UNSUPPORTED, "image layer %d (AGENT_DIRECTION/AGENT_LOAD) is not supported: the "
+                            "reference indexes it transposed (rware/warehouse.py:552,558)", v);
+            if (v != RW_LAYER_SHELVES && v != RW_LAYER_REQUESTS && v != RW_LAYER_AGENTS && v != RW_LAYER_GOALS && v != RW_LAYER_ACCESSIBLE)
+                return fail(nullptr, RW_ERR_INVALID_ARG, "unknown image layer %d", v);
+        }
+    }
     const int HW = H * W;
     if (HW > 10000) return fail(nullptr, RW_ERR_UNSUPPORTED, "H*W > 10000 (numpy switches choice() algorithm)");
     if (N > HW) return fail(nullptr, RW_ERR_INVALID_ARG, "more agents than cells");
@@ -249,8 +271,9 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     eng->wide = S > 255;
     const int cell_bytes = eng->wide ? 2 : 1;
     const int R = cfg->sensor_range, CELLS = (2 * R + 1) * (2 * R + 1);
-    eng->L = 8 + 7 * CELLS;
-    eng->OW = (eng->L + 31) / 32;
+    eng->image = obs_type != RW_OBS_FLATTENED;
+    eng->L = eng->image ? n_layers * CELLS : 8 + 7 * CELLS;  // floats per agent in RW_BUF_OBS
+    eng->OW = (8 + 7 * CELLS + 31) / 32;                       // LDS bit-string words per agent (kernel constant)
     const int SW = (S + 32) / 32;
 
     RW_HIP_C(hipSetDevice(cfg->device_id));
@@ -288,14 +311,14 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         }
     }
     switch (R) {
-        case 1: eng->kernel = generic_kernel<1, false>(eng->wide); eng->kernel_rollout = generic_kernel<1, true>(eng->wide); break;
-        case 2: eng->kernel = generic_kernel<2, false>(eng->wide); eng->kernel_rollout = generic_kernel<2, true>(eng->wide); break;
-        case 3: eng->kernel = generic_kernel<3, false>(eng->wide); eng->kernel_rollout = generic_kernel<3, true>(eng->wide); break;
-        case 4: eng->kernel = generic_kernel<4, false>(eng->wide); eng->kernel_rollout = generic_kernel<4, true>(eng->wide); break;
-        default: eng->kernel = generic_kernel<5, false>(eng->wide); eng->kernel_rollout = generic_kernel<5, true>(eng->wide); break;
+        case 1: eng->kernel = generic_kernel<1, false>(eng->wide, eng->image); eng->kernel_rollout = generic_kernel<1, true>(eng->wide, eng->image); break;
+        case 2: eng->kernel = generic_kernel<2, false>(eng->wide, eng->image); eng->kernel_rollout = generic_kernel<2, true>(eng->wide, eng->image); break;
+        case 3: eng->kernel = generic_kernel<3, false>(eng->wide, eng->image); eng->kernel_rollout = generic_kernel<3, true>(eng->wide, eng->image); break;
+        case 4: eng->kernel = generic_kernel<4, false>(eng->wide, eng->image); eng->kernel_rollout = generic_kernel<4, true>(eng->wide, eng->image); break;
+        default: eng->kernel = generic_kernel<5, false>(eng->wide, eng->image); eng->kernel_rollout = generic_kernel<5, true>(eng->wide, eng->image); break;
     }
     for (const StaticEntry &se : kStatic) {
-        if (eng->specialised) break;  // exact matches are listed first
+        if (eng->specialised || eng->image) break;  // exact matches are listed first; the image kernels are generic builds
         const bool shape = se.H == H && se.W == W && se.S == S && se.R == R && (se.N == 0 || (se.N == N && se.Q == Q));
         const bool geom_default = cfg->envs_per_workgroup == 0 && cfg->threads_per_workgroup == 0;
         const bool geom_same = E == se.E && T == se.T;
@@ -339,13 +362,14 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     n_elems[RW_BUF_RNG] = szB * 6;
     n_elems[RW_BUF_NEED_RESET] = szB;
     n_elems[RW_BUF_ACTIONS] = szB * N;
+    n_elems[RW_BUF_FEATURES] = szB * N * 6;
     // One slab for every buffer: the per-step working set (agent SoA, queue, counters, flags, rewards,
     // shelf shadow) sits in a few contiguous MiB, so a workgroup's ~15 streams share TLB entries
     // instead of touching 15 separate allocations.  Order = hot and small first.
     static const int order[RW_BUF_KIND_COUNT] = {
         RW_BUF_AGENT_X, RW_BUF_AGENT_Y, RW_BUF_AGENT_DIR, RW_BUF_AGENT_CARRY, RW_BUF_AGENT_DELIVERED, RW_BUF_QUEUE,
         RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_NEED_RESET, RW_BUF_REWARDS, RW_BUF_TERMINATED, RW_BUF_TRUNCATED,
-        RW_BUF_ACTIONS, RW_BUF_RNG, RW_BUF_OBS, RW_BUF_GRID};
+        RW_BUF_ACTIONS, RW_BUF_RNG, RW_BUF_FEATURES, RW_BUF_OBS, RW_BUF_GRID};
     auto up = [](size_t x) { return (x + 4095) & ~(size_t)4095; };
     size_t slab_bytes = 0, off[RW_BUF_KIND_COUNT];
     for (int k : order) {
@@ -408,6 +432,10 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.need_reset = (uint8_t *)eng->buf[RW_BUF_NEED_RESET].ptr;
     p.truncated = (uint8_t *)eng->buf[RW_BUF_TRUNCATED].ptr;
     p.status = eng->d_status;
+    p.n_layers = n_layers;
+    p.directional = cfg->image_directional ? 1 : 0;
+    for (int l = 0; l < rw::MAX_IMAGE_LAYERS; ++l) p.layers[l] = l < n_layers ? layers[l] : 0;
+    p.features = obs_type == RW_OBS_IMAGE_DICT ? (float *)eng->buf[RW_BUF_FEATURES].ptr : nullptr;
     rw::LaunchArgs &la = eng->la;
     la.actions = (const int32_t *)eng->buf[RW_BUF_ACTIONS].ptr;
     la.reset_mask = eng->d_mask;

@@ -58,7 +58,10 @@ enum : int { DIR_UP = 0, DIR_DOWN = 1, DIR_LEFT = 2, DIR_RIGHT = 3 };
 enum : int { REW_GLOBAL = 0, REW_INDIVIDUAL = 1, REW_TWO_STAGE = 2 };
 enum : int { AR_DISABLED = 0, AR_NEXT_STEP = 1, AR_SAME_STEP = 2 };
 enum : int { STATUS_INVALID_ACTION = 1 };
-enum : int { MAX_GOALS = 16 };
+enum : int { MAX_GOALS = 16, MAX_IMAGE_LAYERS = 8 };
+enum : int { OBS_FLATTENED = 0, OBS_IMAGE = 1 };
+// ImageLayer values of the reference (rware/warehouse.py:59-70); 3 and 4 are rejected by the host
+enum : int { LAYER_SHELVES = 0, LAYER_REQUESTS = 1, LAYER_AGENTS = 2, LAYER_GOALS = 5, LAYER_ACCESSIBLE = 6 };
 
 struct Params {
     // config
@@ -79,6 +82,10 @@ struct Params {
     uint8_t *need_reset;  // [B]
     uint8_t *truncated;   // [B]
     int32_t *status;      // [1] sticky error bits
+    // IMAGE / IMAGE_DICT observations (rware/warehouse.py:527-596); unused by the FLATTENED kernels
+    int32_t n_layers, directional;
+    int32_t layers[MAX_IMAGE_LAYERS];
+    float *features;      // [B][N][6] one-hot direction, on_highway, carrying (IMAGE_DICT), or nullptr
 };
 
 // What changes from launch to launch.  The kernel-argument segment is rewritten by the host for every
@@ -208,7 +215,7 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
     }
 }
 
-template <int R, typename CellT, typename Cfg, bool kRollout>
+template <int R, typename CellT, typename Cfg, bool kRollout, int kObs = OBS_FLATTENED>
 __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restrict__ cp, const LaunchArgs la) {
     const Params &p = *cp;  // constant per engine, device-resident, L2-warm
     const int op = la.op;
@@ -612,12 +619,20 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             p.ax[gi] = s_ax[i]; p.ay[gi] = s_ay[i]; p.adir[gi] = s_dir[i];
             p.acarry[gi] = 0; p.adeliv[gi] = 0;
             rew_t[gi] = s_rew[i];
-            s_fx[i] = coordf(0, s_ax[i]);
-            s_fy[i] = coordf(1, s_ay[i]);
-            const uint32_t self = (2u << s_dir[i]) | (on_highway(s_ay[i] * W + s_ax[i]) ? 32u : 0u);
-            const int bit = i * L + 2, wd = bit >> 5, sh = bit & 31;
-            atomicOr(&s_obits[wd], self << sh);
-            if (sh > 26) atomicOr(&s_obits[wd + 1], self >> (32 - sh));
+            if (kObs == OBS_FLATTENED) {
+                s_fx[i] = coordf(0, s_ax[i]);
+                s_fy[i] = coordf(1, s_ay[i]);
+                const uint32_t self = (2u << s_dir[i]) | (on_highway(s_ay[i] * W + s_ax[i]) ? 32u : 0u);
+                const int bit = i * L + 2, wd = bit >> 5, sh = bit & 31;
+                atomicOr(&s_obits[wd], self << sh);
+                if (sh > 26) atomicOr(&s_obits[wd + 1], self >> (32 - sh));
+            } else if (p.features) {
+                float *f = p.features + gi * 6;
+                const int d = s_dir[i];
+                f[0] = d == 0 ? 1.0f : 0.0f; f[1] = d == 1 ? 1.0f : 0.0f; f[2] = d == 2 ? 1.0f : 0.0f; f[3] = d == 3 ? 1.0f : 0.0f;
+                f[4] = on_highway(s_ay[i] * W + s_ax[i]) ? 1.0f : 0.0f;
+                f[5] = 0.0f;
+            }
         }
         for (int e = tid; e < ne; e += T) {
             const int32_t *ev = s_envi + e * ENVI_W;
@@ -682,7 +697,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                         g_shadow[ge * HW + tg] = (CellT)carry;
                     }
                 }
-        } else {  // self part of the observation, k = 2..7 (:643-647), and the float coordinates k = 0,1
+        } else if (kObs == OBS_FLATTENED) {  // self part of the observation, k = 2..7 (:643-647), and the float coordinates k = 0,1
             for (int i = lane; i < nea; i += 64) {
                 if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
                 const int x = s_ax[i], y = s_ay[i];
@@ -693,12 +708,22 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 atomicOr(&s_obits[wd], self << sh);
                 if (sh > 26) atomicOr(&s_obits[wd + 1], self >> (32 - sh));
             }
+        } else if (p.features) {  // IMAGE_DICT feature vector: one-hot direction, on_highway, carrying (:730-738)
+            for (int i = lane; i < nea; i += 64) {
+                if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
+                float *f = p.features + ((size_t)e0 * N + i) * 6;
+                const int d = s_dir[i];
+                f[0] = d == 0 ? 1.0f : 0.0f; f[1] = d == 1 ? 1.0f : 0.0f; f[2] = d == 2 ? 1.0f : 0.0f; f[3] = d == 3 ? 1.0f : 0.0f;
+                f[4] = on_highway(s_ay[i] * W + s_ax[i]) ? 1.0f : 0.0f;
+                f[5] = s_carry[i] ? 1.0f : 0.0f;
+            }
         }
     }
 
     // ---------------------------------------------------------------- P7: observation bits (:598-674)
     // One contiguous bit string per workgroup: bit (i*L + k) == obs[agent i][k] for k >= 2; the two
     // coordinate slots k = 0,1 stay 0 here and are filled in as floats during expansion.
+    if constexpr (kObs == OBS_FLATTENED) {
     // one thread per (agent, window row): the agent's position is read once, the row's WIN cells are
     // gathered with independent LDS reads, and the row's 7*WIN bits go out in one or two LDS atomics
     for (int w = tid; w < nea * WIN; w += T) {
@@ -743,11 +768,48 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             atomicOr(&s_obits[wd + 3], w3);
         }
     }
+    } else {
+        // IMAGE observation: per agent n_layers x WIN x WIN binary values, optionally rotated into the
+        // agent's heading (np.rot90 of the north-up window, :584-595).  Same contiguous bit string; one
+        // thread per (agent, layer, image row).
+        const int Limg = p.n_layers * CELLS;
+        for (int w = tid; w < nea * p.n_layers * WIN; w += T) {
+            const int i = w / (p.n_layers * WIN), lr = w - i * (p.n_layers * WIN);
+            const int l = lr / WIN, r = lr - l * WIN;
+            const int e = rw_div18(i, mN), layer = p.layers[l];
+            const int ax = s_ax[i], ay = s_ay[i], d = p.directional ? s_dir[i] : DIR_UP;
+            uint32_t bits = 0;
+#pragma unroll
+            for (int cc = 0; cc < WIN; ++cc) {
+                int wr = r, wc = cc;  // (r, cc) indexes the rotated image, (wr, wc) the north-up window
+                if (d == DIR_DOWN) { wr = WIN - 1 - r; wc = WIN - 1 - cc; }   // k = 2
+                else if (d == DIR_LEFT) { wr = WIN - 1 - cc; wc = r; }        // k = 3
+                else if (d == DIR_RIGHT) { wr = cc; wc = WIN - 1 - r; }       // k = 1
+                const int y = ay - R + wr, x = ax - R + wc;
+                uint32_t v = 0;  // np.pad(..., mode="constant") outside the map (:573)
+                if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+                    const int cell = y * W + x, c = e * HW + cell;
+                    const int ida = s_ga[c] & 0x7f, ids = s_gs[c];
+                    if (layer == LAYER_SHELVES) v = ids ? 1u : 0u;
+                    else if (layer == LAYER_REQUESTS) v = ids ? ((s_req[e * SW + (ids >> 5)] >> (ids & 31)) & 1u) : 0u;
+                    else if (layer == LAYER_AGENTS) v = ida ? 1u : 0u;
+                    else if (layer == LAYER_GOALS) {
+                        for (int g = 0; g < p.n_goals; ++g) v |= (p.goal_cells[g] == cell) ? 1u : 0u;
+                    } else v = ida ? 0u : 1u;  // LAYER_ACCESSIBLE
+                }
+                bits |= v << cc;
+            }
+            const int bit = i * Limg + (l * WIN + r) * WIN;
+            const int wd = bit >> 5, sh = bit & 31;
+            atomicOr(&s_obits[wd], bits << sh);
+            if (sh + WIN > 32) atomicOr(&s_obits[wd + 1], bits >> (32 - sh));
+        }
+    }
     lds_barrier();
     RW_MARK(TL_OBS_BITS);
 
     // ---------------------------------------------------------------- ST: obs, float4 #q == nibble #q
-    {
+    if constexpr (kObs == OBS_FLATTENED) {
         const int nf = nea * L;
         const int nf4 = nf >> 2;
         float *out = obs_t + (size_t)e0 * N * L;  // 16-byte aligned: e0 is a multiple of 4
@@ -791,6 +853,22 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             out[g] = (k >= 2) ? (((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f)
                               : (k == 0 ? s_fx[i] : s_fy[i]);
         }
+    }
+    else {  // IMAGE: every element is a bit of the string; no coordinate slots
+        const int Limg = p.n_layers * CELLS;
+        const int nf = nea * Limg, nf4 = nf >> 2;
+        float *out = obs_t + (size_t)e0 * N * Limg;  // 16-byte aligned: e0 is a multiple of 4
+        float4 *out4 = reinterpret_cast<float4 *>(out);
+        for (int q4 = tid; q4 < nf4; q4 += T) {
+            const uint32_t nib = s_obits[q4 >> 3] >> ((q4 & 7) << 2);
+            float4 v;
+            v.x = (nib & 1u) ? 1.0f : 0.0f;
+            v.y = (nib & 2u) ? 1.0f : 0.0f;
+            v.z = (nib & 4u) ? 1.0f : 0.0f;
+            v.w = (nib & 8u) ? 1.0f : 0.0f;
+            out4[q4] = v;
+        }
+        for (int g = (nf4 << 2) + tid; g < nf; g += T) out[g] = ((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f;
     }
     RW_MARK(TL_OBS_STORED);
     }  // fused-rollout step loop

@@ -30,6 +30,20 @@ class ObservationType(Enum):  # rware/warehouse.py:52-56
     IMAGE_DICT = 3
 
 
+class ImageLayer(Enum):  # rware/warehouse.py:59-70
+    SHELVES = 0
+    REQUESTS = 1
+    AGENTS = 2
+    AGENT_DIRECTION = 3  # not accelerated: the reference writes it with transposed indices (:552)
+    AGENT_LOAD = 4       # not accelerated: same (:558)
+    GOALS = 5
+    ACCESSIBLE = 6
+
+
+DEFAULT_IMAGE_LAYERS = (ImageLayer.SHELVES, ImageLayer.REQUESTS, ImageLayer.AGENTS, ImageLayer.GOALS,
+                        ImageLayer.ACCESSIBLE)  # rware/warehouse.py:160-166
+
+
 def enum_value(v):
     """Accepts this package's enums, the reference's enums (same values) or plain ints."""
     return int(getattr(v, "value", v))

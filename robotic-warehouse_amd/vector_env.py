@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 from . import _capi
-from .enums import Action, ObservationType, RewardType, enum_value
+from .enums import DEFAULT_IMAGE_LAYERS, Action, ImageLayer, ObservationType, RewardType, enum_value
 from .layout import Layout, layout_from_params, layout_from_str, obs_length
 
 try:  # gymnasium is optional (absent in the build image); subclass VectorEnv when present
@@ -64,8 +64,16 @@ class WarehouseVecEnv(_VectorEnvBase):
                  envs_per_workgroup: int = 0, threads_per_workgroup: int = 0, library: str | None = None):
         if msg_bits != 0:
             raise NotImplementedError("msg_bits > 0 is outside the accelerated path (every registered id uses 0)")
-        if enum_value(observation_type) != ObservationType.FLATTENED.value:
-            raise NotImplementedError("only ObservationType.FLATTENED (the reference default) is accelerated")
+        self.observation_type = ObservationType(enum_value(observation_type))
+        if self.observation_type == ObservationType.DICT:
+            raise NotImplementedError("ObservationType.DICT (nested Python dicts) is not accelerated; FLATTENED carries the same content")
+        layers = tuple(ImageLayer(enum_value(l)) for l in (image_observation_layers or DEFAULT_IMAGE_LAYERS))
+        if self.observation_type != ObservationType.FLATTENED and any(
+                l in (ImageLayer.AGENT_DIRECTION, ImageLayer.AGENT_LOAD) for l in layers):
+            raise NotImplementedError("ImageLayer.AGENT_DIRECTION / AGENT_LOAD are written with transposed indices by the "
+                                      "reference (rware/warehouse.py:552,558) and are not accelerated")
+        self.image_observation_layers = layers
+        self.image_observation_directional = bool(image_observation_directional)
         if output not in ("numpy", "torch"):
             raise ValueError("output must be 'numpy' or 'torch'")
         self.layout: Layout = layout_from_str(layout) if layout else layout_from_params(shelf_columns, shelf_rows, column_height)
@@ -114,7 +122,9 @@ class WarehouseVecEnv(_VectorEnvBase):
                 max_steps=max_steps, reward_type=self.reward_type.value,
                 normalised_coordinates=normalised_coordinates, autoreset_mode=autoreset_mode, device_id=dev,
                 envs_per_workgroup=envs_per_workgroup, threads_per_workgroup=threads_per_workgroup,
-                stream=stream, library=library))
+                stream=stream, library=library, observation_type=self.observation_type.value,
+                image_layers=[l.value for l in layers] if self.observation_type != ObservationType.FLATTENED else (),
+                image_directional=image_observation_directional))
         self._bounds = [b for b in self._bounds if b[1] > b[0]]
         self.devices = devices[: len(self.engines)]
         self.n_shelves = self.engines[0].S
@@ -124,6 +134,14 @@ class WarehouseVecEnv(_VectorEnvBase):
     # ------------------------------------------------------------------------------- spaces
     def _make_spaces(self):
         n, l, b = self.n_agents, self.obs_length, self.num_envs
+        if self.observation_type != ObservationType.FLATTENED:
+            win = 2 * self.sensor_range + 1
+            shape = (len(self.image_observation_layers), win, win)
+            self.single_observation_space = tuple(_Space(shape, np.float32) for _ in range(n))
+            self.single_action_space = tuple(_Space((), np.int64, n=len(Action)) for _ in range(n))
+            self.observation_space = _Space((b, n) + shape, np.float32)
+            self.action_space = _Space((b, n), np.int64, n=len(Action))
+            return
         if _gym is not None:
             sp = _gym.spaces
             sa_obs = sp.Box(low=-float("inf"), high=float("inf"), shape=(l,), dtype=np.float32)
@@ -187,7 +205,7 @@ class WarehouseVecEnv(_VectorEnvBase):
     def step_wait(self):
         if self.output == "torch":
             v = self._torch_views()
-            return v["obs"], v["rewards"], v["terminated"].bool(), v["truncated"].bool(), {}
+            return self._observations(), v["rewards"], v["terminated"].bool(), v["truncated"].bool(), {}
         obs = self._observations()
         rew = self._gather("rewards")
         term = self._gather("terminated").astype(bool)
@@ -233,15 +251,21 @@ class WarehouseVecEnv(_VectorEnvBase):
         return parts[0] if len(parts) == 1 else np.concatenate(parts, axis=1 if name == "rng" else 0)
 
     def _observations(self):
+        """FLATTENED: (B, N, L).  IMAGE: (B, N, C, 2r+1, 2r+1).  IMAGE_DICT: {"image": ..., "features": (B, N, 6)}
+        (the batched form of the reference's per-agent dicts, rware/warehouse.py:739-742)."""
         if self.output == "torch":
-            return self._torch_views()["obs"]
-        return self._gather("obs")
+            v = self._torch_views()
+            return {"image": v["obs"], "features": v["features"]} if self.observation_type == ObservationType.IMAGE_DICT else v["obs"]
+        obs = self._gather("obs")
+        if self.observation_type == ObservationType.IMAGE_DICT:
+            return {"image": obs, "features": self._gather("features")}
+        return obs
 
     def _torch_views(self):
         if self._tviews is None:
             t, eng, dev = self._torch, self.engines[0], self.devices[0]
             self._tviews = {k: t.as_tensor(eng.device_array(k), device=f"cuda:{dev}")
-                            for k in ("obs", "rewards", "terminated", "truncated")}
+                            for k in ("obs", "rewards", "terminated", "truncated", "features")}
         return self._tviews
 
     def device_tensor(self, name):

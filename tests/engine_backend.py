@@ -22,15 +22,19 @@ class EngineBackend:
         self.env = rware_amd.WarehouseVecEnv(num_envs, autoreset_mode=autoreset_mode, library=library, **kwargs)
         self.mode = autoreset_mode
 
+    @staticmethod
+    def _obs(o):  # IMAGE_DICT -> (image, features), the form the replay harness compares
+        return (o["image"], o["features"]) if isinstance(o, dict) else o
+
     def reset(self, seed=None, mask=None):
         obs, _ = self.env.reset(seed=seed, mask=mask)
-        return obs
+        return self._obs(obs)
 
     def step_autoreset(self, actions, mode):
         assert mode == self.mode
         obs, rew, term, trunc, _ = self.env.step(actions)
         assert not trunc.any()
-        return obs, rew, term
+        return self._obs(obs), rew, term
 
     def get_state(self):
         return self.env.get_state()

@@ -51,6 +51,11 @@ CASES = [
       "reward_type": 1, "layout": LAYOUT_STR}, 3, 450, 7000),
     ("small-19ag", "rware-small-19ag-v2", {}, 2, 300, 8000),
     ("tiny-1ag-hard-q0", "rware-tiny-1ag-hard-v2", {}, 2, 120, 9000),
+    # IMAGE / IMAGE_DICT observations (warehouse.py:527-596), default layers
+    ("img-small-4ag-directional", "rware-small-4ag-v2", {"observation_type": 2}, 3, 260, 10000),
+    ("img-tiny-3ag-northup-sr2", "rware-tiny-3ag-v2",
+     {"observation_type": 2, "image_observation_directional": False, "sensor_range": 2}, 2, 200, 11000),
+    ("imgdict-medium-6ag-hard", "rware-medium-6ag-hard-v2", {"observation_type": 3, "max_steps": 90}, 2, 200, 12000),
 ]
 
 
@@ -61,24 +66,36 @@ def gen_case(name, env_id, extra, E, T, seed):
     kw_json = dict(kw)
     kw_json["reward_type"] = int(getattr(kw["reward_type"], "value", kw["reward_type"]))
     kw["reward_type"] = wh.RewardType(kw_json["reward_type"])
+    obs_type = int(kw_json.get("observation_type", 1))
+    kw["observation_type"] = wh.ObservationType(obs_type)
+
+    def obs_arrays(o):
+        """(obs, features) of one env in array form for the configured observation type."""
+        if obs_type == 3:
+            return (np.stack([a["image"] for a in o]).astype(np.float32),
+                    np.stack([a["features"] for a in o]).astype(np.float32))
+        return rr.obs_array(o), None
     envs = [wh.Warehouse(**kw) for _ in range(E)]
     N = envs[0].n_agents
     pol = np.random.default_rng(seed + 77)
     rec = {k: [] for k in ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry",
                            "agent_delivered", "queue", "steps", "inactive", "rng",
-                           "obs", "rewards", "done", "actions", "was_reset")}
+                           "obs", "features", "rewards", "done", "actions", "was_reset")}
 
     def record(snaps, obs, rew, done, acts, was_reset):
         for k in ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry", "agent_delivered",
                   "queue", "steps", "inactive", "rng"):
             rec[k].append(np.stack([s[k] for s in snaps]))
-        rec["obs"].append(np.stack(obs))
+        rec["obs"].append(np.stack([o[0] for o in obs]))
+        if obs_type == 3:
+            rec["features"].append(np.stack([o[1] for o in obs]))
         rec["rewards"].append(np.asarray(rew, np.float32))
         rec["done"].append(np.asarray(done, np.uint8))
         rec["actions"].append(np.asarray(acts, np.int8))
         rec["was_reset"].append(np.asarray(was_reset, np.uint8))
 
-    obs0 = [rr.obs_array(env.reset(seed=seed + e)[0]) for e, env in enumerate(envs)]
+    obs0_pairs = [obs_arrays(env.reset(seed=seed + e)[0]) for e, env in enumerate(envs)]
+    obs0 = [o[0] for o in obs0_pairs]
     init = {k: np.stack([rr.snapshot(env)[k] for env in envs]) for k in
             ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry", "agent_delivered",
              "queue", "steps", "inactive", "rng")}
@@ -103,14 +120,14 @@ def gen_case(name, env_id, extra, E, T, seed):
                 o, r, d, _, _ = rr.ref_step(env, a)
                 was_reset.append(0)
             deliveries += sum(r)
-            obs.append(rr.obs_array(o))
+            obs.append(obs_arrays(o))
             rew.append(r)
             done.append(d)
             snaps.append(rr.snapshot(env))
             prev_done[e] = bool(d)
         record(snaps, obs, rew, done, acts, was_reset)
 
-    out = {k: np.stack(v) for k, v in rec.items()}
+    out = {k: np.stack(v) for k, v in rec.items() if v}
     ids_max = max(int(out["grid"].max()), 1)
     out["grid"] = out["grid"].astype(np.uint8 if ids_max < 256 else np.int16)
     for k in ("agent_x", "agent_y", "agent_dir", "agent_delivered"):
@@ -131,7 +148,8 @@ def gen_case(name, env_id, extra, E, T, seed):
         "deliveries": float(deliveries),
     }
     path = os.path.join(HERE, f"{name}.npz")
-    np.savez_compressed(path, meta=json.dumps(meta), obs0=obs0s,
+    extra_arrays = {"features0": np.stack([o[1] for o in obs0_pairs])} if obs_type == 3 else {}
+    np.savez_compressed(path, meta=json.dumps(meta), obs0=obs0s, **extra_arrays,
                         **{f"init_{k}": v for k, v in init.items()}, **out)
     print(f"{name}: E={E} T={T} deliveries={deliveries} resets={int(out['was_reset'].sum())} "
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")

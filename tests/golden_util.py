@@ -38,12 +38,20 @@ def assert_state_equal(got: dict, z, t, prefix=""):
 
 def replay(backend, meta, z, steps=None):
     """backend: .reset(seed) -> obs ; .step_autoreset(actions, mode) -> (obs, rew, done) ; .get_state()"""
-    obs = backend.reset(seed=meta["seed"])
+    def split(o):  # IMAGE_DICT backends return (image, features)
+        return (o[0], o[1]) if isinstance(o, tuple) else (o, None)
+
+    obs, feat = split(backend.reset(seed=meta["seed"]))
     assert np.array_equal(np.asarray(obs, np.float32), z["obs0"].astype(np.float32)), "reset obs"
+    if "features0" in z:
+        assert np.array_equal(np.asarray(feat, np.float32), z["features0"]), "reset features"
     assert_state_equal(backend.get_state(), z, None, prefix="init_")
     T = meta["T"] if steps is None else min(steps, meta["T"])
     for t in range(T):
         obs, rew, done = backend.step_autoreset(z["actions"][t].astype(np.int32), "next_step")
+        obs, feat = split(obs)
+        if "features" in z:
+            assert np.array_equal(np.asarray(feat, np.float32), z["features"][t]), f"features t={t}"
         assert np.array_equal(np.asarray(rew, np.float32), z["rewards"][t]), f"rewards t={t}"
         assert np.array_equal(np.asarray(done).astype(np.uint8), z["done"][t]), f"done t={t}"
         assert_state_equal(backend.get_state(), z, t)

@@ -24,6 +24,9 @@ pytestmark = pytest.mark.timeout(600)
     ("small-3ag-normcoord-sr3", (4, 64)),
     ("tiny-1ag-hard-q0", (4, 64)),
     ("small-19ag", (4, 64)),
+    ("img-small-4ag-directional", (0, 0)),
+    ("img-tiny-3ag-northup-sr2", (4, 64)),
+    ("imgdict-medium-6ag-hard", (8, 128)),
 ])
 def test_emulated_engine_matches_reference_golden(name, geom):
     meta, z = gu.load_fixture(name)
@@ -103,7 +106,10 @@ def test_host_layer_errors_and_views():
     with pytest.raises(NotImplementedError):
         rware_amd.WarehouseVecEnv(2, library=LIB, **dict(kw, msg_bits=1))
     with pytest.raises(NotImplementedError):
-        rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.IMAGE, **kw)
+        rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.DICT, **kw)
+    with pytest.raises(NotImplementedError):   # transposed-index layers of the reference (:552, :558)
+        rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.IMAGE,
+                                  image_observation_layers=[rware_amd.ImageLayer.AGENTS, rware_amd.ImageLayer.AGENT_DIRECTION], **kw)
     with pytest.raises(rware_amd._capi.EngineError):
         rware_amd.WarehouseVecEnv(2, library=LIB, envs_per_workgroup=6, **kw)   # not a multiple of 4
     env.close()
@@ -227,4 +233,37 @@ def test_snapshot_restore_replays_bit_identically():
         for x, y in zip(a[:4], b[:4]):
             assert np.array_equal(x, y)
     env.free_snapshot(snap)
+    env.close()
+
+
+@pytest.mark.parametrize("obs_type,directional,layers,sr", [
+    (2, True, None, 1),
+    (2, False, [6, 0, 5], 2),          # ACCESSIBLE, SHELVES, GOALS in a custom channel order
+    (3, True, [2, 1], 3),              # IMAGE_DICT with two layers
+])
+def test_image_observations_match_oracle(obs_type, directional, layers, sr):
+    kw = rware_amd.env_kwargs("rware-small-5ag-v1")
+    kw.update(sensor_range=sr, max_steps=16)
+    kw["reward_type"] = kw["reward_type"].value
+    extra = dict(observation_type=obs_type, image_observation_directional=directional, image_observation_layers=layers)
+    B = 6
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=128, **kw, **extra)
+    orc = OracleVecEnv(B, **kw, **extra)
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return np.array_equal(a["image"], b[0]) and np.array_equal(a["features"], b[1])
+        return np.array_equal(a, b)
+
+    assert same(env.reset(seed=4)[0], orc.reset(seed=4))
+    rng = np.random.default_rng(7)
+    acts = rng.choice(5, size=(40, B, 5), p=[.1, .5, .15, .15, .1])
+    for t in range(25):
+        o, r, d, _, _ = env.step(acts[t])
+        o2, r2, d2 = orc.step_autoreset(acts[t], "next_step")
+        assert same(o, o2) and np.array_equal(r, r2), t
+    img, rew, term = env.rollout(acts[25:])      # fused rollout writes the image tape
+    for t in range(25, 40):
+        o2, r2, d2 = orc.step_autoreset(acts[t], "next_step")
+        assert np.array_equal(img[t - 25], o2[0] if isinstance(o2, tuple) else o2) and np.array_equal(rew[t - 25], r2), t
     env.close()

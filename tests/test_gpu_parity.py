@@ -199,3 +199,29 @@ def test_snapshot_restore_on_device():
         assert np.array_equal(x, y)
     env.free_snapshot(snap)
     env.close()
+
+
+@pytest.mark.parametrize("env_id,obs_type,directional,sr,B", [
+    ("rware-small-4ag-v1", 2, True, 1, 4096),
+    ("rware-medium-6ag-hard-v1", 3, False, 2, 1024),
+])
+def test_image_observations_match_oracle(env_id, obs_type, directional, sr, B):
+    kw = rware_amd.env_kwargs(env_id)
+    kw.update(sensor_range=sr, max_steps=60)
+    kw["reward_type"] = kw["reward_type"].value
+    extra = dict(observation_type=obs_type, image_observation_directional=directional)
+    env = rware_amd.WarehouseVecEnv(B, **kw, **extra)
+    orc = OracleVecEnv(B, **kw, **extra)
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return np.array_equal(a["image"], b[0]) and np.array_equal(a["features"], b[1])
+        return np.array_equal(a, b)
+
+    assert same(env.reset(seed=4)[0], orc.reset(seed=4))
+    acts = np.random.default_rng(7).choice(5, size=(130, B, kw["n_agents"]), p=[.1, .5, .15, .15, .1])
+    for t in range(130):
+        o, r, d, _, _ = env.step(acts[t])
+        o2, r2, d2 = orc.step_autoreset(acts[t], "next_step")
+        assert same(o, o2) and np.array_equal(r, r2) and np.array_equal(d, d2.astype(bool)), t
+    env.close()
