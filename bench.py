@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="envs per GPU (headline: 16384)")
     ap.add_argument("--env-id", default=ENV_ID)
     ap.add_argument("--sensor-range", type=int, default=0, help="override sensor_range (BASELINE config 5 uses 2)")
+    ap.add_argument("--observation-type", type=int, default=1, help="1 FLATTENED (headline), 2 IMAGE, 3 IMAGE_DICT")
     ap.add_argument("--envs-per-wg", type=int, default=0)
     ap.add_argument("--threads-per-wg", type=int, default=0)
     ap.add_argument("--many", type=int, default=0,
@@ -101,6 +102,8 @@ def main():
     kw = rware_amd.env_kwargs(args.env_id)
     if args.sensor_range:
         kw["sensor_range"] = args.sensor_range
+    if args.observation_type != 1:
+        kw["observation_type"] = args.observation_type
     B, N = args.batch, kw["n_agents"]
     env = rware_amd.WarehouseVecEnv(B, devices=[local_rank], envs_per_workgroup=args.envs_per_wg,
                                     threads_per_workgroup=args.threads_per_wg, **kw)

@@ -772,13 +772,14 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // IMAGE observation: per agent n_layers x WIN x WIN binary values, optionally rotated into the
         // agent's heading (np.rot90 of the north-up window, :584-595).  Same contiguous bit string; one
         // thread per (agent, layer, image row).
+        // thread per (agent, image row): the row's WIN cells are read once and give one WIN-bit mask per
+        // property; every requested layer is then one of those masks.
         const int Limg = p.n_layers * CELLS;
-        for (int w = tid; w < nea * p.n_layers * WIN; w += T) {
-            const int i = w / (p.n_layers * WIN), lr = w - i * (p.n_layers * WIN);
-            const int l = lr / WIN, r = lr - l * WIN;
-            const int e = rw_div18(i, mN), layer = p.layers[l];
+        for (int w = tid; w < nea * WIN; w += T) {
+            const int i = w / WIN, r = w - i * WIN;
+            const int e = rw_div18(i, mN);
             const int ax = s_ax[i], ay = s_ay[i], d = p.directional ? s_dir[i] : DIR_UP;
-            uint32_t bits = 0;
+            uint32_t m_shelf = 0, m_req = 0, m_agent = 0, m_goal = 0, m_map = 0;
 #pragma unroll
             for (int cc = 0; cc < WIN; ++cc) {
                 int wr = r, wc = cc;  // (r, cc) indexes the rotated image, (wr, wc) the north-up window
@@ -786,23 +787,29 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 else if (d == DIR_LEFT) { wr = WIN - 1 - cc; wc = r; }        // k = 3
                 else if (d == DIR_RIGHT) { wr = cc; wc = WIN - 1 - r; }       // k = 1
                 const int y = ay - R + wr, x = ax - R + wc;
-                uint32_t v = 0;  // np.pad(..., mode="constant") outside the map (:573)
-                if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+                if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {  // outside: np.pad zeros (:573)
                     const int cell = y * W + x, c = e * HW + cell;
                     const int ida = s_ga[c] & 0x7f, ids = s_gs[c];
-                    if (layer == LAYER_SHELVES) v = ids ? 1u : 0u;
-                    else if (layer == LAYER_REQUESTS) v = ids ? ((s_req[e * SW + (ids >> 5)] >> (ids & 31)) & 1u) : 0u;
-                    else if (layer == LAYER_AGENTS) v = ida ? 1u : 0u;
-                    else if (layer == LAYER_GOALS) {
-                        for (int g = 0; g < p.n_goals; ++g) v |= (p.goal_cells[g] == cell) ? 1u : 0u;
-                    } else v = ida ? 0u : 1u;  // LAYER_ACCESSIBLE
+                    m_map |= 1u << cc;
+                    if (ida) m_agent |= 1u << cc;
+                    if (ids) {
+                        m_shelf |= 1u << cc;
+                        m_req |= ((s_req[e * SW + (ids >> 5)] >> (ids & 31)) & 1u) << cc;
+                    }
+                    for (int g = 0; g < p.n_goals; ++g)
+                        if (p.goal_cells[g] == cell) m_goal |= 1u << cc;
                 }
-                bits |= v << cc;
             }
-            const int bit = i * Limg + (l * WIN + r) * WIN;
-            const int wd = bit >> 5, sh = bit & 31;
-            atomicOr(&s_obits[wd], bits << sh);
-            if (sh + WIN > 32) atomicOr(&s_obits[wd + 1], bits >> (32 - sh));
+            for (int l = 0; l < p.n_layers; ++l) {
+                const int layer = p.layers[l];
+                const uint32_t bits = layer == LAYER_SHELVES ? m_shelf : layer == LAYER_REQUESTS ? m_req
+                                    : layer == LAYER_AGENTS ? m_agent : layer == LAYER_GOALS ? m_goal
+                                    : (m_map & ~m_agent);  // LAYER_ACCESSIBLE
+                const int bit = i * Limg + (l * WIN + r) * WIN;
+                const int wd = bit >> 5, sh = bit & 31;
+                atomicOr(&s_obits[wd], bits << sh);
+                if (sh + WIN > 32) atomicOr(&s_obits[wd + 1], bits >> (32 - sh));
+            }
         }
     }
     lds_barrier();
