@@ -17,13 +17,16 @@
 //         P3  apply (move / turn / load / unload) + incremental grid update instead of
 //             _recalc_grid                                   (:880-901, :749-755)
 //         P5  goals, request replacement (numpy-exact PCG64 draw), rewards, termination (:903-942)
-//       and, straight from the agent lanes' registers, the state write-back: agent SoA, rewards,
-//       queue, counters, and the grid/shadow patch of the <= 2N cells per layer that changed.
 //   RS  on-device reset for autoreset / rw_reset, numpy-exact draws (rare path)   (:757-802)
-//   P7  observation: per (agent, window cell) 7-bit codes OR-ed into ONE contiguous bit string
-//       per workgroup (bit g == obs element g of the chunk), so float4 #q is nibble #q (:598-674),
-//       written with dwordx4 stores.  The barriers around it wait on LDS only, so the state
-//       stores issued in AG drain underneath.
+//   WB  write-back, one role per wavefront so that the four jobs run side by side: per-env
+//       counters/flags + queue; agent SoA + rewards (coalesced); the grid/shadow patch of the
+//       <= 2N cells per layer that changed; the self part of the observation.
+//   P7  observation (:598-674): per (agent, window row) the 7-bit cell codes are OR-ed into ONE
+//       contiguous bit string per workgroup (bit g == obs element g of the chunk), so float4 #q is
+//       nibble #q; dwordx4 stores, the two coordinate floats per agent in a small second pass.
+//       IMAGE / IMAGE_DICT observations (:527-596) use the same bit string (kObs == OBS_IMAGE).
+//       The barriers after P0 wait on LDS only, so the WB stores drain underneath P7.
+//   The rollout variant (kRollout) wraps AG..P7 in a step loop: the chunk stays in LDS for T steps.
 //
 // Roofline: integer/indexing work, no MFMA; bound by HBM bytes.  Algorithmic bytes per
 // env-step A = 8HW + 4N + 40N + 4Q + 16 + 4NL + 4N + 4; the shadow makes the
