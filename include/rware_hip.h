@@ -88,10 +88,11 @@ enum rw_buffer_kind {
     RW_BUF_RNG = 13,         /* uint64  [6][B]     FIELD-major: state_hi, state_lo, inc_hi, inc_lo,
                                                    has_uint32, uinteger (numpy PCG64 state)       */
     RW_BUF_NEED_RESET = 14,  /* uint8   [B]        NEXT_STEP autoreset: env resets on next step   */
-    RW_BUF_ACTIONS = 15,     /* int32   [B][N]     staging buffer used by rw_step (host actions)  */
+    RW_BUF_ACTIONS = 15,     /* int32   [B][N][1+M] staging buffer used by rw_step (host actions)  */
     RW_BUF_FEATURES = 16,    /* float32 [B][N][6]  IMAGE_DICT features: one-hot direction, on_highway,
                                                    carrying (:727-742); unused otherwise          */
-    RW_BUF_KIND_COUNT = 17
+    RW_BUF_AGENT_MSG = 17,   /* int32   [B][N]     bit k == message[k] of the agent (msg_bits > 0, :89)   */
+    RW_BUF_KIND_COUNT = 18
 };
 
 /* Mirrors the constructor of rware.warehouse.Warehouse (rware/warehouse.py:146-170).  The
@@ -117,6 +118,9 @@ typedef struct rw_config {
     int32_t image_directional;    /* image_observation_directional (:167)                        */
     int32_t n_image_layers;       /* 0 == the reference default list (:160-166)                  */
     int32_t image_layers[8];      /* rw_image_layer values, channel order                        */
+    int32_t msg_bits;             /* M communication bits (:152): an agent's action is then
+                                     [Action, bit_0..bit_{M-1}], L = 8 + (7+M)(2r+1)^2; FLATTENED only */
+    int32_t reserved_;
     const uint8_t *highways;      /* host, [H*W], 1 == highway (no shelf spawns, no unloading)   */
     const int32_t *goals_xy;      /* host, [n_goals][2] = (x, y), list order == reward order     */
     void *stream;                 /* hipStream_t to enqueue on; NULL == engine creates its own   */
@@ -139,8 +143,9 @@ const char *rw_last_error(const rw_engine *eng);
 int rw_reset(rw_engine *eng, const uint64_t *seeds, const uint8_t *mask);
 
 /* replaces Warehouse.step(actions) (:804-946) for all B envs.
- *   rw_step:        actions is a HOST array int32 [B][N]; copied to RW_BUF_ACTIONS, then launched.
- *   rw_step_device: actions is a DEVICE array int32 [B][N] (e.g. the policy's output tensor);
+ *   rw_step:        actions is a HOST array int32 [B][N] ([B][N][1+M] with msg_bits = M); copied to
+ *                   RW_BUF_ACTIONS, then launched.
+ *   rw_step_device: actions is a DEVICE array of the same shape (e.g. the policy's output tensor);
  *                   no copy.  Must stay valid until the step has executed.
  * Results land in RW_BUF_OBS / REWARDS / TERMINATED / TRUNCATED. */
 int rw_step(rw_engine *eng, const int32_t *actions_host);

@@ -191,6 +191,8 @@ def snapshot(env) -> dict:
         "inactive": np.int32(env._cur_inactive_steps),
         "rng": rng_state_tuple(env),
     }
+    if env.msg_bits:
+        out["agent_msg"] = np.array([sum(int(b) << k for k, b in enumerate(a.message)) for a in env.agents], dtype=np.int32)
     assert out["agent_x"].shape == (n,)
     return out
 

@@ -46,6 +46,8 @@ typedef struct orc_cfg {
     int32_t max_steps;      /* 0 == None */
     int32_t reward_type;
     int32_t normalised;
+    int32_t msg_bits;        /* M communication bits per agent (warehouse.py:152, 255-259) */
+    int32_t pad_;
     const uint8_t *highways; /* [H*W] */
     const int32_t *goals;    /* [n_goals*2] (x, y) */
 } orc_cfg;
@@ -62,6 +64,7 @@ typedef struct orc_state {
     int32_t *steps;     /* [B] _cur_steps */
     int32_t *inactive;  /* [B] _cur_inactive_steps */
     uint64_t *rng;      /* [B][6] state_hi,state_lo,inc_hi,inc_lo,has_uint32,uinteger */
+    int32_t *agent_msg; /* [B][N] bit k == message[k] of the agent (Agent.message, :89); msg_bits == 0: unused */
 } orc_state;
 
 /* ------------------------------------------------------------------------------------ */
@@ -212,12 +215,13 @@ int orc_num_shelves(const orc_cfg *c) {
 }
 int orc_obs_len(const orc_cfg *c) {
     int win = (2 * c->R + 1) * (2 * c->R + 1);
-    return 8 + win * 5 + win * 2; /* warehouse.py:432-443 with msg_bits = 0 */
+    return 8 + win * (5 + c->msg_bits) + win * 2; /* warehouse.py:432-443 */
 }
 
 typedef struct {
     int32_t *grid, *ax, *ay, *adir, *acarry, *adeliv, *queue, *steps, *inactive;
     uint64_t *rng;
+    int32_t *amsg;
 } env_view;
 
 static env_view view(const orc_cfg *c, const orc_state *s, int e) {
@@ -232,6 +236,7 @@ static env_view view(const orc_cfg *c, const orc_state *s, int e) {
     v.steps = s->steps + e;
     v.inactive = s->inactive + e;
     v.rng = s->rng + (size_t)e * 6;
+    v.amsg = s->agent_msg ? s->agent_msg + (size_t)e * c->N : 0;
     return v;
 }
 
@@ -261,6 +266,7 @@ static void reset_one(const orc_cfg *c, env_view v) {
     for (int i = 0; i < N; ++i) {
         v.acarry[i] = 0;
         v.adeliv[i] = 0;
+        if (v.amsg) v.amsg[i] = 0; /* Agent(...) starts with message = zeros(msg_bits) :89 */
         v.grid[v.ay[i] * W + v.ax[i]] = i + 1; /* _recalc_grid :754-755 */
     }
     /* request queue: choice(shelfs, size=Q, replace=False) :796-800 ; shelfs[k].id == k+1 */
@@ -301,9 +307,19 @@ static int step_one(const orc_cfg *c, env_view v, const int32_t *act, float *rew
     int32_t *gA = v.grid, *gS = v.grid + HW;
     int req[MAXN], start[MAXN], target[MAXN], commit[MAXN];
     if (N > MAXN) return -1;
+    const int AM = 1 + c->msg_bits; /* per-agent action = [Action, message bits...] (:809-814) */
     for (int i = 0; i < N; ++i) {
-        if (act[i] < 0 || act[i] > 4) return -2; /* Action(action) raises ValueError :814 */
-        req[i] = act[i];
+        if (act[i * AM] < 0 || act[i * AM] > 4) return -2; /* Action(action) raises ValueError :814 */
+        for (int k = 1; k < AM; ++k)
+            if (act[i * AM + k] < 0 || act[i * AM + k] > 1) return -2; /* MultiDiscrete([5, 2, 2, ...]) :255-259 */
+    }
+    for (int i = 0; i < N; ++i) {
+        req[i] = act[i * AM];
+        if (c->msg_bits) { /* agent.message[:] = action[1:] :812 */
+            int m = 0;
+            for (int k = 1; k < AM; ++k) m |= act[i * AM + k] << (k - 1);
+            v.amsg[i] = m;
+        }
     }
     /* intent + shelf-block cancel :825-846 (reads the start-of-step grid) */
     for (int i = 0; i < N; ++i) {
@@ -505,8 +521,8 @@ int orc_step(const orc_cfg *c, int B, orc_state *s, const int32_t *actions, floa
              uint8_t *done, const uint8_t *mask) {
     for (int e = 0; e < B; ++e) {
         if (mask && !mask[e]) continue;
-        int rc = step_one(c, view(c, s, e), actions + (size_t)e * c->N, rewards + (size_t)e * c->N,
-                          done + e);
+        int rc = step_one(c, view(c, s, e), actions + (size_t)e * c->N * (1 + c->msg_bits),
+                          rewards + (size_t)e * c->N, done + e);
         if (rc) return rc;
     }
     return 0;
@@ -545,9 +561,11 @@ static void obs_one(const orc_cfg *c, env_view v, float *obs) {
                     o[k++] = 0.0f;
                     o[k++] = 0.0f;
                     o[k++] = 0.0f;
+                    for (int m = 0; m < c->msg_bits; ++m) o[k++] = 0.0f; /* obs.skip(msg_bits) :660 */
                 } else {
                     o[k++] = 1.0f;
                     for (int d = 0; d < 4; ++d) o[k++] = v.adir[ida - 1] == d ? 1.0f : 0.0f;
+                    for (int m = 0; m < c->msg_bits; ++m) o[k++] = (float)((v.amsg[ida - 1] >> m) & 1); /* :667 */
                 }
                 if (!ids) {
                     o[k++] = 0.0f;

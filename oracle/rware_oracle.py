@@ -33,6 +33,7 @@ class _Cfg(C.Structure):
         ("H", C.c_int32), ("W", C.c_int32), ("N", C.c_int32), ("Q", C.c_int32),
         ("R", C.c_int32), ("n_goals", C.c_int32), ("max_inactivity", C.c_int32),
         ("max_steps", C.c_int32), ("reward_type", C.c_int32), ("normalised", C.c_int32),
+        ("msg_bits", C.c_int32), ("pad_", C.c_int32),
         ("highways", C.c_void_p), ("goals", C.c_void_p),
     ]
 
@@ -40,7 +41,7 @@ class _Cfg(C.Structure):
 class _State(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "grid", "agent_x", "agent_y", "agent_dir", "agent_carry", "agent_delivered",
-        "queue", "steps", "inactive", "rng")]
+        "queue", "steps", "inactive", "rng", "agent_msg")]
 
 
 _lib = None
@@ -111,7 +112,7 @@ class OracleVecEnv:
                  msg_bits=0, sensor_range=1, request_queue_size=2, max_inactivity_steps=None,
                  max_steps=500, reward_type=1, layout=None, normalised_coordinates=False, observation_type=1,
                  image_observation_layers=None, image_observation_directional=True, **_):
-        assert msg_bits == 0
+        self.M = int(msg_bits)
         self.observation_type = int(getattr(observation_type, "value", observation_type))  # 1 FLATTENED 2 IMAGE 3 IMAGE_DICT
         assert self.observation_type in (1, 2, 3)
         self.image_layers = tuple(int(getattr(l, "value", l)) for l in (image_observation_layers or self.DEFAULT_IMAGE_LAYERS))
@@ -125,10 +126,10 @@ class OracleVecEnv:
         self.B, self.N, self.Q, self.R = int(num_envs), int(n_agents), int(request_queue_size), int(sensor_range)
         self.H, self.W = self.hw.shape
         self.S = int((self.hw == 0).sum())
-        self.L = 8 + 7 * (2 * self.R + 1) ** 2
+        self.L = 8 + (7 + self.M) * (2 * self.R + 1) ** 2
         self.cfg = _Cfg(self.H, self.W, self.N, self.Q, self.R, len(self.goals),
                         int(max_inactivity_steps or 0), int(max_steps or 0), reward_type,
-                        int(bool(normalised_coordinates)), self.hw.ctypes.data, self._goals.ctypes.data)
+                        int(bool(normalised_coordinates)), self.M, 0, self.hw.ctypes.data, self._goals.ctypes.data)
         B, N, Q = self.B, self.N, self.Q
         self.grid = np.zeros((B, 2, self.H, self.W), np.int32)
         self.agent_x = np.zeros((B, N), np.int32)
@@ -141,6 +142,7 @@ class OracleVecEnv:
         self.steps = np.zeros(B, np.int32)
         self.inactive = np.zeros(B, np.int32)
         self.rng = np.zeros((B, 6), np.uint64)
+        self.agent_msg = np.zeros((B, N), np.int32)
         self._st = None
 
     FIELDS = ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry", "agent_delivered",
@@ -150,10 +152,13 @@ class OracleVecEnv:
         for f in self.FIELDS:
             a = getattr(self, f)
             assert a.flags.c_contiguous, f
-        return _State(*[getattr(self, f).ctypes.data for f in self.FIELDS])
+        return _State(*[getattr(self, f).ctypes.data for f in self.FIELDS], self.agent_msg.ctypes.data)
 
     def get_state(self):
-        return {f: getattr(self, f).copy() for f in self.FIELDS}
+        out = {f: getattr(self, f).copy() for f in self.FIELDS}
+        if self.M:
+            out["agent_msg"] = self.agent_msg.copy()
+        return out
 
     def set_state(self, **fields):
         for k, v in fields.items():
@@ -175,7 +180,7 @@ class OracleVecEnv:
         return self.obs()
 
     def step(self, actions, mask=None):
-        a = np.ascontiguousarray(np.asarray(actions, dtype=np.int32).reshape(self.B, self.N))
+        a = np.ascontiguousarray(np.asarray(actions, dtype=np.int32).reshape(self.B, self.N * (1 + self.M)))
         rew = np.zeros((self.B, self.N), np.float32)
         done = np.zeros(self.B, np.uint8)
         st = self._state()

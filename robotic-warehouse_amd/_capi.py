@@ -19,7 +19,7 @@ RW_OK, RW_ERR_INVALID_ARG, RW_ERR_INVALID_ACTION, RW_ERR_HIP, RW_ERR_UNSUPPORTED
 BUF = {
     "obs": 0, "rewards": 1, "terminated": 2, "truncated": 3, "grid": 4, "agent_x": 5, "agent_y": 6,
     "agent_dir": 7, "agent_carry": 8, "agent_delivered": 9, "queue": 10, "steps": 11, "inactive": 12,
-    "rng": 13, "need_reset": 14, "actions": 15, "features": 16,
+    "rng": 13, "need_reset": 14, "actions": 15, "features": 16, "agent_msg": 17,
 }
 BUF_DTYPE = {
     "obs": np.float32, "rewards": np.float32, "terminated": np.uint8, "truncated": np.uint8,
@@ -35,7 +35,7 @@ class RwConfig(C.Structure):
         "request_queue_size", "max_inactivity_steps", "max_steps", "reward_type",
         "normalised_coordinates", "autoreset_mode", "n_goals", "device_id",
         "envs_per_workgroup", "threads_per_workgroup", "observation_type", "image_directional",
-        "n_image_layers")] + [("image_layers", C.c_int32 * 8),
+        "n_image_layers")] + [("image_layers", C.c_int32 * 8), ("msg_bits", C.c_int32), ("reserved_", C.c_int32),
         ("highways", C.c_void_p), ("goals_xy", C.c_void_p), ("stream", C.c_void_p)]
 
 
@@ -155,7 +155,7 @@ class Engine:
                  max_inactivity_steps, max_steps, reward_type, normalised_coordinates=False,
                  autoreset_mode="next_step", device_id=0, envs_per_workgroup=0,
                  threads_per_workgroup=0, stream=None, library=None, observation_type=1,
-                 image_layers=(), image_directional=True):
+                 image_layers=(), image_directional=True, msg_bits=0):
         self.lib = load(library)
         self._h = C.c_void_p()
         hw = np.ascontiguousarray(layout.highways, dtype=np.uint8)
@@ -166,7 +166,7 @@ class Engine:
             int(reward_type), int(bool(normalised_coordinates)), AUTORESET[autoreset_mode], len(layout.goals),
             int(device_id), int(envs_per_workgroup), int(threads_per_workgroup),
             int(observation_type), int(bool(image_directional)), len(image_layers),
-            (C.c_int32 * 8)(*[int(l) for l in image_layers]),
+            (C.c_int32 * 8)(*[int(l) for l in image_layers]), int(msg_bits), 0,
             hw.ctypes.data, goals.ctypes.data, C.c_void_p(stream or 0))
         rc = self.lib.rw_create(C.byref(cfg), C.byref(self._h))
         if rc != RW_OK:
@@ -176,6 +176,7 @@ class Engine:
         i = self.info
         self.B, self.N, self.Q, self.L, self.S = i.num_envs, i.n_agents, i.request_queue_size, i.obs_length, i.n_shelves
         self.H, self.W = i.grid_h, i.grid_w
+        self.M = int(msg_bits)
         win = 2 * int(sensor_range) + 1
         obs_shape = (self.B, self.N, self.L) if int(observation_type) == 1 else (self.B, self.N, self.L // (win * win), win, win)
         self.shapes = {
@@ -184,7 +185,8 @@ class Engine:
             "truncated": (self.B,), "grid": (self.B, 2, self.H, self.W), "agent_x": (self.B, self.N),
             "agent_y": (self.B, self.N), "agent_dir": (self.B, self.N), "agent_carry": (self.B, self.N),
             "agent_delivered": (self.B, self.N), "queue": (self.B, self.Q), "steps": (self.B,),
-            "inactive": (self.B,), "rng": (6, self.B), "need_reset": (self.B,), "actions": (self.B, self.N),
+            "inactive": (self.B,), "rng": (6, self.B), "need_reset": (self.B,),
+            "actions": (self.B, self.N, 1 + self.M) if self.M else (self.B, self.N), "agent_msg": (self.B, self.N),
         }
 
     def _check(self, rc):
@@ -213,7 +215,7 @@ class Engine:
 
     def step_host(self, actions_i32):
         a = np.ascontiguousarray(actions_i32, dtype=np.int32)
-        assert a.size == self.B * self.N
+        assert a.size == self.B * self.N * (1 + self.M)
         self._check(self.lib.rw_step(self._h, a.ctypes.data))
 
     def step_device(self, dev_ptr):
@@ -227,7 +229,7 @@ class Engine:
     def rollout_host(self, actions, want_obs=True):
         """`T` fused steps (one launch) from a host action tape (T, B, N); returns host tapes
         (obs (T,B,N,L) or None, rewards (T,B,N), terminated (T,B))."""
-        a = np.ascontiguousarray(actions, dtype=np.int32).reshape(-1, self.B, self.N)
+        a = np.ascontiguousarray(actions, dtype=np.int32).reshape(-1, self.B, self.N * (1 + self.M))
         T = a.shape[0]
         obs = np.empty((T,) + self.shapes["obs"], np.float32) if want_obs else None
         rew = np.empty((T, self.B, self.N), np.float32)

@@ -49,6 +49,7 @@ struct rw_engine {
     void *d_shadow = nullptr;  // compact shelf layer (uint8 when S <= 255, else uint16), the kernel's read path
     bool wide = false;
     bool image = false;        // IMAGE / IMAGE_DICT observation kernels
+    int msg_bits = 0;          // communication bits per agent (FLATTENED only)
     int32_t *d_status = nullptr;
     hipEvent_t events[8]{};
     std::vector<uint8_t> h_highways;
@@ -80,7 +81,10 @@ int fail(rw_engine *eng, int code, const char *fmt, ...) {
 using step_kernel_t = void (*)(const rw::Params *, const rw::LaunchArgs);
 
 template <int R, bool kRollout>
-step_kernel_t generic_kernel(bool wide, bool image) {
+step_kernel_t generic_kernel(bool wide, bool image, bool msg) {
+    if (msg)
+        return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg, kRollout, rw::OBS_FLATTENED_MSG>
+                    : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg, kRollout, rw::OBS_FLATTENED_MSG>;
     if (image)
         return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg, kRollout, rw::OBS_IMAGE>
                     : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg, kRollout, rw::OBS_IMAGE>;
@@ -229,6 +233,9 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
                 return fail(nullptr, RW_ERR_INVALID_ARG, "unknown image layer %d", v);
         }
     }
+    if (cfg->msg_bits < 0 || cfg->msg_bits > 16) return fail(nullptr, RW_ERR_INVALID_ARG, "msg_bits %d not in 0..16", cfg->msg_bits);
+    if (cfg->msg_bits > 0 && obs_type != RW_OBS_FLATTENED)
+        return fail(nullptr, RW_ERR_UNSUPPORTED, "msg_bits > 0 is accelerated with FLATTENED observations only");
     const int HW = H * W;
     if (HW > 10000) return fail(nullptr, RW_ERR_UNSUPPORTED, "H*W > 10000 (numpy switches choice() algorithm)");
     if (N > HW) return fail(nullptr, RW_ERR_INVALID_ARG, "more agents than cells");
@@ -272,8 +279,10 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     const int cell_bytes = eng->wide ? 2 : 1;
     const int R = cfg->sensor_range, CELLS = (2 * R + 1) * (2 * R + 1);
     eng->image = obs_type != RW_OBS_FLATTENED;
-    eng->L = eng->image ? n_layers * CELLS : 8 + 7 * CELLS;  // floats per agent in RW_BUF_OBS
-    eng->OW = (8 + 7 * CELLS + 31) / 32;                       // LDS bit-string words per agent (kernel constant)
+    eng->msg_bits = cfg->msg_bits;
+    const int AM = 1 + cfg->msg_bits;
+    eng->L = eng->image ? n_layers * CELLS : 8 + (7 + cfg->msg_bits) * CELLS;  // floats per agent in RW_BUF_OBS
+    eng->OW = (8 + (7 + cfg->msg_bits) * CELLS + 31) / 32;                      // LDS bit-string words per agent
     const int SW = (S + 32) / 32;
 
     RW_HIP_C(hipSetDevice(cfg->device_id));
@@ -294,7 +303,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         return bail(RW_ERR_INVALID_ARG);
     }
     if (E == 0) {
-        const size_t per_env = sizeof(int32_t) * (size_t)rw::make_lds_layout(4, N, Q, HW, SW, eng->OW, cell_bytes).total / 4;
+        const size_t per_env = sizeof(int32_t) * (size_t)rw::make_lds_layout(4, N, Q, HW, SW, eng->OW, cell_bytes, AM).total / 4;
         E = (int)((32 * 1024) / per_env) & ~3;
         if (E < 4) E = 4;
         if (E > 16) E = 16;  // measured best on MI355X for the registered configs (profiles/)
@@ -311,14 +320,14 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         }
     }
     switch (R) {
-        case 1: eng->kernel = generic_kernel<1, false>(eng->wide, eng->image); eng->kernel_rollout = generic_kernel<1, true>(eng->wide, eng->image); break;
-        case 2: eng->kernel = generic_kernel<2, false>(eng->wide, eng->image); eng->kernel_rollout = generic_kernel<2, true>(eng->wide, eng->image); break;
-        case 3: eng->kernel = generic_kernel<3, false>(eng->wide, eng->image); eng->kernel_rollout = generic_kernel<3, true>(eng->wide, eng->image); break;
-        case 4: eng->kernel = generic_kernel<4, false>(eng->wide, eng->image); eng->kernel_rollout = generic_kernel<4, true>(eng->wide, eng->image); break;
-        default: eng->kernel = generic_kernel<5, false>(eng->wide, eng->image); eng->kernel_rollout = generic_kernel<5, true>(eng->wide, eng->image); break;
+        case 1: eng->kernel = generic_kernel<1, false>(eng->wide, eng->image, eng->msg_bits > 0); eng->kernel_rollout = generic_kernel<1, true>(eng->wide, eng->image, eng->msg_bits > 0); break;
+        case 2: eng->kernel = generic_kernel<2, false>(eng->wide, eng->image, eng->msg_bits > 0); eng->kernel_rollout = generic_kernel<2, true>(eng->wide, eng->image, eng->msg_bits > 0); break;
+        case 3: eng->kernel = generic_kernel<3, false>(eng->wide, eng->image, eng->msg_bits > 0); eng->kernel_rollout = generic_kernel<3, true>(eng->wide, eng->image, eng->msg_bits > 0); break;
+        case 4: eng->kernel = generic_kernel<4, false>(eng->wide, eng->image, eng->msg_bits > 0); eng->kernel_rollout = generic_kernel<4, true>(eng->wide, eng->image, eng->msg_bits > 0); break;
+        default: eng->kernel = generic_kernel<5, false>(eng->wide, eng->image, eng->msg_bits > 0); eng->kernel_rollout = generic_kernel<5, true>(eng->wide, eng->image, eng->msg_bits > 0); break;
     }
     for (const StaticEntry &se : kStatic) {
-        if (eng->specialised || eng->image) break;  // exact matches are listed first; the image kernels are generic builds
+        if (eng->specialised || eng->image || eng->msg_bits > 0) break;  // exact matches are listed first; the image kernels are generic builds
         const bool shape = se.H == H && se.W == W && se.S == S && se.R == R && (se.N == 0 || (se.N == N && se.Q == Q));
         const bool geom_default = cfg->envs_per_workgroup == 0 && cfg->threads_per_workgroup == 0;
         const bool geom_same = E == se.E && T == se.T;
@@ -333,7 +342,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     eng->E = E;
     eng->T = T;
     eng->n_wg = (B + E - 1) / E;
-    eng->lds_bytes = sizeof(int32_t) * (size_t)rw::make_lds_layout(E, N, Q, HW, SW, eng->OW, cell_bytes).total;
+    eng->lds_bytes = sizeof(int32_t) * (size_t)rw::make_lds_layout(E, N, Q, HW, SW, eng->OW, cell_bytes, AM).total;
     if (eng->lds_bytes > 160 * 1024) {
         fail(eng, RW_ERR_INVALID_ARG, "LDS footprint %zu B exceeds 160 KiB; lower envs_per_workgroup", eng->lds_bytes);
         return bail(RW_ERR_INVALID_ARG);
@@ -361,14 +370,15 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     n_elems[RW_BUF_INACTIVE] = szB;
     n_elems[RW_BUF_RNG] = szB * 6;
     n_elems[RW_BUF_NEED_RESET] = szB;
-    n_elems[RW_BUF_ACTIONS] = szB * N;
+    n_elems[RW_BUF_ACTIONS] = szB * N * AM;
     n_elems[RW_BUF_FEATURES] = szB * N * 6;
+    n_elems[RW_BUF_AGENT_MSG] = szB * N;
     // One slab for every buffer: the per-step working set (agent SoA, queue, counters, flags, rewards,
     // shelf shadow) sits in a few contiguous MiB, so a workgroup's ~15 streams share TLB entries
     // instead of touching 15 separate allocations.  Order = hot and small first.
     static const int order[RW_BUF_KIND_COUNT] = {
         RW_BUF_AGENT_X, RW_BUF_AGENT_Y, RW_BUF_AGENT_DIR, RW_BUF_AGENT_CARRY, RW_BUF_AGENT_DELIVERED, RW_BUF_QUEUE,
-        RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_NEED_RESET, RW_BUF_REWARDS, RW_BUF_TERMINATED, RW_BUF_TRUNCATED,
+        RW_BUF_AGENT_MSG, RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_NEED_RESET, RW_BUF_REWARDS, RW_BUF_TERMINATED, RW_BUF_TRUNCATED,
         RW_BUF_ACTIONS, RW_BUF_RNG, RW_BUF_FEATURES, RW_BUF_OBS, RW_BUF_GRID};
     auto up = [](size_t x) { return (x + 4095) & ~(size_t)4095; };
     size_t slab_bytes = 0, off[RW_BUF_KIND_COUNT];
@@ -436,6 +446,8 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.directional = cfg->image_directional ? 1 : 0;
     for (int l = 0; l < rw::MAX_IMAGE_LAYERS; ++l) p.layers[l] = l < n_layers ? layers[l] : 0;
     p.features = obs_type == RW_OBS_IMAGE_DICT ? (float *)eng->buf[RW_BUF_FEATURES].ptr : nullptr;
+    p.msg_bits = cfg->msg_bits;
+    p.amsg = (int32_t *)eng->buf[RW_BUF_AGENT_MSG].ptr;
     rw::LaunchArgs &la = eng->la;
     la.actions = (const int32_t *)eng->buf[RW_BUF_ACTIONS].ptr;
     la.reset_mask = eng->d_mask;
@@ -528,7 +540,7 @@ int rw_step_many_device(rw_engine *eng, const int32_t *actions_dev, int32_t n_st
     rw::LaunchArgs la = eng->la;
     la.actions = actions_dev;
     la.n_steps = n_steps;
-    la.act_stride = (int64_t)BN;
+    la.act_stride = (int64_t)BN * (1 + eng->msg_bits);
     if (obs_tape) { la.obs = obs_tape; la.obs_stride = (int64_t)(BN * eng->L); }
     if (reward_tape) { la.rewards = reward_tape; la.rew_stride = (int64_t)BN; }
     if (terminated_tape) { la.terminated = terminated_tape; la.term_stride = (int64_t)eng->prm.B; }
@@ -602,7 +614,7 @@ namespace {
 std::vector<std::pair<void *, size_t>> state_pieces(rw_engine *eng) {
     static const int kinds[] = {RW_BUF_GRID, RW_BUF_AGENT_X, RW_BUF_AGENT_Y, RW_BUF_AGENT_DIR, RW_BUF_AGENT_CARRY,
                                 RW_BUF_AGENT_DELIVERED, RW_BUF_QUEUE, RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_RNG,
-                                RW_BUF_NEED_RESET};
+                                RW_BUF_NEED_RESET, RW_BUF_AGENT_MSG};
     std::vector<std::pair<void *, size_t>> v;
     for (int k : kinds) v.emplace_back(eng->buf[k].ptr, eng->buf[k].bytes);
     v.emplace_back(eng->d_shadow, (size_t)eng->prm.B * eng->prm.HW * (eng->wide ? 2 : 1));

@@ -62,7 +62,7 @@ enum : int { REW_GLOBAL = 0, REW_INDIVIDUAL = 1, REW_TWO_STAGE = 2 };
 enum : int { AR_DISABLED = 0, AR_NEXT_STEP = 1, AR_SAME_STEP = 2 };
 enum : int { STATUS_INVALID_ACTION = 1 };
 enum : int { MAX_GOALS = 16, MAX_IMAGE_LAYERS = 8 };
-enum : int { OBS_FLATTENED = 0, OBS_IMAGE = 1 };
+enum : int { OBS_FLATTENED = 0, OBS_IMAGE = 1, OBS_FLATTENED_MSG = 2 };  // _MSG: FLATTENED with msg_bits > 0
 // ImageLayer values of the reference (rware/warehouse.py:59-70); 3 and 4 are rejected by the host
 enum : int { LAYER_SHELVES = 0, LAYER_REQUESTS = 1, LAYER_AGENTS = 2, LAYER_GOALS = 5, LAYER_ACCESSIBLE = 6 };
 
@@ -89,6 +89,9 @@ struct Params {
     int32_t n_layers, directional;
     int32_t layers[MAX_IMAGE_LAYERS];
     float *features;      // [B][N][6] one-hot direction, on_highway, carrying (IMAGE_DICT), or nullptr
+    // communication bits (rware/warehouse.py:255-259, 660-667, 810-812); only the OBS_FLATTENED_MSG kernels
+    int32_t msg_bits;     // M: an action is [Action, bit_0 .. bit_{M-1}] per agent, L = 8 + (7 + M)(2r+1)^2
+    int32_t *amsg;        // [B][N] bit k == message[k]
 };
 
 // What changes from launch to launch.  The kernel-argument segment is rewritten by the host for every
@@ -118,7 +121,7 @@ struct LdsLayout {
     // LDS-DMA stream): shelf layer, agent SoA, actions, queue, highway bitmap, per-env counters/flags
     int gs, ax, ay, dir, carry, deliv, act, queue, hw, dsteps, dinact, dflag, dma_end;
     int ga, zero_end;  // cleared every launch
-    int tgt, nxt, depth, win, rew, mv, fx, fy, req, obits, envi, misc, total;
+    int tgt, nxt, depth, win, rew, mv, msg, fx, fy, req, obits, envi, misc, total;
 };
 enum : int { ENVI_STEPS = 0, ENVI_INACTIVE = 1, ENVI_RESET = 2, ENVI_DONE = 3, ENVI_SKIP = 4, ENVI_W = 8 };
 
@@ -126,7 +129,7 @@ RW_HD int rw_up4(int x) { return (x + 3) & ~3; }
 RW_HD uint32_t rw_magic18(int d) { return d > 0 ? (uint32_t)(((1u << 18) + (uint32_t)d - 1u) / (uint32_t)d) : 0u; }
 RW_HD int rw_div18(int x, uint32_t magic) { return (int)(((uint32_t)x * magic) >> 18); }
 
-RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int cell_bytes) {
+RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int cell_bytes, int act_words = 1) {
     LdsLayout l;
     int o = 0;
     const int en = rw_up4(E * N);
@@ -136,7 +139,7 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
     l.dir = o;    o += en;
     l.carry = o;  o += en;
     l.deliv = o;  o += en;
-    l.act = o;    o += en;
+    l.act = o;    o += rw_up4(E * N * act_words);  // [Action, message bits...] per agent
     l.queue = o;  o += rw_up4(E * Q);
     l.hw = o;     o += rw_up4((HW + 31) / 32);
     l.dsteps = o; o += rw_up4(E);
@@ -151,6 +154,7 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
     l.win = o;    o += en;
     l.rew = o;    o += en;
     l.mv = o;     o += en;
+    l.msg = o;    o += en;
     l.fx = o;     o += en;
     l.fy = o;     o += en;
     l.req = o;    o += rw_up4(E * SW);
@@ -220,9 +224,13 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
 
 template <int R, typename CellT, typename Cfg, bool kRollout, int kObs = OBS_FLATTENED>
 __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restrict__ cp, const LaunchArgs la) {
+    constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L0 = 8 + 7 * CELLS, OW0 = (L0 + 31) / 32;
+    constexpr bool kMsg = (kObs == OBS_FLATTENED_MSG);
     const Params &p = *cp;  // constant per engine, device-resident, L2-warm
     const int op = la.op;
-    constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L = 8 + 7 * CELLS, OW = (L + 31) / 32;
+    // observation row length: a compile-time constant except with communication bits
+    const int M = kMsg ? p.msg_bits : 0, AM = 1 + M, CW = 7 + M;
+    const int L = kMsg ? 8 + CW * CELLS : L0, OW = kMsg ? (L + 31) / 32 : OW0;
     extern __shared__ __align__(16) int32_t smem[];
 
     int tid = threadIdx.x;
@@ -242,14 +250,14 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
 #define RW_MARK(k) do { if (la.timeline && tid == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + (k)] = wall_clock64(); } while (0)
     RW_MARK(TL_START);
 
-    const LdsLayout lo = make_lds_layout(E, N, Q, HW, SW, OW, (int)sizeof(CellT));
+    const LdsLayout lo = make_lds_layout(E, N, Q, HW, SW, OW, (int)sizeof(CellT), AM);
     CellT *s_gs = reinterpret_cast<CellT *>(smem + lo.gs);
     uint8_t *s_ga = reinterpret_cast<uint8_t *>(smem + lo.ga);
     int32_t *s_ax = smem + lo.ax, *s_ay = smem + lo.ay, *s_dir = smem + lo.dir;
     int32_t *s_carry = smem + lo.carry, *s_deliv = smem + lo.deliv, *s_act = smem + lo.act;
     int32_t *s_tgt = smem + lo.tgt, *s_nxt = smem + lo.nxt, *s_depth = smem + lo.depth, *s_win = smem + lo.win;
     float *s_rew = reinterpret_cast<float *>(smem + lo.rew);
-    int32_t *s_mv = smem + lo.mv;
+    int32_t *s_mv = smem + lo.mv, *s_msg = smem + lo.msg;
     float *s_fx = reinterpret_cast<float *>(smem + lo.fx), *s_fy = reinterpret_cast<float *>(smem + lo.fy);
     int32_t *s_queue = smem + lo.queue;
     uint32_t *s_req = reinterpret_cast<uint32_t *>(smem + lo.req);
@@ -329,7 +337,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         dma_in(s_carry, p.acarry + (size_t)e0 * N, nea, tid, T);
         dma_in(s_deliv, p.adeliv + (size_t)e0 * N, nea, tid, T);
         dma_in(s_queue, p.queue + (size_t)e0 * Q, ne * Q, tid, T);
-        if (op == OP_STEP) dma_in(s_act, la.actions + (size_t)e0 * N, nea, tid, T);
+        if (op == OP_STEP) dma_in(s_act, la.actions + (size_t)e0 * N * AM, nea * AM, tid, T);
+        if (kMsg) dma_in(s_msg, p.amsg + (size_t)e0 * N, nea, tid, T);
         dma_in(smem + lo.hw, reinterpret_cast<const int32_t *>(p.highway_bits), (HW + 31) / 32, tid, T);
         RW_MARK(TL_DMA_ISSUED);
         lds_barrier();  // orders the s_misc clear above before the flag writes below
@@ -352,7 +361,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int n_steps = (kRollout && op == OP_STEP) ? la.n_steps : 1;
     // Rollout: when every agent lane owns exactly one (env, agent) for the whole launch, the NEXT step's
     // action is fetched into a register one step ahead, so its HBM latency hides under the current step.
-    const bool act_prefetch = kRollout && (ne <= nw * (Cfg::kN ? 64 / (Cfg::kN ? Cfg::kN : 1) : p.groups_per_wave));
+    const bool act_prefetch = kRollout && !kMsg && (ne <= nw * (Cfg::kN ? 64 / (Cfg::kN ? Cfg::kN : 1) : p.groups_per_wave));
     int a_pref = ACT_NOOP;
     for (int t = 0; t < n_steps; ++t) {  // fused rollout: one iteration per env step
     if (kRollout) {
@@ -399,7 +408,16 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         int x = 0, y = 0, d = 0, carry = 0, deliv = 0, a = ACT_NOOP;
         if (mine) {
             x = s_ax[i]; y = s_ay[i]; d = s_dir[i]; carry = s_carry[i]; deliv = s_deliv[i];
-            if (stepping) a = (t == 0) ? s_act[i] : (act_prefetch ? a_pref : act_t[(size_t)ge * N + a_idx]);
+            if (stepping) a = (t == 0) ? s_act[i * AM] : (act_prefetch ? a_pref : act_t[((size_t)ge * N + a_idx) * AM]);
+            if (kMsg && stepping) {  // agent.message[:] = action[1:] — for every agent, whatever its move does (:812)
+                int msg = 0;
+                for (int k = 0; k < M; ++k) {
+                    const int v = (t == 0) ? s_act[i * AM + 1 + k] : act_t[((size_t)ge * N + a_idx) * AM + 1 + k];
+                    if ((unsigned)v > 1u) atomicOr(p.status, STATUS_INVALID_ACTION);  // MultiDiscrete([5, 2, 2, ...])
+                    msg |= (v & 1) << k;
+                }
+                s_msg[i] = msg;
+            }
             if (act_prefetch && t + 1 < n_steps) a_pref = (act_t + la.act_stride)[(size_t)ge * N + a_idx];
         }
         const int st = y * W + x;
@@ -621,8 +639,9 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             const size_t gi = (size_t)e0 * N + i;
             p.ax[gi] = s_ax[i]; p.ay[gi] = s_ay[i]; p.adir[gi] = s_dir[i];
             p.acarry[gi] = 0; p.adeliv[gi] = 0;
+            if (kMsg) { s_msg[i] = 0; p.amsg[gi] = 0; }  // fresh Agent objects: message = zeros (:89)
             rew_t[gi] = s_rew[i];
-            if (kObs == OBS_FLATTENED) {
+            if (kObs != OBS_IMAGE) {
                 s_fx[i] = coordf(0, s_ax[i]);
                 s_fy[i] = coordf(1, s_ay[i]);
                 const uint32_t self = (2u << s_dir[i]) | (on_highway(s_ay[i] * W + s_ax[i]) ? 32u : 0u);
@@ -679,6 +698,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     p.acarry[gi] = s_carry[i];
                     p.adeliv[gi] = s_deliv[i];
                     rew_t[gi] = s_rew[i];
+                    if (kMsg) p.amsg[gi] = s_msg[i];
                 }
         } else if (role == 2) {  // patch the exported int32 grid and the shadow at the two cells a mover changed
             if (op == OP_STEP)
@@ -700,7 +720,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                         g_shadow[ge * HW + tg] = (CellT)carry;
                     }
                 }
-        } else if (kObs == OBS_FLATTENED) {  // self part of the observation, k = 2..7 (:643-647), and the float coordinates k = 0,1
+        } else if (kObs != OBS_IMAGE) {  // self part of the observation, k = 2..7 (:643-647), and the float coordinates k = 0,1
             for (int i = lane; i < nea; i += 64) {
                 if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
                 const int x = s_ax[i], y = s_ay[i];
@@ -726,7 +746,26 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // ---------------------------------------------------------------- P7: observation bits (:598-674)
     // One contiguous bit string per workgroup: bit (i*L + k) == obs[agent i][k] for k >= 2; the two
     // coordinate slots k = 0,1 stay 0 here and are filled in as floats during expansion.
-    if constexpr (kObs == OBS_FLATTENED) {
+    if constexpr (kMsg) {
+        // with communication bits a cell code is 7 + M bits wide: [has_agent, dir x4, message x M, has_shelf,
+        // requested] (:655-673); gathered per (agent, cell)
+        for (int w = tid; w < nea * CELLS; w += T) {
+            const int i = w / CELLS, cidx = w - i * CELLS;
+            const int e = rw_div18(i, mN);
+            const int x = s_ax[i] + cidx % WIN - R, y = s_ay[i] + cidx / WIN - R;
+            uint32_t code = 2u;  // empty / off-map: direction one-hot [1,0,0,0], message skipped (zeros)
+            if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+                const int c = e * HW + y * W + x;
+                const int ida = s_ga[c] & 0x7f, ids = s_gs[c];
+                if (ida) code = 1u | (2u << s_dir[e * N + ida - 1]) | ((uint32_t)s_msg[e * N + ida - 1] << 5);
+                if (ids) code |= (1u << (5 + M)) | (((s_req[e * SW + (ids >> 5)] >> (ids & 31)) & 1u) << (6 + M));
+            }
+            const int bit = i * L + 8 + CW * cidx;
+            const int wd = bit >> 5, sh = bit & 31;
+            atomicOr(&s_obits[wd], code << sh);
+            if (sh + CW > 32) atomicOr(&s_obits[wd + 1], code >> (32 - sh));
+        }
+    } else if constexpr (kObs == OBS_FLATTENED) {
     // one thread per (agent, window row): the agent's position is read once, the row's WIN cells are
     // gathered with independent LDS reads, and the row's 7*WIN bits go out in one or two LDS atomics
     for (int w = tid; w < nea * WIN; w += T) {
@@ -819,7 +858,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     RW_MARK(TL_OBS_BITS);
 
     // ---------------------------------------------------------------- ST: obs, float4 #q == nibble #q
-    if constexpr (kObs == OBS_FLATTENED) {
+    if constexpr (kObs != OBS_IMAGE) {
         const int nf = nea * L;
         const int nf4 = nf >> 2;
         float *out = obs_t + (size_t)e0 * N * L;  // 16-byte aligned: e0 is a multiple of 4

@@ -62,8 +62,9 @@ class WarehouseVecEnv(_VectorEnvBase):
                  normalised_coordinates: bool = False, render_mode=None, *,
                  autoreset_mode: str = "next_step", devices=None, output: str = "numpy",
                  envs_per_workgroup: int = 0, threads_per_workgroup: int = 0, library: str | None = None):
-        if msg_bits != 0:
-            raise NotImplementedError("msg_bits > 0 is outside the accelerated path (every registered id uses 0)")
+        if not 0 <= int(msg_bits) <= 16:
+            raise ValueError("msg_bits must be in 0..16")
+        self.msg_bits = int(msg_bits)
         self.observation_type = ObservationType(enum_value(observation_type))
         if self.observation_type == ObservationType.DICT:
             raise NotImplementedError("ObservationType.DICT (nested Python dicts) is not accelerated; FLATTENED carries the same content")
@@ -72,6 +73,8 @@ class WarehouseVecEnv(_VectorEnvBase):
                 l in (ImageLayer.AGENT_DIRECTION, ImageLayer.AGENT_LOAD) for l in layers):
             raise NotImplementedError("ImageLayer.AGENT_DIRECTION / AGENT_LOAD are written with transposed indices by the "
                                       "reference (rware/warehouse.py:552,558) and are not accelerated")
+        if self.msg_bits and self.observation_type != ObservationType.FLATTENED:
+            raise NotImplementedError("msg_bits > 0 is accelerated with FLATTENED observations only")
         self.image_observation_layers = layers
         self.image_observation_directional = bool(image_observation_directional)
         if output not in ("numpy", "torch"):
@@ -79,7 +82,6 @@ class WarehouseVecEnv(_VectorEnvBase):
         self.layout: Layout = layout_from_str(layout) if layout else layout_from_params(shelf_columns, shelf_rows, column_height)
         self.num_envs = int(num_envs)
         self.n_agents = int(n_agents)
-        self.msg_bits = 0
         self.sensor_range = int(sensor_range)
         self.request_queue_size = int(request_queue_size)
         self.max_inactivity_steps = max_inactivity_steps
@@ -92,7 +94,7 @@ class WarehouseVecEnv(_VectorEnvBase):
         self.autoreset_mode = autoreset_mode
         self.metadata = dict(self.metadata, autoreset_mode=autoreset_mode)
         self.output = output
-        self.obs_length = obs_length(self.sensor_range)
+        self.obs_length = obs_length(self.sensor_range, self.msg_bits)
         self._seeded = False
         self.closed = False
 
@@ -124,7 +126,7 @@ class WarehouseVecEnv(_VectorEnvBase):
                 envs_per_workgroup=envs_per_workgroup, threads_per_workgroup=threads_per_workgroup,
                 stream=stream, library=library, observation_type=self.observation_type.value,
                 image_layers=[l.value for l in layers] if self.observation_type != ObservationType.FLATTENED else (),
-                image_directional=image_observation_directional))
+                image_directional=image_observation_directional, msg_bits=self.msg_bits))
         self._bounds = [b for b in self._bounds if b[1] > b[0]]
         self.devices = devices[: len(self.engines)]
         self.n_shelves = self.engines[0].S
@@ -146,9 +148,11 @@ class WarehouseVecEnv(_VectorEnvBase):
             sp = _gym.spaces
             sa_obs = sp.Box(low=-float("inf"), high=float("inf"), shape=(l,), dtype=np.float32)
             self.single_observation_space = sp.Tuple(tuple(n * [sa_obs]))      # rware/warehouse.py:505-522
-            self.single_action_space = sp.Tuple(tuple(n * [sp.Discrete(len(Action))]))  # :255-260
+            sa_act = sp.Discrete(len(Action)) if not self.msg_bits else sp.MultiDiscrete([len(Action)] + self.msg_bits * [2])
+            self.single_action_space = sp.Tuple(tuple(n * [sa_act]))  # :255-260
             self.observation_space = sp.Box(-float("inf"), float("inf"), shape=(b, n, l), dtype=np.float32)
-            self.action_space = sp.MultiDiscrete(np.full((b, n), len(Action)))
+            nvec = np.full((b, n), len(Action)) if not self.msg_bits else np.tile([len(Action)] + self.msg_bits * [2], (b, n, 1))
+            self.action_space = sp.MultiDiscrete(nvec)
         else:
             self.single_observation_space = tuple(_Space((l,), np.float32) for _ in range(n))
             self.single_action_space = tuple(_Space((), np.int64, n=len(Action)) for _ in range(n))
@@ -184,20 +188,25 @@ class WarehouseVecEnv(_VectorEnvBase):
     def step_async(self, actions):
         t = self._torch
         if t is not None and isinstance(actions, t.Tensor) and actions.is_cuda:
-            if actions.dtype != t.int32 or not actions.is_contiguous() or actions.numel() != self.num_envs * self.n_agents:
-                raise ValueError("device actions must be a contiguous int32 tensor of B*N elements")
+            if (actions.dtype != t.int32 or not actions.is_contiguous()
+                    or actions.numel() != self.num_envs * self.n_agents * (1 + self.msg_bits)):
+                raise ValueError("device actions must be a contiguous int32 tensor of B*N*(1+msg_bits) elements")
             self._live_actions = actions  # keep alive until the step has run
             self.engines[0].step_device(actions.data_ptr())
             return
         a = np.asarray(actions)
         if a.dtype == object:
             a = np.vectorize(enum_value, otypes=[np.int64])(a)
-        if a.size != self.num_envs * self.n_agents:
-            raise AssertionError(f"expected {self.num_envs}x{self.n_agents} actions, got shape {a.shape}")  # :807
-        a = a.reshape(self.num_envs, self.n_agents)
-        if a.size and (a.min() < 0 or a.max() > 4):
-            bad = a[(a < 0) | (a > 4)].flat[0]
-            raise ValueError(f"{bad} is not a valid Action")  # Action(action) at :814
+        am = 1 + self.msg_bits  # per-agent action: [Action, message bits...] (rware/warehouse.py:255-259)
+        if a.size != self.num_envs * self.n_agents * am:
+            raise AssertionError(f"expected {self.num_envs}x{self.n_agents}" + (f"x{am}" if self.msg_bits else "")
+                                 + f" actions, got shape {a.shape}")  # :807
+        a = a.reshape(self.num_envs, self.n_agents, am)
+        if a.size and (a[..., 0].min() < 0 or a[..., 0].max() > 4):
+            bad = a[..., 0][(a[..., 0] < 0) | (a[..., 0] > 4)].flat[0]
+            raise ValueError(f"{bad} is not a valid Action")  # Action(action) at :811/:814
+        if self.msg_bits and (a[..., 1:].min() < 0 or a[..., 1:].max() > 1):
+            raise ValueError("message bits must be 0 or 1 (MultiDiscrete([5, 2, ...]))")
         a = a.astype(np.int32, copy=False)
         for eng, (lo, hi) in zip(self.engines, self._bounds):
             eng.step_host(a[lo:hi])
@@ -217,10 +226,13 @@ class WarehouseVecEnv(_VectorEnvBase):
         One fused kernel launch per shard (`rw_step_many_device`): the env chunk stays in LDS across
         the T steps.  Bit-identical to T calls of step() with the same actions."""
         a = np.asarray(actions)
-        if a.ndim != 3 or a.shape[1:] != (self.num_envs, self.n_agents):
-            raise AssertionError(f"expected (T, {self.num_envs}, {self.n_agents}) actions, got {a.shape}")
-        if a.size and (a.min() < 0 or a.max() > 4):
+        am = 1 + self.msg_bits
+        a = a.reshape(a.shape[0], self.num_envs, self.n_agents, am) if a.size and a.size % (self.num_envs * self.n_agents * am) == 0 else a
+        if a.ndim != 4 or a.shape[1:] != (self.num_envs, self.n_agents, am):
+            raise AssertionError(f"expected (T, {self.num_envs}, {self.n_agents}" + (f", {am}" if self.msg_bits else "") + f") actions, got {a.shape}")
+        if a.size and (a[..., 0].min() < 0 or a[..., 0].max() > 4 or (self.msg_bits and (a[..., 1:].min() < 0 or a[..., 1:].max() > 1))):
             raise ValueError("invalid Action in tape")
+        a = a.reshape(a.shape[0], self.num_envs, self.n_agents * am)
         parts = [eng.rollout_host(a[:, lo:hi], want_obs) for eng, (lo, hi) in zip(self.engines, self._bounds)]
         cat = lambda k: parts[0][k] if len(parts) == 1 else np.concatenate([p[k] for p in parts], axis=1)
         return (cat(0) if want_obs else None), cat(1), cat(2).astype(bool)
@@ -277,13 +289,13 @@ class WarehouseVecEnv(_VectorEnvBase):
     # ------------------------------------------------------------------------------- state
     def get_state(self) -> dict:
         """Batched SoA state: grid (B,2,H,W), agent_* (B,N), queue (B,Q), steps/inactive (B,), rng (B,6)."""
-        out = {k: self._gather(k) for k in STATE_FIELDS}
+        out = {k: self._gather(k) for k in STATE_FIELDS + (("agent_msg",) if self.msg_bits else ())}
         out["rng"] = np.ascontiguousarray(out["rng"].T)
         return out
 
     def set_state(self, refresh_obs: bool = True, **fields):
         for k, v in fields.items():
-            if k not in STATE_FIELDS and k != "need_reset":
+            if k not in STATE_FIELDS and k not in ("need_reset", "agent_msg"):
                 raise KeyError(k)
             v = np.asarray(v)
             for eng, (lo, hi) in zip(self.engines, self._bounds):

@@ -56,6 +56,9 @@ CASES = [
     ("img-tiny-3ag-northup-sr2", "rware-tiny-3ag-v2",
      {"observation_type": 2, "image_observation_directional": False, "sensor_range": 2}, 2, 200, 11000),
     ("imgdict-medium-6ag-hard", "rware-medium-6ag-hard-v2", {"observation_type": 3, "max_steps": 90}, 2, 200, 12000),
+    # communication bits (warehouse.py:255-259, 660-667, 810-812): actions are [Action, bit, bit, ...] per agent
+    ("msg2-small-4ag", "rware-small-4ag-v2", {"msg_bits": 2, "max_steps": 150}, 3, 330, 13000),
+    ("msg3-tiny-3ag-sr2", "rware-tiny-3ag-v2", {"msg_bits": 3, "sensor_range": 2}, 2, 200, 14000),
 ]
 
 
@@ -77,14 +80,14 @@ def gen_case(name, env_id, extra, E, T, seed):
         return rr.obs_array(o), None
     envs = [wh.Warehouse(**kw) for _ in range(E)]
     N = envs[0].n_agents
+    M = int(kw_json.get("msg_bits", 0))
+    state_keys = ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry", "agent_delivered",
+                  "queue", "steps", "inactive", "rng") + (("agent_msg",) if M else ())
     pol = np.random.default_rng(seed + 77)
-    rec = {k: [] for k in ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry",
-                           "agent_delivered", "queue", "steps", "inactive", "rng",
-                           "obs", "features", "rewards", "done", "actions", "was_reset")}
+    rec = {k: [] for k in state_keys + ("obs", "features", "rewards", "done", "actions", "was_reset")}
 
     def record(snaps, obs, rew, done, acts, was_reset):
-        for k in ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry", "agent_delivered",
-                  "queue", "steps", "inactive", "rng"):
+        for k in state_keys:
             rec[k].append(np.stack([s[k] for s in snaps]))
         rec["obs"].append(np.stack([o[0] for o in obs]))
         if obs_type == 3:
@@ -96,9 +99,7 @@ def gen_case(name, env_id, extra, E, T, seed):
 
     obs0_pairs = [obs_arrays(env.reset(seed=seed + e)[0]) for e, env in enumerate(envs)]
     obs0 = [o[0] for o in obs0_pairs]
-    init = {k: np.stack([rr.snapshot(env)[k] for env in envs]) for k in
-            ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry", "agent_delivered",
-             "queue", "steps", "inactive", "rng")}
+    init = {k: np.stack([rr.snapshot(env)[k] for env in envs]) for k in state_keys}
     prev_done = [False] * E
     deliveries = 0
     for t in range(T):
@@ -111,6 +112,8 @@ def gen_case(name, env_id, extra, E, T, seed):
                 a = [int(v) for v in pol.integers(0, 5, size=N)]
             else:
                 a = [int(v) for v in pol.choice(5, size=N, p=[0.1, 0.6, 0.1, 0.1, 0.1])]
+            if M:  # [Action, message bits...] per agent
+                a = [[int(v)] + [int(b) for b in pol.integers(0, 2, size=M)] for v in a]
             acts.append(a)
             if prev_done[e]:
                 o, _ = env.reset()
@@ -130,7 +133,7 @@ def gen_case(name, env_id, extra, E, T, seed):
     out = {k: np.stack(v) for k, v in rec.items() if v}
     ids_max = max(int(out["grid"].max()), 1)
     out["grid"] = out["grid"].astype(np.uint8 if ids_max < 256 else np.int16)
-    for k in ("agent_x", "agent_y", "agent_dir", "agent_delivered"):
+    for k in ("agent_x", "agent_y", "agent_dir", "agent_delivered") + (("agent_msg",) if M else ()):
         out[k] = out[k].astype(np.int8)
     for k in ("agent_carry", "queue"):
         out[k] = out[k].astype(np.int16)

@@ -21,13 +21,11 @@ def load_fixture(name):
 
 
 def ctor_kwargs(meta):
-    kw = dict(meta["kwargs"])
-    kw.pop("msg_bits", None)
-    return kw
+    return dict(meta["kwargs"])
 
 
 def assert_state_equal(got: dict, z, t, prefix=""):
-    for k in STATE_FIELDS:
+    for k in STATE_FIELDS + (("agent_msg",) if "agent_msg" in z else ()):
         want = z[prefix + k] if t is None else z[k][t]
         g = np.asarray(got[k])
         assert g.shape == want.shape, (k, t, g.shape, want.shape)

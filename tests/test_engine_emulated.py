@@ -27,6 +27,8 @@ pytestmark = pytest.mark.timeout(600)
     ("img-small-4ag-directional", (0, 0)),
     ("img-tiny-3ag-northup-sr2", (4, 64)),
     ("imgdict-medium-6ag-hard", (8, 128)),
+    ("msg2-small-4ag", (0, 0)),
+    ("msg3-tiny-3ag-sr2", (4, 64)),
 ])
 def test_emulated_engine_matches_reference_golden(name, geom):
     meta, z = gu.load_fixture(name)
@@ -103,8 +105,16 @@ def test_host_layer_errors_and_views():
     o, r, term, trunc, info = env.step([[rware_amd.Action.FORWARD, rware_amd.Action.NOOP]] * 4)
     assert r.shape == (4, 2) and term.dtype == bool and not trunc.any() and info == {}
     assert env.shelf_xy().shape == (4, env.n_shelves, 2)
-    with pytest.raises(NotImplementedError):
-        rware_amd.WarehouseVecEnv(2, library=LIB, **dict(kw, msg_bits=1))
+    with pytest.raises(NotImplementedError):   # communication bits only with FLATTENED observations
+        rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.IMAGE, **dict(kw, msg_bits=1))
+    menv = rware_amd.WarehouseVecEnv(4, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **dict(kw, msg_bits=2))
+    mo, _ = menv.reset(seed=0)
+    assert mo.shape == (4, 2, 8 + 9 * 9)              # L = 8 + (7 + M)(2r+1)^2
+    with pytest.raises(ValueError):                   # message bits are binary
+        menv.step(np.full((4, 2, 3), 2))
+    with pytest.raises(AssertionError):               # [Action, bit, bit] per agent
+        menv.step(np.zeros((4, 2), int))
+    menv.close()
     with pytest.raises(NotImplementedError):
         rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.DICT, **kw)
     with pytest.raises(NotImplementedError):   # transposed-index layers of the reference (:552, :558)
@@ -266,4 +276,28 @@ def test_image_observations_match_oracle(obs_type, directional, layers, sr):
     for t in range(25, 40):
         o2, r2, d2 = orc.step_autoreset(acts[t], "next_step")
         assert np.array_equal(img[t - 25], o2[0] if isinstance(o2, tuple) else o2) and np.array_equal(rew[t - 25], r2), t
+    env.close()
+
+
+def test_communication_bits_rollout_and_state():
+    kw = rware_amd.env_kwargs("rware-small-6ag-v1")
+    kw.update(msg_bits=2, max_steps=14)
+    kw["reward_type"] = kw["reward_type"].value
+    B = 5
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=128, autoreset_mode="same_step", **kw)
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=2)[0], orc.reset(seed=2))
+    rng = np.random.default_rng(8)
+    acts = np.concatenate([rng.choice(5, size=(40, B, 6, 1), p=[.1, .5, .15, .15, .1]), rng.integers(0, 2, size=(40, B, 6, 2))], axis=-1)
+    for t in range(15):
+        o, r, d, _, _ = env.step(acts[t])
+        o2, r2, d2 = orc.step_autoreset(acts[t], "same_step")
+        assert np.array_equal(o, o2) and np.array_equal(r, r2) and np.array_equal(d, d2.astype(bool)), t
+    obs, rew, term = env.rollout(acts[15:])
+    for t in range(15, 40):
+        o2, r2, d2 = orc.step_autoreset(acts[t], "same_step")
+        assert np.array_equal(obs[t - 15], o2) and np.array_equal(rew[t - 15], r2), t
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
     env.close()
