@@ -225,3 +225,37 @@ def test_image_observations_match_oracle(env_id, obs_type, directional, sr, B):
         o2, r2, d2 = orc.step_autoreset(acts[t], "next_step")
         assert same(o, o2) and np.array_equal(r, r2) and np.array_equal(d, d2.astype(bool)), t
     env.close()
+
+
+def test_headline_batch_soak_every_env_against_oracle():
+    """BASELINE config 3 at full size for 1100 steps (two mass autoresets): EVERY env's rewards and done
+    flags each step, observations every 25 steps, and the complete final state, against the oracle."""
+    B, N, T = 16384, 4, 1100
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    env = rware_amd.WarehouseVecEnv(B, **kw)
+    assert env.engines[0].info.specialised == 1
+    orc = OracleVecEnv(B, **dict(kw, reward_type=kw["reward_type"].value))
+    assert np.array_equal(env.reset(seed=2024)[0], orc.reset(seed=2024))
+    rng = np.random.default_rng(99)
+    t = 0
+    while t < T:
+        if t % 100 < 60:   # stepwise launches
+            a = rng.choice(5, size=(B, N), p=[.1, .5, .15, .15, .1]).astype(np.int32)
+            obs, rew, term, _, _ = env.step(a)
+            o2, r2, d2 = orc.step_autoreset(a, "next_step")
+            assert np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+            if t % 25 == 0:
+                assert np.array_equal(obs, o2), t
+            t += 1
+        else:              # a fused 40-step rollout
+            acts = rng.choice(5, size=(40, B, N), p=[.1, .5, .15, .15, .1]).astype(np.int32)
+            _, rew, term = env.rollout(acts, want_obs=False)
+            for k in range(40):
+                o2, r2, d2 = orc.step_autoreset(acts[k], "next_step")
+                assert np.array_equal(rew[k], r2) and np.array_equal(term[k], d2.astype(bool)), t + k
+            t += 40
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    assert np.array_equal(env.observations(), orc.obs())
+    env.close()
