@@ -864,12 +864,14 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         float *out = obs_t + (size_t)e0 * N * L;  // 16-byte aligned: e0 is a multiple of 4
         float4 *out4 = reinterpret_cast<float4 *>(out);
         auto expand = [&](int q4) -> float4 {  // float4 #q4 of the chunk == nibble #q4 of the bit string
-            const uint32_t nib = s_obits[q4 >> 3] >> ((q4 & 7) << 2);
+            const uint32_t nib = (s_obits[q4 >> 3] >> ((q4 & 7) << 2)) & 0xFu;
+            // one multiply spreads the 4 bits into 4 bytes (0 or 1 each); each byte converts with v_cvt_f32_ubyteN
+            const uint32_t b = (nib * 0x00204081u) & 0x01010101u;
             float4 v;
-            v.x = (nib & 1u) ? 1.0f : 0.0f;
-            v.y = (nib & 2u) ? 1.0f : 0.0f;
-            v.z = (nib & 4u) ? 1.0f : 0.0f;
-            v.w = (nib & 8u) ? 1.0f : 0.0f;
+            v.x = (float)(b & 0xFFu);
+            v.y = (float)((b >> 8) & 0xFFu);
+            v.z = (float)((b >> 16) & 0xFFu);
+            v.w = (float)(b >> 24);
             return v;
         };
         // bulk pass: every float4 that holds no coordinate slot (all but ~2 in 18)
@@ -909,12 +911,13 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         float *out = obs_t + (size_t)e0 * N * Limg;  // 16-byte aligned: e0 is a multiple of 4
         float4 *out4 = reinterpret_cast<float4 *>(out);
         for (int q4 = tid; q4 < nf4; q4 += T) {
-            const uint32_t nib = s_obits[q4 >> 3] >> ((q4 & 7) << 2);
+            const uint32_t nib = (s_obits[q4 >> 3] >> ((q4 & 7) << 2)) & 0xFu;
+            const uint32_t b = (nib * 0x00204081u) & 0x01010101u;  // 4 bits -> 4 bytes -> v_cvt_f32_ubyteN
             float4 v;
-            v.x = (nib & 1u) ? 1.0f : 0.0f;
-            v.y = (nib & 2u) ? 1.0f : 0.0f;
-            v.z = (nib & 4u) ? 1.0f : 0.0f;
-            v.w = (nib & 8u) ? 1.0f : 0.0f;
+            v.x = (float)(b & 0xFFu);
+            v.y = (float)((b >> 8) & 0xFFu);
+            v.z = (float)((b >> 16) & 0xFFu);
+            v.w = (float)(b >> 24);
             out4[q4] = v;
         }
         for (int g = (nf4 << 2) + tid; g < nf; g += T) out[g] = ((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f;
