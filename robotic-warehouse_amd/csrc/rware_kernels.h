@@ -47,6 +47,7 @@
 //                              N hops without either       => i feeds a cycle => fail.
 // The tie rule (lowest agent id among equal depths) is the pinned rule of DESIGN.md §tie-break.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include <rware_cdna4.h>
@@ -67,6 +68,15 @@ enum : int { OBS_FLATTENED = 0, OBS_IMAGE = 1, OBS_FLATTENED_MSG = 2 };  // _MSG
 enum : int { LAYER_SHELVES = 0, LAYER_REQUESTS = 1, LAYER_AGENTS = 2, LAYER_GOALS = 5, LAYER_ACCESSIBLE = 6 };
 
 struct Params {
+    // Hot block: the twelve pointers the P0 stage-in needs, first and cache-line aligned, so that the
+    // static kernels fetch them with two early scalar loads (sload16_issue / sload8_issue at kernel
+    // entry, offsets kHotA / kHotB) whose latency hides under the LDS clear.
+    void *shelf_shadow;            // CellT [B][HW] (+ padding): compact copy of grid layer 1, the kernel's read path
+    int32_t *ax, *ay, *adir, *acarry, *adeliv, *queue;
+    const uint32_t *highway_bits;  // [HWW] bit c == highways[c]                  (static per config)
+    int32_t *steps, *inactive;
+    uint8_t *need_reset;           // [B]
+    uint64_t *rng;                 // [6][B]
     // config
     int32_t B, H, W, HW, N, Q, S, SW;  // SW = dwords of the requested-shelf bitmap = (S+32)/32
     int32_t HWW;                       // dwords of the highway bitmap = (HW+31)/32
@@ -75,14 +85,9 @@ struct Params {
     int32_t groups_per_wave;           // envs whose agents share one wavefront = 64 / N
     uint32_t magic_n;                  // ceil(2^18 / N): x / N == (x * magic) >> 18 for x * N < 2^18
     int32_t goal_cells[MAX_GOALS];     // cell index y*W+x per goal, list order
-    // static per config (device)
-    const uint32_t *highway_bits;  // [HWW] bit c == highways[c]
     const int32_t *shelf_init;     // [HW] shelf layer right after reset: ids 1..S row-major on non-highway cells
     // state (device)
-    int32_t *grid, *ax, *ay, *adir, *acarry, *adeliv, *queue, *steps, *inactive;
-    void *shelf_shadow;   // CellT [B][HW] (+ padding): compact copy of grid layer 1, the kernel's read path
-    uint64_t *rng;        // [6][B]
-    uint8_t *need_reset;  // [B]
+    int32_t *grid;
     uint8_t *truncated;   // [B]
     int32_t *status;      // [1] sticky error bits
     // IMAGE / IMAGE_DICT observations (rware/warehouse.py:527-596); unused by the FLATTENED kernels
@@ -112,6 +117,9 @@ struct LaunchArgs {
     int32_t n_steps;
     int64_t act_stride, obs_stride, rew_stride, term_stride;
 };
+static constexpr int kHotA = 0, kHotB = 64;  // byte offsets of the two hot pointer blocks in Params
+static_assert(offsetof(Params, shelf_shadow) == kHotA && offsetof(Params, highway_bits) == kHotA + 56, "Params hot block A");
+static_assert(offsetof(Params, steps) == kHotB && offsetof(Params, rng) == kHotB + 24, "Params hot block B");
 enum : int { TL_START = 0, TL_ZEROED, TL_DMA_ISSUED, TL_ENV_LOADED, TL_LOADED, TL_AGENTS, TL_RESET, TL_OBS_BITS,
              TL_OBS_STORED, TL_END, TL_MARKS = 12 };
 
@@ -223,7 +231,13 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
 }
 
 template <int R, typename CellT, typename Cfg, bool kRollout, int kObs = OBS_FLATTENED>
-__global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restrict__ cp, const LaunchArgs la) {
+__global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restrict__ cp, const uint64_t cp_addr, const LaunchArgs la) {
+    // cp_addr == (uint64_t)cp.  The early scalar loads below take the address from this integer: handing
+    // `cp` itself to inline asm would capture the pointer, and hipcc then demotes every later Params read
+    // from s_load to global_load.  (Both arguments arrive preloaded in SGPRs: -amdgpu-kernarg-preload-count.)
+    // first thing: start fetching the stage-in pointers; they are consumed after the LDS clear (sload_wait)
+    sreg16 hot_a = sload16_issue<kHotA>(cp_addr);
+    sreg8 hot_b = sload8_issue<kHotB>(cp_addr);
     constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L0 = 8 + 7 * CELLS, OW0 = (L0 + 31) / 32;
     constexpr bool kMsg = (kObs == OBS_FLATTENED_MSG);
     const Params &p = *cp;  // constant per engine, device-resident, L2-warm
@@ -282,34 +296,54 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         for (int i = tid; i < ne * SW; i += T) s_req[i] = 0u;
         if (tid == 0) s_misc[0] = 0;
     };
-    const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : p.need_reset;  // OP_RESET: all-ones when no mask was given
     clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
     RW_MARK(TL_ZEROED);
+    sload_wait(hot_a, hot_b);
+    const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : sreg_ptr<const uint8_t>(hot_b, 2);  // OP_RESET: all-ones when no mask was given
     if constexpr (Cfg::kE != 0) {
         // Static build: every DMA destination is contiguous in LDS and every source chunk is a whole
         // number of 16-byte pieces, so the chunk is ONE linear stream — thread t moves LDS piece t;
         // its HBM source is picked from the segment table (all pointers fetched in one scalar batch).
         static_assert((Cfg::kE * Cfg::kN) % 4 == 0 && (Cfg::kE * Cfg::kQ) % 4 == 0 && Cfg::kE % 4 == 0, "chunk not 16-byte granular");
         static_assert((Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0, "shelf chunk not 16-byte granular");
+        const int32_t *h_ax = sreg_ptr<const int32_t>(hot_a, 1);
         const char *src[12] = {
-            reinterpret_cast<const char *>(g_shadow + (size_t)e0 * HW),
-            reinterpret_cast<const char *>(p.ax + (size_t)e0 * N), reinterpret_cast<const char *>(p.ay + (size_t)e0 * N),
-            reinterpret_cast<const char *>(p.adir + (size_t)e0 * N), reinterpret_cast<const char *>(p.acarry + (size_t)e0 * N),
-            reinterpret_cast<const char *>(p.adeliv + (size_t)e0 * N),
-            reinterpret_cast<const char *>((op == OP_STEP ? la.actions : p.ax) + (size_t)e0 * N),
-            reinterpret_cast<const char *>(p.queue + (size_t)e0 * Q), reinterpret_cast<const char *>(p.highway_bits),
-            reinterpret_cast<const char *>(p.steps + e0), reinterpret_cast<const char *>(p.inactive + e0),
+            sreg_ptr<const char>(hot_a, 0) + (size_t)e0 * HW * sizeof(CellT),
+            reinterpret_cast<const char *>(h_ax + (size_t)e0 * N),
+            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_a, 2) + (size_t)e0 * N),
+            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_a, 3) + (size_t)e0 * N),
+            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_a, 4) + (size_t)e0 * N),
+            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_a, 5) + (size_t)e0 * N),
+            reinterpret_cast<const char *>((op == OP_STEP ? la.actions : h_ax) + (size_t)e0 * N),
+            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_a, 6) + (size_t)e0 * Q),
+            sreg_ptr<const char>(hot_a, 7),
+            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_b, 0) + e0),
+            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_b, 1) + e0),
             reinterpret_cast<const char *>(flag_src + e0)};
         const int seg[13] = {lo.gs, lo.ax, lo.ay, lo.dir, lo.carry, lo.deliv, lo.act, lo.queue, lo.hw,
                              lo.dsteps, lo.dinact, lo.dflag, lo.dma_end};  // dword offsets, all multiples of 4
-        const int pieces = (lo.dma_end - lo.gs) >> 2;
-        for (int b = wave * 64; b < pieces; b += nw * 64) {  // wave-uniform
-            const int t = b + lane;
-            const char *g = src[0] + (size_t)t * 16;
+        if constexpr (Cfg::kN != 0) {
+            // One DMA instruction moves up to 64 pieces of ONE segment (LDS base + lane * 16), so the source
+            // pick is scalar; the (compile-time) list of such instructions is dealt round-robin to the waves.
+            // Per wave that is 3-4 instructions of ~3 VALU ops each — the phase is VALU-issue bound otherwise.
+            const int wave_s = uniform(wave);
+            int job = 0;
+            for (int k = 0; k < 12; ++k) {  // (fully unrolled when the shapes are compile-time constants)
+                const int pieces = (seg[k + 1] - seg[k]) >> 2;
+                for (int c = 0; c < pieces; c += 64, ++job)
+                    if (job % nw == wave_s && c + lane < pieces)
+                        lds_dma_b128(src[k] + (size_t)(c + lane) * 16, smem + seg[k] + 4 * c);
+            }
+        } else {  // N, Q are run-time values: thread t moves LDS piece t, its source picked per lane
+            const int pieces = (lo.dma_end - lo.gs) >> 2;
+            for (int b = wave * 64; b < pieces; b += nw * 64) {  // wave-uniform
+                const int t = b + lane;
+                const char *g = src[0] + (size_t)t * 16;
 #pragma unroll
-            for (int k = 1; k < 12; ++k)
-                if (t >= ((seg[k] - seg[0]) >> 2)) g = src[k] + (size_t)(t - ((seg[k] - seg[0]) >> 2)) * 16;
-            if (t < pieces) lds_dma_b128(g, smem + lo.gs + 4 * b);
+                for (int k = 1; k < 12; ++k)
+                    if (t >= ((seg[k] - seg[0]) >> 2)) g = src[k] + (size_t)(t - ((seg[k] - seg[0]) >> 2)) * 16;
+                if (t < pieces) lds_dma_b128(g, smem + lo.gs + 4 * b);
+            }
         }
         // (rounding pieces at the tail of hw / dflag read a few bytes past the logical end of their
         //  source; both live inside the engine's slab, whose sub-buffers are padded)
@@ -925,6 +959,11 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     RW_MARK(TL_OBS_STORED);
     }  // fused-rollout step loop
     RW_MARK(TL_END);
+    if (la.timeline && lane == 0) {  // where each wavefront ran: slot 10 = 4 x 16 bits of HW_ID, slot 11 = XCC id
+        atomicOr(reinterpret_cast<unsigned long long *>(la.timeline + (size_t)blockIdx.x * TL_MARKS + 10),
+                 (unsigned long long)(hw_id() & 0xFFFFu) << (16 * (wave & 3)));
+        if (wave == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + 11] = xcc_id();
+    }
 #undef RW_MARK
 }
 
