@@ -39,8 +39,8 @@ struct rw_engine {
     uint32_t *d_highway_bits = nullptr;
     int32_t *d_shelf_init = nullptr;
     uint8_t *d_mask = nullptr;
-    void (*kernel)(const rw::Params *, const uint64_t, const rw::LaunchArgs) = nullptr;  // the step kernel instance this engine launches
-    void (*kernel_rollout)(const rw::Params *, const uint64_t, const rw::LaunchArgs) = nullptr;  // its fused multi-step (rollout) sibling
+    void (*kernel)(const rw::Params *, const int32_t *, const int32_t, const int32_t, float *, float *, uint8_t *, const uint8_t *, uint64_t *, const int64_t, const int64_t, const int64_t, const int64_t) = nullptr;  // the step kernel instance this engine launches
+    void (*kernel_rollout)(const rw::Params *, const int32_t *, const int32_t, const int32_t, float *, float *, uint8_t *, const uint8_t *, uint64_t *, const int64_t, const int64_t, const int64_t, const int64_t) = nullptr;  // its fused multi-step (rollout) sibling
     rw::Params *d_prm = nullptr;  // device copy of `prm` (constant for the engine's lifetime)
     rw::LaunchArgs la{};          // per-launch defaults: the engine's own output buffers
     bool specialised = false;
@@ -78,7 +78,7 @@ int fail(rw_engine *eng, int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
-using step_kernel_t = void (*)(const rw::Params *, const uint64_t, const rw::LaunchArgs);
+using step_kernel_t = void (*)(const rw::Params *, const int32_t *, const int32_t, const int32_t, float *, float *, uint8_t *, const uint8_t *, uint64_t *, const int64_t, const int64_t, const int64_t, const int64_t);
 
 template <int R, bool kRollout>
 step_kernel_t generic_kernel(bool wide, bool image, bool msg) {
@@ -115,9 +115,9 @@ const StaticEntry kStatic[] = {
 #undef RW_STATIC
 
 int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false) {
-    la.op = op;
+    la.op = op | (la.timeline ? rw::OP_FLAG_TIMELINE : 0);
     hipLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
-                       eng->stream, (const rw::Params *)eng->d_prm, (uint64_t)(uintptr_t)eng->d_prm, la);
+                       eng->stream, (const rw::Params *)eng->d_prm, RW_LAUNCH_ARGS(la));
     RW_HIP(eng, hipGetLastError());
     return RW_OK;
 }

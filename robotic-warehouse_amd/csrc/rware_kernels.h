@@ -68,9 +68,8 @@ enum : int { OBS_FLATTENED = 0, OBS_IMAGE = 1, OBS_FLATTENED_MSG = 2 };  // _MSG
 enum : int { LAYER_SHELVES = 0, LAYER_REQUESTS = 1, LAYER_AGENTS = 2, LAYER_GOALS = 5, LAYER_ACCESSIBLE = 6 };
 
 struct Params {
-    // Hot block: the twelve pointers the P0 stage-in needs, first and cache-line aligned, so that the
-    // static kernels fetch them with two early scalar loads (sload16_issue / sload8_issue at kernel
-    // entry, offsets kHotA / kHotB) whose latency hides under the LDS clear.
+    // The twelve pointers the P0 stage-in needs come first, contiguous and cache-line aligned: the
+    // compiler fetches them with two wide scalar loads.
     void *shelf_shadow;            // CellT [B][HW] (+ padding): compact copy of grid layer 1, the kernel's read path
     int32_t *ax, *ay, *adir, *acarry, *adeliv, *queue;
     const uint32_t *highway_bits;  // [HWW] bit c == highways[c]                  (static per config)
@@ -105,21 +104,30 @@ struct Params {
 // device memory, stays warm in L2 across launches and is read through a pointer.
 struct LaunchArgs {
     const int32_t *actions;     // [B][N] (or the [T][B][N] tape of a fused rollout)   (OP_STEP)
-    const uint8_t *reset_mask;  // [B]                                                  (OP_RESET)
+    int32_t op;                 // OP_STEP / OP_RESET / OP_OBS, | OP_FLAG_TIMELINE
+    // fused rollout (rw_step_many_device): n_steps consecutive steps in ONE launch; the env chunk stays
+    // in LDS between steps, only actions are read and obs/rewards/terminated written per step.
+    int32_t n_steps;
     float *obs;                 // [B][N][L]
     float *rewards;             // [B][N]
     uint8_t *terminated;        // [B]
+    const uint8_t *reset_mask;  // [B]                                                  (OP_RESET)
     uint64_t *timeline;         // nullptr, or [n_wg][TL_MARKS] wall-clock stamps (rw_debug_timeline)
-    int32_t op;                 // OP_STEP / OP_RESET / OP_OBS
-    // fused rollout (rw_step_many_device): n_steps consecutive steps in ONE launch; the env chunk stays
-    // in LDS between steps, only actions are read and obs/rewards/terminated written per step.
     // Strides are in elements per step (0 == every step writes the same buffer).
-    int32_t n_steps;
     int64_t act_stride, obs_stride, rew_stride, term_stride;
 };
-static constexpr int kHotA = 0, kHotB = 64;  // byte offsets of the two hot pointer blocks in Params
-static_assert(offsetof(Params, shelf_shadow) == kHotA && offsetof(Params, highway_bits) == kHotA + 56, "Params hot block A");
-static_assert(offsetof(Params, steps) == kHotB && offsetof(Params, rng) == kHotB + 24, "Params hot block B");
+// The kernel takes these fields as separate scalar arguments after `cp`: with
+// -amdgpu-kernarg-preload-count=16 the first 14 dwords — cp and everything up to reset_mask — arrive in
+// SGPRs at wave launch, so nothing on the stage-in path waits on the (cold) kernel-argument segment.
+#define RW_LAUNCH_PARAMS                                                                                   \
+    const int32_t *la_actions, const int32_t la_op, const int32_t la_n_steps, float *la_obs,               \
+        float *la_rewards, uint8_t *la_terminated, const uint8_t *la_reset_mask, uint64_t *la_timeline,    \
+        const int64_t la_act_stride, const int64_t la_obs_stride, const int64_t la_rew_stride,             \
+        const int64_t la_term_stride
+#define RW_LAUNCH_ARGS(la)                                                                                  \
+    (la).actions, (la).op, (la).n_steps, (la).obs, (la).rewards, (la).terminated, (la).reset_mask,         \
+        (la).timeline, (la).act_stride, (la).obs_stride, (la).rew_stride, (la).term_stride
+enum : int { OP_FLAG_TIMELINE = 0x100 };
 enum : int { TL_START = 0, TL_ZEROED, TL_DMA_ISSUED, TL_ENV_LOADED, TL_LOADED, TL_AGENTS, TL_RESET, TL_OBS_BITS,
              TL_OBS_STORED, TL_END, TL_MARKS = 12 };
 
@@ -231,17 +239,14 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
 }
 
 template <int R, typename CellT, typename Cfg, bool kRollout, int kObs = OBS_FLATTENED>
-__global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restrict__ cp, const uint64_t cp_addr, const LaunchArgs la) {
-    // cp_addr == (uint64_t)cp.  The early scalar loads below take the address from this integer: handing
-    // `cp` itself to inline asm would capture the pointer, and hipcc then demotes every later Params read
-    // from s_load to global_load.  (Both arguments arrive preloaded in SGPRs: -amdgpu-kernarg-preload-count.)
-    // first thing: start fetching the stage-in pointers; they are consumed after the LDS clear (sload_wait)
-    sreg16 hot_a = sload16_issue<kHotA>(cp_addr);
-    sreg8 hot_b = sload8_issue<kHotB>(cp_addr);
+__global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L0 = 8 + 7 * CELLS, OW0 = (L0 + 31) / 32;
     constexpr bool kMsg = (kObs == OBS_FLATTENED_MSG);
     const Params &p = *cp;  // constant per engine, device-resident, L2-warm
-    const int op = la.op;
+    const LaunchArgs la{la_actions, la_op, la_n_steps, la_obs, la_rewards, la_terminated, la_reset_mask, la_timeline,
+                        la_act_stride, la_obs_stride, la_rew_stride, la_term_stride};
+    const int op = la.op & 0xff;
+    const bool tl_on = (la.op & OP_FLAG_TIMELINE) != 0;  // the flag is preloaded; la.timeline itself is fetched only when set
     // observation row length: a compile-time constant except with communication bits
     const int M = kMsg ? p.msg_bits : 0, AM = 1 + M, CW = 7 + M;
     const int L = kMsg ? 8 + CW * CELLS : L0, OW = kMsg ? (L + 31) / 32 : OW0;
@@ -261,7 +266,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int nea = ne * N;
     const uint32_t mN = Cfg::kN ? rw_magic18(Cfg::kN) : p.magic_n;
     // optional per-workgroup phase stamps (100 MHz wall clock); one scalar branch per mark when off
-#define RW_MARK(k) do { if (la.timeline && tid == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + (k)] = wall_clock64(); } while (0)
+#define RW_MARK(k) do { if (tl_on && tid == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + (k)] = wall_clock64(); } while (0)
     RW_MARK(TL_START);
 
     const LdsLayout lo = make_lds_layout(E, N, Q, HW, SW, OW, (int)sizeof(CellT), AM);
@@ -298,27 +303,21 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     };
     clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
     RW_MARK(TL_ZEROED);
-    sload_wait(hot_a, hot_b);
-    const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : sreg_ptr<const uint8_t>(hot_b, 2);  // OP_RESET: all-ones when no mask was given
+    const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : p.need_reset;  // OP_RESET: all-ones when no mask was given
     if constexpr (Cfg::kE != 0) {
         // Static build: every DMA destination is contiguous in LDS and every source chunk is a whole
         // number of 16-byte pieces, so the chunk is ONE linear stream — thread t moves LDS piece t;
         // its HBM source is picked from the segment table (all pointers fetched in one scalar batch).
         static_assert((Cfg::kE * Cfg::kN) % 4 == 0 && (Cfg::kE * Cfg::kQ) % 4 == 0 && Cfg::kE % 4 == 0, "chunk not 16-byte granular");
         static_assert((Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0, "shelf chunk not 16-byte granular");
-        const int32_t *h_ax = sreg_ptr<const int32_t>(hot_a, 1);
         const char *src[12] = {
-            sreg_ptr<const char>(hot_a, 0) + (size_t)e0 * HW * sizeof(CellT),
-            reinterpret_cast<const char *>(h_ax + (size_t)e0 * N),
-            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_a, 2) + (size_t)e0 * N),
-            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_a, 3) + (size_t)e0 * N),
-            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_a, 4) + (size_t)e0 * N),
-            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_a, 5) + (size_t)e0 * N),
-            reinterpret_cast<const char *>((op == OP_STEP ? la.actions : h_ax) + (size_t)e0 * N),
-            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_a, 6) + (size_t)e0 * Q),
-            sreg_ptr<const char>(hot_a, 7),
-            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_b, 0) + e0),
-            reinterpret_cast<const char *>(sreg_ptr<const int32_t>(hot_b, 1) + e0),
+            reinterpret_cast<const char *>(g_shadow + (size_t)e0 * HW),
+            reinterpret_cast<const char *>(p.ax + (size_t)e0 * N), reinterpret_cast<const char *>(p.ay + (size_t)e0 * N),
+            reinterpret_cast<const char *>(p.adir + (size_t)e0 * N), reinterpret_cast<const char *>(p.acarry + (size_t)e0 * N),
+            reinterpret_cast<const char *>(p.adeliv + (size_t)e0 * N),
+            reinterpret_cast<const char *>((op == OP_STEP ? la.actions : p.ax) + (size_t)e0 * N),
+            reinterpret_cast<const char *>(p.queue + (size_t)e0 * Q), reinterpret_cast<const char *>(p.highway_bits),
+            reinterpret_cast<const char *>(p.steps + e0), reinterpret_cast<const char *>(p.inactive + e0),
             reinterpret_cast<const char *>(flag_src + e0)};
         const int seg[13] = {lo.gs, lo.ax, lo.ay, lo.dir, lo.carry, lo.deliv, lo.act, lo.queue, lo.hw,
                              lo.dsteps, lo.dinact, lo.dflag, lo.dma_end};  // dword offsets, all multiples of 4
@@ -959,7 +958,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     RW_MARK(TL_OBS_STORED);
     }  // fused-rollout step loop
     RW_MARK(TL_END);
-    if (la.timeline && lane == 0) {  // where each wavefront ran: slot 10 = 4 x 16 bits of HW_ID, slot 11 = XCC id
+    if (tl_on && lane == 0) {  // where each wavefront ran: slot 10 = 4 x 16 bits of HW_ID, slot 11 = XCC id
         atomicOr(reinterpret_cast<unsigned long long *>(la.timeline + (size_t)blockIdx.x * TL_MARKS + 10),
                  (unsigned long long)(hw_id() & 0xFFFFu) << (16 * (wave & 3)));
         if (wave == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + 11] = xcc_id();

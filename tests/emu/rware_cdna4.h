@@ -10,18 +10,6 @@ inline void lds_dma_b128(const void *g_lane, void *lds_wave_base) {
 inline void lds_dma_b32(const void *g_lane, void *lds_wave_base) {
     memcpy((char *)lds_wave_base + (threadIdx.x & 63u) * 4, g_lane, 4);
 }
-struct sreg16 { uint32_t v[16]; uint32_t operator[](int i) const { return v[i]; } };
-struct sreg8 { uint32_t v[8]; uint32_t operator[](int i) const { return v[i]; } };
-template <int kByteOffset> inline sreg16 sload16_issue(uint64_t base) {
-    sreg16 r; memcpy(&r, (const char *)(uintptr_t)base + kByteOffset, sizeof r); return r;
-}
-template <int kByteOffset> inline sreg8 sload8_issue(uint64_t base) {
-    sreg8 r; memcpy(&r, (const char *)(uintptr_t)base + kByteOffset, sizeof r); return r;
-}
-inline void sload_wait(sreg16 &, sreg8 &) {}
-template <typename P, typename V> inline P *sreg_ptr(const V &r, int k) {
-    return reinterpret_cast<P *>((uint64_t)r[2 * k] | ((uint64_t)r[2 * k + 1] << 32));
-}
 inline uint32_t hw_id() { return 0; }
 inline uint32_t xcc_id() { return 0; }
 inline int uniform(int x) { return x; }
