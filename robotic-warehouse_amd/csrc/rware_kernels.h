@@ -457,26 +457,27 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         if (mine && !ev[ENVI_RESET]) gA[st] = (uint8_t)((a_idx + 1) | (carry ? 0x80 : 0));
         wave_sync();
         // ------------------------------------------------------------ P1: intent (:825-846)
-        int tg = st, nxt = -2, shelf_here = 0;
+        int tg = st, nxt = -2, shelf_here = 0, tx = x, ty = y;
         if (stepping) {
             if ((unsigned)a > 4u) {  // Action(a) raises in the reference (:814); flagged, runs as NOOP
                 atomicOr(p.status, STATUS_INVALID_ACTION);
                 a = ACT_NOOP;
             }
-            int tx = x, ty = y;
-            if (a == ACT_FORWARD) {  // clamped at the walls (:105-112)
-                if (d == DIR_UP) ty = max(0, y - 1);
-                else if (d == DIR_DOWN) ty = min(H - 1, y + 1);
-                else if (d == DIR_LEFT) tx = max(0, x - 1);
-                else tx = min(W - 1, x + 1);
-            }
+            // branch-free: the wave holds every action / heading at once, so a 4-way branch costs all 4 arms
+            const int fwd = (a == ACT_FORWARD) ? 1 : 0;
+            const int dx = fwd & ((d == DIR_RIGHT) ? 1 : 0), dxn = fwd & ((d == DIR_LEFT) ? 1 : 0);
+            const int dy = fwd & ((d == DIR_DOWN) ? 1 : 0), dyn = fwd & ((d == DIR_UP) ? 1 : 0);
+            tx = min(max(x + dx - dxn, 0), W - 1);  // clamped at the walls (:105-112)
+            ty = min(max(y + dy - dyn, 0), H - 1);
             tg = ty * W + tx;
             const int sh_tg = gS[tg], ag_tg = gA[tg];
             shelf_here = gS[st];
-            if (carry && tg != st && sh_tg && !(ag_tg & 0x80)) {  // a standing shelf blocks a loaded agent
-                a = ACT_NOOP;
-                tg = st;
-            }
+            // a standing shelf blocks a loaded agent (:836-846)
+            const bool blocked = (carry != 0) & (tg != st) & (sh_tg != 0) & ((ag_tg & 0x80) == 0);
+            a = blocked ? (int)ACT_NOOP : a;
+            tg = blocked ? st : tg;
+            tx = blocked ? x : tx;
+            ty = blocked ? y : ty;
             // successor on the chain: agent index on the target cell, -1 empty, -2 == i is stationary
             nxt = (tg == st) ? -2 : ((ag_tg & 0x7f) - 1);
             s_tgt[i] = (nxt == -2) ? -1 : tg;  // contested-cell key: only movers compete
@@ -495,15 +496,15 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         wave_sync();
         // ------------------------------------------------------------ P2b: winner per contested cell
         if (stepping) {  // larger follower depth wins, then the LOWER agent id
-            int w = 1;
+            int lose = 0;
             if (nxt != -2) {
                 const int dme = s_depth[i];
-                for (int k = 0; k < N; ++k) {
+                for (int k = 0; k < N; ++k) {  // (bitwise on purpose: no short-circuit branches)
                     const int tk = s_tgt[base + k], dk = s_depth[base + k];
-                    if (tk == tg && k != a_idx && (dk > dme || (dk == dme && k < a_idx))) w = 0;
+                    lose |= ((tk == tg) & (k != a_idx) & ((dk > dme) | ((dk == dme) & (k < a_idx)))) ? 1 : 0;
                 }
             }
-            s_win[i] = w;
+            s_win[i] = lose ^ 1;
         }
         wave_sync();
         // ------------------------------------------------------------ P2c + P3: commit, apply (:871-899)
@@ -524,28 +525,24 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 }
                 if (!commit) a = ACT_NOOP;
             }
-            if (a == ACT_FORWARD) {
-                if (tg != st) {
-                    moved = true;
-                    x = tg % W;
-                    y = tg / W;
-                    gA[st] = 0;  // clear phase of the incremental _recalc_grid
-                    if (carry) gS[st] = 0;
-                }
-            } else if (a == ACT_LEFT || a == ACT_RIGHT) {
-                // wraplist [UP, RIGHT, DOWN, LEFT] (:119): RIGHT 0->3->1->2->0, LEFT 0->2->1->3->0
-                const int right = (0x1023 >> (4 * d)) & 0xF;  // d: 0->3, 1->2, 2->0, 3->1
-                const int left = (0x0132 >> (4 * d)) & 0xF;   // d: 0->2, 1->3, 2->1, 3->0
-                d = (a == ACT_RIGHT) ? right : left;
-            } else if (a == ACT_TOGGLE) {
-                if (!carry) {
-                    if (shelf_here) carry = shelf_here;
-                } else if (!on_highway(st)) {
-                    carry = 0;
-                    if (deliv && p.reward_type == REW_TWO_STAGE) rew = 0.5f;
-                    deliv = 0;
-                }
+            moved = (a == ACT_FORWARD) & (tg != st);
+            x = moved ? tx : x;
+            y = moved ? ty : y;
+            if (moved) {
+                gA[st] = 0;  // clear phase of the incremental _recalc_grid
+                if (carry) gS[st] = 0;
             }
+            // wraplist [UP, RIGHT, DOWN, LEFT] (:119): RIGHT 0->3->1->2->0, LEFT 0->2->1->3->0
+            const int right = (0x1023 >> (4 * d)) & 0xF;  // d: 0->3, 1->2, 2->0, 3->1
+            const int left = (0x0132 >> (4 * d)) & 0xF;   // d: 0->2, 1->3, 2->1, 3->0
+            d = (a == ACT_RIGHT) ? right : ((a == ACT_LEFT) ? left : d);
+            // TOGGLE_LOAD (:886-899): pick up the shelf under the agent, or put the carried one down off the highways
+            const bool toggle = (a == ACT_TOGGLE);
+            const bool drop = toggle & (carry != 0) & !on_highway(st);
+            const bool pick = toggle & (carry == 0) & (shelf_here != 0);
+            rew = (drop & (deliv != 0) & (p.reward_type == REW_TWO_STAGE)) ? 0.5f : 0.0f;
+            deliv = drop ? 0 : deliv;
+            carry = drop ? 0 : (pick ? shelf_here : carry);
             s_ax[i] = x; s_ay[i] = y; s_dir[i] = d; s_carry[i] = carry; s_deliv[i] = deliv;
         }
         if (mine) s_rew[i] = rew;  // every agent of the chunk gets its reward slot
