@@ -28,6 +28,8 @@ __device__ __forceinline__ void lds_barrier() {
 // HW_ID (hwreg 4): wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]; XCC_ID (hwreg 20): xcc[3:0]
 __device__ __forceinline__ uint32_t hw_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 4); }
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20); }
+// wave_any(v): true in every lane iff v holds in some active lane of the wavefront (one s_cmp on the ballot)
+__device__ __forceinline__ bool wave_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0; }
 // uniform(x): tells the compiler a value is wave-uniform (v_readfirstlane), so tests on it become scalar branches
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ void wave_sync() {

@@ -436,12 +436,15 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         uint8_t *gA = s_ga + e * HW;
         int32_t *ev = s_envi + e * ENVI_W;
         const int ge = e0 + e;  // global env index
-        const bool stepping = (op == OP_STEP) && mine && !ev[ENVI_SKIP];
         // ---- R1: own record into registers; rebuild the agent layer (id | 0x80 if loaded)
-        int x = 0, y = 0, d = 0, carry = 0, deliv = 0, a = ACT_NOOP;
+        // (all LDS reads are issued as one batch: idle lanes read a valid slot and ignore it)
+        const int ev_skip = ev[ENVI_SKIP], ev_reset = ev[ENVI_RESET];
+        int x = s_ax[i], y = s_ay[i], d = s_dir[i], carry = s_carry[i], deliv = s_deliv[i];
+        const int a_lds = (t == 0) ? s_act[i * AM] : (int)ACT_NOOP;
+        const bool stepping = (op == OP_STEP) && mine && !ev_skip;
+        int a = ACT_NOOP;
         if (mine) {
-            x = s_ax[i]; y = s_ay[i]; d = s_dir[i]; carry = s_carry[i]; deliv = s_deliv[i];
-            if (stepping) a = (t == 0) ? s_act[i * AM] : (act_prefetch ? a_pref : act_t[((size_t)ge * N + a_idx) * AM]);
+            if (stepping) a = (t == 0) ? a_lds : (act_prefetch ? a_pref : act_t[((size_t)ge * N + a_idx) * AM]);
             if (kMsg && stepping) {  // agent.message[:] = action[1:] — for every agent, whatever its move does (:812)
                 int msg = 0;
                 for (int k = 0; k < M; ++k) {
@@ -454,7 +457,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             if (act_prefetch && t + 1 < n_steps) a_pref = (act_t + la.act_stride)[(size_t)ge * N + a_idx];
         }
         const int st = y * W + x;
-        if (mine && !ev[ENVI_RESET]) gA[st] = (uint8_t)((a_idx + 1) | (carry ? 0x80 : 0));
+        if (mine && !ev_reset) gA[st] = (uint8_t)((a_idx + 1) | (carry ? 0x80 : 0));
         wave_sync();
         // ------------------------------------------------------------ P1: intent (:825-846)
         int tg = st, nxt = -2, shelf_here = 0, tx = x, ty = y;
@@ -484,34 +487,46 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             s_nxt[i] = nxt;
         }
         wave_sync();
+        // Chains (an agent stepping onto a cell another agent stands on) are rare; when the wavefront has
+        // none, every follower depth is 0, a mover commits iff it wins its cell, and P2a, the depth reads
+        // and the s_win exchange (two LDS round trips) drop out.
+        const bool chains = wave_any(stepping && nxt >= 0);  // wave-uniform
         // ------------------------------------------------------------ P2a: follower depth
-        if (stepping && nxt != -2) {
-            int j = nxt, dd = 1;
-            while (j >= 0 && j != a_idx && dd <= N && s_nxt[base + j] != -2) {
-                atomicMax(&s_depth[base + j], dd);
-                j = s_nxt[base + j];
-                ++dd;
+        if (chains) {
+            if (stepping && nxt >= 0) {
+                int j = nxt, dd = 1;
+                while (j >= 0 && j != a_idx && dd <= N && s_nxt[base + j] != -2) {
+                    atomicMax(&s_depth[base + j], dd);
+                    j = s_nxt[base + j];
+                    ++dd;
+                }
             }
+            wave_sync();
         }
-        wave_sync();
         // ------------------------------------------------------------ P2b: winner per contested cell
-        if (stepping) {  // larger follower depth wins, then the LOWER agent id
-            int lose = 0;
-            if (nxt != -2) {
+        int lose = 0;  // larger follower depth wins, then the LOWER agent id
+        if (stepping && nxt != -2) {
+            if (chains) {
                 const int dme = s_depth[i];
                 for (int k = 0; k < N; ++k) {  // (bitwise on purpose: no short-circuit branches)
                     const int tk = s_tgt[base + k], dk = s_depth[base + k];
                     lose |= ((tk == tg) & (k != a_idx) & ((dk > dme) | ((dk == dme) & (k < a_idx)))) ? 1 : 0;
                 }
+            } else {
+                for (int k = 0; k < N; ++k) lose |= ((s_tgt[base + k] == tg) & (k < a_idx)) ? 1 : 0;
             }
-            s_win[i] = lose ^ 1;
         }
-        wave_sync();
+        if (chains) {
+            if (stepping) s_win[i] = lose ^ 1;
+            wave_sync();
+        }
         // ------------------------------------------------------------ P2c + P3: commit, apply (:871-899)
         bool moved = false;
         float rew = 0.0f;
         if (stepping) {
-            if (nxt != -2) {  // a mover: walk the chain ahead
+            if (nxt == -1) {  // drains into an empty cell: commits iff it won the cell
+                if (lose) a = ACT_NOOP;
+            } else if (nxt >= 0) {  // walk the chain ahead
                 int j = a_idx, hops = 0, ok = 1, commit = 0;
                 for (;;) {
                     ok &= s_win[base + j];

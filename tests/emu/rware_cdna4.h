@@ -12,6 +12,17 @@ inline void lds_dma_b32(const void *g_lane, void *lds_wave_base) {
 }
 inline uint32_t hw_id() { return 0; }
 inline uint32_t xcc_id() { return 0; }
+extern int emu_wave_any_flag[16];
+inline bool wave_any(bool v) {  // every thread of the wave calls this (wave-uniform control flow)
+    const int w = threadIdx.x >> 6;
+    if (v) __atomic_store_n(&emu_wave_any_flag[w], 1, __ATOMIC_SEQ_CST);
+    pthread_barrier_wait(emu_wave_barrier);
+    const bool r = __atomic_load_n(&emu_wave_any_flag[w], __ATOMIC_SEQ_CST) != 0;
+    pthread_barrier_wait(emu_wave_barrier);
+    if ((threadIdx.x & 63u) == 0) __atomic_store_n(&emu_wave_any_flag[w], 0, __ATOMIC_SEQ_CST);
+    pthread_barrier_wait(emu_wave_barrier);
+    return r;
+}
 inline int uniform(int x) { return x; }
 inline void lds_barrier() { pthread_barrier_wait(emu_barrier); }
 inline void wave_sync() { pthread_barrier_wait(emu_wave_barrier); }
