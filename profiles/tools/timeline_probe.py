@@ -38,9 +38,16 @@ def main():
         c = us[:, k]
         print(f"{name:12s} {np.percentile(c, 10):8.2f} {np.median(c):8.2f} {np.percentile(c, 90):8.2f} {c.max():8.2f}")
     d = np.diff(us, axis=1)
-    print("per-workgroup phase durations (us): median / p90")
+    print("per-workgroup phase durations (us): median / p90 / p99 / max")
     for k in range(len(MARKS) - 1):
-        print(f"  {MARKS[k]:>10s} -> {MARKS[k + 1]:10s} {np.median(d[:, k]):7.2f} {np.percentile(d[:, k], 90):7.2f}")
+        print(f"  {MARKS[k]:>10s} -> {MARKS[k + 1]:10s} {np.median(d[:, k]):7.2f} {np.percentile(d[:, k], 90):7.2f} "
+              f"{np.percentile(d[:, k], 99):7.2f} {d[:, k].max():7.2f}")
+    life = us[:, -1] - us[:, 0]
+    last = np.argsort(us[:, -1])[-8:]
+    print("the 8 workgroups that end last: id, start, end, lifetime, agents-phase")
+    for b in last:
+        print(f"  {b:5d} {us[b, 0]:6.2f} {us[b, -1]:6.2f} {life[b]:6.2f} {d[b, 4]:6.2f}")
+    print(f"lifetime p50 {np.median(life):.2f} p90 {np.percentile(life, 90):.2f} p99 {np.percentile(life, 99):.2f} max {life.max():.2f}")
     print(f"workgroup lifetime median {np.median(us[:, -1] - us[:, 0]):.2f} us; kernel span {us[:, -1].max():.2f} us")
 
 

@@ -715,9 +715,13 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     }
     RW_MARK(TL_RESET);
 
-    // ---------------------------------------------------------------- WB: write-back, one role per wavefront
-    // The agent wave only resolved the step; the HBM write-back and the self part of the observation are
-    // four independent jobs, spread over the workgroup's wavefronts (envs flagged for reset were written by RS).
+    // ---------------------------------------------------------------- WB: state write-back, one role per wavefront
+    // (envs flagged for reset were written by RS).  Where it runs is a measured choice:
+    //   single step    before the observation: its small stores then drain underneath P7; issued after the
+    //                  18 MB observation stream they queue behind it and hold every wavefront ~0.8 us longer
+    //   fused rollout  after the observation stores: the next step's compute hides them, and the stream
+    //                  starts 0.4 us earlier (5.62 -> 5.44 us per step)
+    auto write_back = [&]() {
     for (int role = wave; role < 4; role += nw) {  // wave-uniform
         if (role == 0) {  // per-env counters and flags, request queue
             if (op == OP_STEP)
@@ -765,7 +769,17 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                         g_shadow[ge * HW + tg] = (CellT)carry;
                     }
                 }
-        } else if (kObs != OBS_IMAGE) {  // self part of the observation, k = 2..7 (:643-647), and the float coordinates k = 0,1
+        }
+    }
+    };
+    if (!kRollout) write_back();
+
+    // ---------------------------------------------------------------- OS: self part of the observation
+    // Runs on the LAST role slot (wavefront 3 of 4), side by side with the window rows below, which fill
+    // wavefronts 0..2 first.
+    for (int role = wave; role < 4; role += nw) {  // wave-uniform
+        if (role != 3) continue;
+        if (kObs != OBS_IMAGE) {  // self part of the observation, k = 2..7 (:643-647), and the float coordinates k = 0,1
             for (int i = lane; i < nea; i += 64) {
                 if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
                 const int x = s_ax[i], y = s_ay[i];
@@ -968,6 +982,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         for (int g = (nf4 << 2) + tid; g < nf; g += T) out[g] = ((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f;
     }
     RW_MARK(TL_OBS_STORED);
+    if (kRollout) write_back();
     }  // fused-rollout step loop
     RW_MARK(TL_END);
     if (tl_on && lane == 0) {  // where each wavefront ran: slot 10 = 4 x 16 bits of HW_ID, slot 11 = XCC id
