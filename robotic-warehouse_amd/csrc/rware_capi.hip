@@ -96,21 +96,26 @@ step_kernel_t generic_kernel(bool wide, bool image, bool msg) {
 //   {H, W, N, Q, S, R}  ->  kernel with those shapes (and E, T) folded in at compile time.
 struct StaticEntry {
     int H, W, N, Q, S, R, E, T;
+    int max_B;  // with the default geometry: chosen only for batches up to this size (0 = any); first match wins
     step_kernel_t fn, fn_rollout;
 };
-#define RW_STATIC(H, W, N, Q, S, R, E, T)                                                                   \
-    {H, W, N, Q, S, R, E, T, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
+#define RW_STATIC(H, W, N, Q, S, R, E, T, MAXB)                                                                   \
+    {H, W, N, Q, S, R, E, T, MAXB, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true>}
 const StaticEntry kStatic[] = {
-    RW_STATIC(11, 10, 2, 2, 32, 1, 16, 256),    // rware-tiny-2ag
-    RW_STATIC(20, 10, 4, 4, 80, 1, 16, 256),    // rware-small-4ag (headline)
-    RW_STATIC(20, 16, 6, 3, 144, 1, 16, 256),   // rware-medium-6ag-hard
-    RW_STATIC(29, 16, 16, 16, 224, 2, 8, 256),  // rware-large-16ag, sensor_range = 2
+    // half-size workgroups for batches that leave the CUs short of workgroups at E = 16 (measured:
+    // medium-6ag-hard B=8192 9.44 -> 8.62 us, small-4ag B=4096 6.57 -> 6.48 us; slower above these sizes)
+    RW_STATIC(20, 10, 4, 4, 80, 1, 8, 256, 4096),
+    RW_STATIC(20, 16, 6, 3, 144, 1, 8, 256, 8192),
+    RW_STATIC(11, 10, 2, 2, 32, 1, 16, 256, 0),    // rware-tiny-2ag
+    RW_STATIC(20, 10, 4, 4, 80, 1, 16, 256, 0),    // rware-small-4ag (headline)
+    RW_STATIC(20, 16, 6, 3, 144, 1, 16, 256, 0),   // rware-medium-6ag-hard
+    RW_STATIC(29, 16, 16, 16, 224, 2, 8, 256, 0),  // rware-large-16ag, sensor_range = 2
     // size-static builds (N == 0: any agent count / queue length): every other registered id, sensor_range 1
-    RW_STATIC(11, 10, 0, 0, 32, 1, 16, 256),    // rware-tiny-*
-    RW_STATIC(20, 10, 0, 0, 80, 1, 16, 256),    // rware-small-*
-    RW_STATIC(20, 16, 0, 0, 144, 1, 16, 256),   // rware-medium-*
-    RW_STATIC(29, 16, 0, 0, 224, 1, 16, 256),   // rware-large-*
+    RW_STATIC(11, 10, 0, 0, 32, 1, 16, 256, 0),    // rware-tiny-*
+    RW_STATIC(20, 10, 0, 0, 80, 1, 16, 256, 0),    // rware-small-*
+    RW_STATIC(20, 16, 0, 0, 144, 1, 16, 256, 0),   // rware-medium-*
+    RW_STATIC(29, 16, 0, 0, 224, 1, 16, 256, 0),   // rware-large-*
 };
 #undef RW_STATIC
 
@@ -326,16 +331,22 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         case 4: eng->kernel = generic_kernel<4, false>(eng->wide, eng->image, eng->msg_bits > 0); eng->kernel_rollout = generic_kernel<4, true>(eng->wide, eng->image, eng->msg_bits > 0); break;
         default: eng->kernel = generic_kernel<5, false>(eng->wide, eng->image, eng->msg_bits > 0); eng->kernel_rollout = generic_kernel<5, true>(eng->wide, eng->image, eng->msg_bits > 0); break;
     }
-    for (const StaticEntry &se : kStatic) {
-        if (eng->specialised || eng->image || eng->msg_bits > 0) break;  // exact matches are listed first; the image kernels are generic builds
-        const bool shape = se.H == H && se.W == W && se.S == S && se.R == R && (se.N == 0 || (se.N == N && se.Q == Q));
+    if (!eng->image && eng->msg_bits == 0) {  // (the image / message kernels are generic builds)
+        // Pick a specialised build: exact-shape entries before size-static ones, first match wins.
         const bool geom_default = cfg->envs_per_workgroup == 0 && cfg->threads_per_workgroup == 0;
-        const bool geom_same = E == se.E && T == se.T;
-        if (shape && (geom_default || geom_same) && B % se.E == 0) {
-            E = se.E;
-            T = se.T;
-            eng->kernel = se.fn;
-            eng->kernel_rollout = se.fn_rollout;
+        const StaticEntry *best = nullptr;
+        for (int exact = 1; exact >= 0 && !best; --exact)
+            for (const StaticEntry &se : kStatic) {
+                if ((se.N != 0) != (exact != 0)) continue;
+                const bool shape = se.H == H && se.W == W && se.S == S && se.R == R && (se.N == 0 || (se.N == N && se.Q == Q));
+                if (!shape || B % se.E != 0) continue;
+                if (geom_default ? (se.max_B == 0 || B <= se.max_B) : (E == se.E && T == se.T)) { best = &se; break; }
+            }
+        if (best) {
+            E = best->E;
+            T = best->T;
+            eng->kernel = best->fn;
+            eng->kernel_rollout = best->fn_rollout;
             eng->specialised = true;
         }
     }
