@@ -43,6 +43,13 @@ int main() {
     timeit("store_only 18.6MB 4096 wg", [&] { hipLaunchKernelGGL(store_only, dim3(4 * n_wg), dim3(256), 0, s, buf, n4 / 4); });
     timeit("store_only 18.6MB 256 wg", [&] { hipLaunchKernelGGL(store_only, dim3(n_wg / 4), dim3(256), 0, s, buf, n4 * 4); });
     timeit("store_only 18.6MB 512 wg x512", [&] { hipLaunchKernelGGL(store_only, dim3(n_wg / 2), dim3(512), 0, s, buf, n4 * 2); });
+    {   // the observation batch of rware-large-16ag, sensor_range 2, B = 16384: 2048 workgroups x 93 696 B = 192 MB
+        float4 *big; CK(hipMalloc(&big, (size_t)2048 * 5856 * sizeof(float4)));
+        timeit("store_only 192 MB (2048 wg)", [&] { hipLaunchKernelGGL(store_only, dim3(2048), dim3(256), 0, s, big, 5856); });
+        timeit("store_only 96 MB (2048 wg)", [&] { hipLaunchKernelGGL(store_only, dim3(2048), dim3(256), 0, s, big, 2928); });
+        timeit("store_only 74 MB = 4x small-4ag", [&] { hipLaunchKernelGGL(store_only, dim3(4096), dim3(256), 0, s, big, 1136); });
+        hipFree(big);
+    }
     for (int sl : {0, 3, 6, 9, 12, 15})
         { char nm[64]; snprintf(nm, 64, "sleep(%d x1024clk)+store", sl);
           timeit(nm, [&] { hipLaunchKernelGGL(sleep_store, dim3(n_wg), dim3(256), 12000, s, buf, n4, sl); }); }

@@ -30,6 +30,8 @@ __device__ __forceinline__ uint32_t hw_id() { return __builtin_amdgcn_s_getreg((
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20); }
 // wave_any(v): true in every lane iff v holds in some active lane of the wavefront (one s_cmp on the ballot)
 __device__ __forceinline__ bool wave_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0; }
+// opaque(x): the value, with everything the optimiser knew about its bits forgotten
+__device__ __forceinline__ uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
 // uniform(x): tells the compiler a value is wave-uniform (v_readfirstlane), so tests on it become scalar branches
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ void wave_sync() {

@@ -922,10 +922,10 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         const int nf4 = nf >> 2;
         float *out = obs_t + (size_t)e0 * N * L;  // 16-byte aligned: e0 is a multiple of 4
         float4 *out4 = reinterpret_cast<float4 *>(out);
-        auto expand = [&](int q4) -> float4 {  // float4 #q4 of the chunk == nibble #q4 of the bit string
-            const uint32_t nib = (s_obits[q4 >> 3] >> ((q4 & 7) << 2)) & 0xFu;
-            // one multiply spreads the 4 bits into 4 bytes (0 or 1 each); each byte converts with v_cvt_f32_ubyteN
-            const uint32_t b = (nib * 0x00204081u) & 0x01010101u;
+        auto spread = [&](uint32_t nib) -> float4 {  // 4 bits -> 4 floats
+            // one multiply spreads the bits into 4 bytes (0 or 1 each); hidden from the optimiser so that each
+            // byte converts with ONE v_cvt_f32_ubyteN instead of a shift/and/convert chain
+            const uint32_t b = opaque((nib * 0x00204081u) & 0x01010101u);
             float4 v;
             v.x = (float)(b & 0xFFu);
             v.y = (float)((b >> 8) & 0xFFu);
@@ -933,12 +933,31 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             v.w = (float)(b >> 24);
             return v;
         };
-        // bulk pass: every float4 that holds no coordinate slot (all but ~2 in 18)
-#pragma unroll 8
-        for (int q4 = tid; q4 < nf4; q4 += T) {
-            const int il = (4 * q4 + 3) / L;  // agent that owns the last element of this float4
-            const int pos = il * L - 4 * q4;  // slot of that agent's x inside the float4 (its y is pos + 1)
-            if ((unsigned)(pos + 1) > 4u) out4[q4] = expand(q4);
+        // 16-byte store at (uniform) out + a per-lane byte offset the optimiser cannot take apart: it then keeps
+        // the scalar-base form of the store instead of rebuilding a 64-bit per-lane address for every pass.
+        // (Not inline asm: hipcc must see the store to respect the write-data hazard of 128-bit stores.)
+        auto store4 = [&](uint32_t byte_off, float4 v) {
+            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(out) + (size_t)opaque(byte_off)) = v;
+        };
+        auto expand = [&](int q4) -> float4 {  // float4 #q4 of the chunk == nibble #q4 of the bit string
+            return spread((s_obits[q4 >> 3] >> ((q4 & 7) << 2)) & 0xFu);
+        };
+        // bulk pass: every float4 that holds no coordinate slot (all but ~2 in 18).  Thread t takes float4
+        // t, t + T, ...: its nibble position inside the word (t & 7) and its word column (t >> 3) never change
+        // (T % 8 == 0), and m = (4 q + 3) mod L — the float4 holds a coordinate slot iff m < 5 — advances by
+        // a constant, so an iteration is a ds_read at a constant offset, ~10 VALU ops and the store.
+        {
+            const int shift = (tid & 7) << 2, words_per_pass = T >> 3;
+            const uint32_t *wp = s_obits + (tid >> 3);
+            const int dm = (4 * T) % L;
+            int m = (4 * tid + 3) % L;
+            const int passes = (nf4 + T - 1) / T;  // a compile-time constant in the specialised builds (full unroll)
+            for (int k = 0; k < passes; ++k) {
+                const int q4 = tid + k * T;
+                if (q4 < nf4 && m >= 5) store4((uint32_t)q4 << 4, spread((wp[k * words_per_pass] >> shift) & 0xFu));
+                m += dm;
+                m = (m >= L) ? m - L : m;
+            }
         }
         // coordinate pass: per agent, the one or two float4s that hold its x (element i*L) and y (i*L + 1)
         for (int i = tid; i < nea; i += T) {
@@ -968,16 +987,21 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         const int Limg = p.n_layers * CELLS;
         const int nf = nea * Limg, nf4 = nf >> 2;
         float *out = obs_t + (size_t)e0 * N * Limg;  // 16-byte aligned: e0 is a multiple of 4
-        float4 *out4 = reinterpret_cast<float4 *>(out);
-        for (int q4 = tid; q4 < nf4; q4 += T) {
-            const uint32_t nib = (s_obits[q4 >> 3] >> ((q4 & 7) << 2)) & 0xFu;
-            const uint32_t b = (nib * 0x00204081u) & 0x01010101u;  // 4 bits -> 4 bytes -> v_cvt_f32_ubyteN
-            float4 v;
-            v.x = (float)(b & 0xFFu);
-            v.y = (float)((b >> 8) & 0xFFu);
-            v.z = (float)((b >> 16) & 0xFFu);
-            v.w = (float)(b >> 24);
-            out4[q4] = v;
+        {
+            const int shift = (tid & 7) << 2, words_per_pass = T >> 3;  // (see the FLATTENED bulk pass)
+            const uint32_t *wp = s_obits + (tid >> 3);
+            const int passes = (nf4 + T - 1) / T;
+            for (int k = 0; k < passes; ++k) {
+                const int q4 = tid + k * T;
+                if (q4 >= nf4) break;
+                const uint32_t b = opaque((((wp[k * words_per_pass] >> shift) & 0xFu) * 0x00204081u) & 0x01010101u);  // 4 bits -> 4 bytes
+                float4 v;
+                v.x = (float)(b & 0xFFu);
+                v.y = (float)((b >> 8) & 0xFFu);
+                v.z = (float)((b >> 16) & 0xFFu);
+                v.w = (float)(b >> 24);
+                *reinterpret_cast<float4 *>(reinterpret_cast<char *>(out) + (size_t)opaque((uint32_t)q4 << 4)) = v;
+            }
         }
         for (int g = (nf4 << 2) + tid; g < nf; g += T) out[g] = ((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f;
     }
