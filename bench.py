@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 ENV_ID = "rware-small-4ag-v1"
 BATCH_PER_GPU = 16384
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-TAPE_STEPS = 256
+TAPE_STEPS = int(os.environ.get("RWARE_BENCH_TAPE_STEPS", "256"))
 
 
 def cpu_baseline(seconds: float = 12.0):
