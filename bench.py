@@ -92,12 +92,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    # Test hooks (tests/test_gpu_parity.py runs the N > 1 path on a 1-GPU box): RWARE_BENCH_BACKEND=gloo replaces
+    # RCCL for the barrier / MAX-over-ranks, RWARE_BENCH_SHARE_GPU=1 lets several ranks share one device.
+    backend = os.environ.get("RWARE_BENCH_BACKEND", "nccl")
+    if os.environ.get("RWARE_BENCH_SHARE_GPU") == "1":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     kw = rware_amd.env_kwargs(args.env_id)
     if args.sensor_range:
@@ -169,7 +177,8 @@ def main():
         fused_elapsed = time.perf_counter() - tf
 
     if dist is not None:
-        tt = torch.tensor([elapsed, kernel_ms, fused_elapsed or 0.0], device=f"cuda:{local_rank}", dtype=torch.float64)
+        tt = torch.tensor([elapsed, kernel_ms, fused_elapsed or 0.0], dtype=torch.float64,
+                          device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(tt[0]), float(tt[1])
         fused_elapsed = float(tt[2]) or None

@@ -3,6 +3,8 @@
   (1) the golden vectors produced by the unmodified reference, and
   (2) the CPU oracle on the same seeded inputs at larger batches,
 bit-exact on every field (grid, agent SoA, queue, counters, PCG64 state, obs, rewards, done)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -262,3 +264,27 @@ def test_headline_batch_soak_every_env_against_oracle():
         assert np.array_equal(st[k], so[k]), k
     assert np.array_equal(env.observations(), orc.obs())
     env.close()
+
+
+def test_bench_two_ranks_through_torchrun():
+    """The driver's N > 1 invocation of bench.py (torch.distributed.run, one rank per GPU), exercised on this
+    1-GPU box: both ranks share the device and gloo stands in for RCCL (bench.py test hooks).  Checks the
+    contract of the JSON line and that rank 0 reports the whole-job rate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RWARE_BENCH_BACKEND="gloo", RWARE_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "200", "--warmup", "20", "--batch", "4096"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 200 and d["warmup"] == 20 and d["scaling"] == "weak"
+    assert d["unit"] == "agent-steps/s" and d["higher_is_better"] is True and "cpu_baseline" not in d
+    expect = 2 * 4096 * 4 * 200 / (d["ms_per_step"] * 1e-3 * 200)
+    assert abs(d["value"] - expect) / expect < 1e-6     # whole-job aggregate over both ranks
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 2
