@@ -39,8 +39,11 @@ enum rw_status {
     RW_ERR_INVALID_ACTION = -2, /* an action outside 0..4 was seen (reference: Action(a) raises
                                    ValueError, rware/warehouse.py:814); sticky until rw_sync      */
     RW_ERR_HIP = -3,            /* a HIP runtime call failed                                      */
-    RW_ERR_UNSUPPORTED = -4,    /* feature outside the accelerated path (msg_bits>0, image obs)   */
-    RW_ERR_NO_DEVICE = -5       /* no usable HIP device: there is NO CPU fallback                 */
+    RW_ERR_UNSUPPORTED = -4,    /* feature outside the accelerated path (DICT observations, ...)  */
+    RW_ERR_NO_DEVICE = -5,      /* no usable HIP device: there is NO CPU fallback                 */
+    RW_ERR_INDEX = -6           /* an AGENT_DIRECTION / AGENT_LOAD image layer met an agent at
+                                   x >= grid_h or y >= grid_w, where the reference raises IndexError
+                                   (rware/warehouse.py:552,558); sticky until rw_sync             */
 };
 
 /* rware/warehouse.py:31-36 */
@@ -52,10 +55,12 @@ enum rw_reward_type { RW_REWARD_GLOBAL = 0, RW_REWARD_INDIVIDUAL = 1, RW_REWARD_
 
 /* rware/warehouse.py:52-56.  DICT is not accelerated (Python-object output). */
 enum rw_observation_type { RW_OBS_FLATTENED = 1, RW_OBS_IMAGE = 2, RW_OBS_IMAGE_DICT = 3 };
-/* rware/warehouse.py:59-70.  AGENT_DIRECTION (3) and AGENT_LOAD (4) are rejected: the reference writes
- * them with transposed indices (`layer[ag.x, ag.y]`, :552/:558), an IndexError on non-square grids. */
-enum rw_image_layer { RW_LAYER_SHELVES = 0, RW_LAYER_REQUESTS = 1, RW_LAYER_AGENTS = 2, RW_LAYER_GOALS = 5,
-                      RW_LAYER_ACCESSIBLE = 6 };
+/* rware/warehouse.py:59-70.  AGENT_DIRECTION and AGENT_LOAD are reproduced as the reference writes them:
+ * with transposed indices (`layer[ag.x, ag.y]` on an (H, W) array, :552/:558), i.e. the value lands on the
+ * mirrored cell, and a state in which the reference raises IndexError is reported as RW_ERR_INDEX by the
+ * next rw_sync (every registered layout has H > W, so that happens as soon as an agent reaches y >= W). */
+enum rw_image_layer { RW_LAYER_SHELVES = 0, RW_LAYER_REQUESTS = 1, RW_LAYER_AGENTS = 2, RW_LAYER_AGENT_DIRECTION = 3,
+                      RW_LAYER_AGENT_LOAD = 4, RW_LAYER_GOALS = 5, RW_LAYER_ACCESSIBLE = 6 };
 
 /* What a step does with an env whose episode ended (Gymnasium vector-env autoreset modes).
  * The reference env itself never resets (the caller calls reset()); DISABLED reproduces that. */

@@ -593,13 +593,24 @@ int orc_obs(const orc_cfg *c, int B, const orc_state *s, float *obs) {
  * out: float32 [B][N][n_layers][WIN][WIN]; features (may be NULL): float32 [B][N][6] =
  * one-hot direction, on_highway, carrying (:730-738). */
 int orc_obs_image(const orc_cfg *c, int B, const orc_state *s, const int32_t *layers, int n_layers,
-                  int directional, float *out, float *features) {
+                  int directional, float *out, float *features, int32_t *index_error) {
+    /* index_error (may be NULL): int32 [B], set to 1 where the reference would raise IndexError.  Its
+     * AGENT_DIRECTION (:547-552) and AGENT_LOAD (:553-558) layers are written as layer[ag.x, ag.y] on an
+     * (H, W) array — transposed — so an agent at x >= H or y >= W (a loaded one for AGENT_LOAD) is out of
+     * bounds; where it is in bounds the value lands on the transposed cell, which is restated as is. */
     const int H = c->H, W = c->W, N = c->N, R = c->R, HW = H * W, WIN = 2 * R + 1;
     for (int l = 0; l < n_layers; ++l)
-        if (layers[l] == 3 || layers[l] == 4 || layers[l] < 0 || layers[l] > 6) return -4;
+        if (layers[l] < 0 || layers[l] > 6) return -4;
     for (int e = 0; e < B; ++e) {
         env_view v = view(c, s, e);
         const int32_t *gA = v.grid, *gS = v.grid + HW;
+        if (index_error) {
+            index_error[e] = 0;
+            for (int l = 0; l < n_layers; ++l)
+                for (int j = 0; j < N; ++j)
+                    if ((layers[l] == 3 || (layers[l] == 4 && v.acarry[j])) && (v.ax[j] >= H || v.ay[j] >= W))
+                        index_error[e] = 1;
+        }
         for (int i = 0; i < N; ++i) {
             float *o = out + ((size_t)e * N + i) * n_layers * WIN * WIN;
             for (int l = 0; l < n_layers; ++l)
@@ -620,6 +631,14 @@ int orc_obs_image(const orc_cfg *c, int B, const orc_state *s, const int32_t *la
                                 case 0: val = gS[cell] > 0 ? 1.0f : 0.0f; break;
                                 case 1: val = (gS[cell] && in_queue(v.queue, c->Q, gS[cell]) >= 0) ? 1.0f : 0.0f; break;
                                 case 2: val = gA[cell] > 0 ? 1.0f : 0.0f; break;
+                                case 3: /* layer[ag.x, ag.y] = dir + 1: row index = the agent's x, column = its y */
+                                    for (int j = 0; j < N; ++j)
+                                        if (v.ax[j] == y && v.ay[j] == x) val = (float)(v.adir[j] + 1);
+                                    break;
+                                case 4: /* layer[ag.x, ag.y] = 1 for loaded agents */
+                                    for (int j = 0; j < N; ++j)
+                                        if (v.ax[j] == y && v.ay[j] == x && v.acarry[j]) val = 1.0f;
+                                    break;
                                 case 5:
                                     for (int g = 0; g < c->n_goals; ++g)
                                         if (c->goals[2 * g] == x && c->goals[2 * g + 1] == y) val = 1.0f;

@@ -228,6 +228,7 @@ class OracleVecEnv:
         return out
 
     DEFAULT_IMAGE_LAYERS = (0, 1, 2, 5, 6)  # SHELVES, REQUESTS, AGENTS, GOALS, ACCESSIBLE (warehouse.py:160-166)
+    raise_index_error = True  # mirror the reference's IndexError of the transposed layers
 
     def obs_image(self, layers=DEFAULT_IMAGE_LAYERS, directional=True, with_features=False):
         """IMAGE observation (B, N, C, WIN, WIN) [+ features (B, N, 6) for IMAGE_DICT]."""
@@ -236,12 +237,16 @@ class OracleVecEnv:
         out = np.zeros((self.B, self.N, len(ly), win, win), np.float32)
         feat = np.zeros((self.B, self.N, 6), np.float32) if with_features else None
         st = self._state()
+        bad = np.zeros(self.B, np.int32)
         rc = lib().orc_obs_image(C.byref(self.cfg), self.B, C.byref(st), ly.ctypes.data_as(C.c_void_p), len(ly),
                                  int(bool(directional)), out.ctypes.data_as(C.c_void_p),
-                                 None if feat is None else feat.ctypes.data_as(C.c_void_p))
-        if rc == -4:
-            raise NotImplementedError("AGENT_DIRECTION / AGENT_LOAD image layers are not restated (transposed indexing)")
+                                 None if feat is None else feat.ctypes.data_as(C.c_void_p),
+                                 bad.ctypes.data_as(C.c_void_p))
         assert rc == 0
+        self.image_index_error = bad.astype(bool)  # envs where the reference raises IndexError (:552, :558)
+        if bad.any() and self.raise_index_error:
+            raise IndexError(f"AGENT_DIRECTION / AGENT_LOAD layer: transposed index out of bounds in {int(bad.sum())} env(s) "
+                             "(rware/warehouse.py:552,558)")
         return (out, feat) if with_features else out
 
     def recalc_grid(self, shelf_xy):

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "librware_hip.so")
 
 RW_ABI_VERSION = 1
-RW_OK, RW_ERR_INVALID_ARG, RW_ERR_INVALID_ACTION, RW_ERR_HIP, RW_ERR_UNSUPPORTED, RW_ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+RW_OK, RW_ERR_INVALID_ARG, RW_ERR_INVALID_ACTION, RW_ERR_HIP, RW_ERR_UNSUPPORTED, RW_ERR_NO_DEVICE, RW_ERR_INDEX = 0, -1, -2, -3, -4, -5, -6
 
 BUF = {
     "obs": 0, "rewards": 1, "terminated": 2, "truncated": 3, "grid": 4, "agent_x": 5, "agent_y": 6,
@@ -194,6 +194,8 @@ class Engine:
             msg = (self.lib.rw_last_error(self._h) or b"").decode()
             if rc == RW_ERR_INVALID_ACTION:
                 raise ValueError(msg or "invalid action")
+            if rc == RW_ERR_INDEX:  # the reference's IndexError in _make_img_obs (rware/warehouse.py:552,558)
+                raise IndexError(msg or "image layer index out of bounds")
             raise EngineError(rc, msg)
 
     def close(self):

@@ -231,10 +231,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         for (int l = 0; l < n_layers; ++l) {
             layers[l] = cfg->image_layers[l];
             const int v = layers[l];
-            if (v == 3 || v == 4)
-                return fail(nullptr, RW_ERR_UNSUPPORTED, "image layer %d (AGENT_DIRECTION/AGENT_LOAD) is not supported: the "
-                            "reference indexes it transposed (rware/warehouse.py:552,558)", v);
-            if (v != RW_LAYER_SHELVES && v != RW_LAYER_REQUESTS && v != RW_LAYER_AGENTS && v != RW_LAYER_GOALS && v != RW_LAYER_ACCESSIBLE)
+            if (v < RW_LAYER_SHELVES || v > RW_LAYER_ACCESSIBLE)
                 return fail(nullptr, RW_ERR_INVALID_ARG, "unknown image layer %d", v);
         }
     }
@@ -455,6 +452,10 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.status = eng->d_status;
     p.n_layers = n_layers;
     p.directional = cfg->image_directional ? 1 : 0;
+    p.transposed_layers = 0;
+    if (eng->image)
+        for (int l = 0; l < n_layers; ++l)
+            p.transposed_layers |= (layers[l] == RW_LAYER_AGENT_DIRECTION ? 1 : 0) | (layers[l] == RW_LAYER_AGENT_LOAD ? 2 : 0);
     for (int l = 0; l < rw::MAX_IMAGE_LAYERS; ++l) p.layers[l] = l < n_layers ? layers[l] : 0;
     p.features = obs_type == RW_OBS_IMAGE_DICT ? (float *)eng->buf[RW_BUF_FEATURES].ptr : nullptr;
     p.msg_bits = cfg->msg_bits;
@@ -698,6 +699,9 @@ int rw_sync(rw_engine *eng) {
         RW_HIP(eng, hipStreamSynchronize(eng->stream));
         if (st & rw::STATUS_INVALID_ACTION)
             return fail(eng, RW_ERR_INVALID_ACTION, "an action outside 0..4 was submitted (executed as NOOP)");
+        if (st & rw::STATUS_IMAGE_INDEX)
+            return fail(eng, RW_ERR_INDEX, "AGENT_DIRECTION / AGENT_LOAD image layer: an agent at x >= grid height or y >= grid "
+                        "width; the reference raises IndexError there (rware/warehouse.py:552,558)");
     }
     return RW_OK;
 }

@@ -61,11 +61,14 @@ enum : int { ACT_NOOP = 0, ACT_FORWARD = 1, ACT_LEFT = 2, ACT_RIGHT = 3, ACT_TOG
 enum : int { DIR_UP = 0, DIR_DOWN = 1, DIR_LEFT = 2, DIR_RIGHT = 3 };
 enum : int { REW_GLOBAL = 0, REW_INDIVIDUAL = 1, REW_TWO_STAGE = 2 };
 enum : int { AR_DISABLED = 0, AR_NEXT_STEP = 1, AR_SAME_STEP = 2 };
-enum : int { STATUS_INVALID_ACTION = 1 };
+enum : int { STATUS_INVALID_ACTION = 1,
+             // an AGENT_DIRECTION / AGENT_LOAD image layer of the reference would have raised IndexError (:552, :558)
+             STATUS_IMAGE_INDEX = 2 };
 enum : int { MAX_GOALS = 16, MAX_IMAGE_LAYERS = 8 };
 enum : int { OBS_FLATTENED = 0, OBS_IMAGE = 1, OBS_FLATTENED_MSG = 2 };  // _MSG: FLATTENED with msg_bits > 0
 // ImageLayer values of the reference (rware/warehouse.py:59-70); 3 and 4 are rejected by the host
-enum : int { LAYER_SHELVES = 0, LAYER_REQUESTS = 1, LAYER_AGENTS = 2, LAYER_GOALS = 5, LAYER_ACCESSIBLE = 6 };
+enum : int { LAYER_SHELVES = 0, LAYER_REQUESTS = 1, LAYER_AGENTS = 2, LAYER_AGENT_DIRECTION = 3, LAYER_AGENT_LOAD = 4,
+             LAYER_GOALS = 5, LAYER_ACCESSIBLE = 6 };
 
 struct Params {
     // The twelve pointers the P0 stage-in needs come first, contiguous and cache-line aligned: the
@@ -91,6 +94,7 @@ struct Params {
     int32_t *status;      // [1] sticky error bits
     // IMAGE / IMAGE_DICT observations (rware/warehouse.py:527-596); unused by the FLATTENED kernels
     int32_t n_layers, directional;
+    int32_t transposed_layers;  // bit 0: AGENT_DIRECTION requested, bit 1: AGENT_LOAD requested
     int32_t layers[MAX_IMAGE_LAYERS];
     float *features;      // [B][N][6] one-hot direction, on_highway, carrying (IMAGE_DICT), or nullptr
     // communication bits (rware/warehouse.py:255-259, 660-667, 810-812); only the OBS_FLATTENED_MSG kernels
@@ -790,18 +794,24 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 atomicOr(&s_obits[wd], self << sh);
                 if (sh > 26) atomicOr(&s_obits[wd + 1], self >> (32 - sh));
             }
-        } else if (p.features) {  // IMAGE_DICT feature vector: one-hot direction, on_highway, carrying (:730-738)
-            for (int i = lane; i < nea; i += 64) {
-                if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
-                float *f = p.features + ((size_t)e0 * N + i) * 6;
-                const int d = s_dir[i];
-                f[0] = d == 0 ? 1.0f : 0.0f; f[1] = d == 1 ? 1.0f : 0.0f; f[2] = d == 2 ? 1.0f : 0.0f; f[3] = d == 3 ? 1.0f : 0.0f;
-                f[4] = on_highway(s_ay[i] * W + s_ax[i]) ? 1.0f : 0.0f;
-                f[5] = s_carry[i] ? 1.0f : 0.0f;
-            }
+        } else {
+            if (p.features)  // IMAGE_DICT feature vector: one-hot direction, on_highway, carrying (:730-738)
+                for (int i = lane; i < nea; i += 64) {
+                    if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
+                    float *f = p.features + ((size_t)e0 * N + i) * 6;
+                    const int d = s_dir[i];
+                    f[0] = d == 0 ? 1.0f : 0.0f; f[1] = d == 1 ? 1.0f : 0.0f; f[2] = d == 2 ? 1.0f : 0.0f; f[3] = d == 3 ? 1.0f : 0.0f;
+                    f[4] = on_highway(s_ay[i] * W + s_ax[i]) ? 1.0f : 0.0f;
+                    f[5] = s_carry[i] ? 1.0f : 0.0f;
+                }
+            if (p.transposed_layers)  // layer[ag.x, ag.y] on an (H, W) array (:552, :558): IndexError when out of bounds
+                for (int i = lane; i < nea; i += 64) {  // (envs reset in this launch included: nobody is loaded there)
+                    const bool loaded = s_carry[i] && !s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET];
+                    const bool counted = (p.transposed_layers & 1) || loaded;
+                    if (counted && (s_ax[i] >= H || s_ay[i] >= W)) atomicOr(p.status, STATUS_IMAGE_INDEX);
+                }
         }
     }
-
     // ---------------------------------------------------------------- P7: observation bits (:598-674)
     // One contiguous bit string per workgroup: bit (i*L + k) == obs[agent i][k] for k >= 2; the two
     // coordinate slots k = 0,1 stay 0 here and are filled in as floats during expansion.
@@ -881,6 +891,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             const int e = rw_div18(i, mN);
             const int ax = s_ax[i], ay = s_ay[i], d = p.directional ? s_dir[i] : DIR_UP;
             uint32_t m_shelf = 0, m_req = 0, m_agent = 0, m_goal = 0, m_map = 0;
+            uint32_t m_tagent = 0, m_tload = 0;  // the transposed layers: an agent / a loaded agent with (x, y) == (row, col)
 #pragma unroll
             for (int cc = 0; cc < WIN; ++cc) {
                 int wr = r, wc = cc;  // (r, cc) indexes the rotated image, (wr, wc) the north-up window
@@ -899,12 +910,20 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     }
                     for (int g = 0; g < p.n_goals; ++g)
                         if (p.goal_cells[g] == cell) m_goal |= 1u << cc;
+                    if (p.transposed_layers && x < H && y < W) {  // layer[ag.x, ag.y]: the agent standing at (x', y') = (y, x)
+                        const int t = s_ga[e * HW + x * W + y];
+                        if (t & 0x7f) m_tagent |= 1u << cc;
+                        if (t & 0x80) m_tload |= 1u << cc;
+                    }
                 }
             }
             for (int l = 0; l < p.n_layers; ++l) {
                 const int layer = p.layers[l];
+                // (AGENT_DIRECTION holds dir + 1 in 1..4: its bit marks the cell, the value is patched in after the
+                //  expansion, see below)
                 const uint32_t bits = layer == LAYER_SHELVES ? m_shelf : layer == LAYER_REQUESTS ? m_req
                                     : layer == LAYER_AGENTS ? m_agent : layer == LAYER_GOALS ? m_goal
+                                    : layer == LAYER_AGENT_DIRECTION ? m_tagent : layer == LAYER_AGENT_LOAD ? m_tload
                                     : (m_map & ~m_agent);  // LAYER_ACCESSIBLE
                 const int bit = i * Limg + (l * WIN + r) * WIN;
                 const int wd = bit >> 5, sh = bit & 31;
@@ -1004,6 +1023,29 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             }
         }
         for (int g = (nf4 << 2) + tid; g < nf; g += T) out[g] = ((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f;
+        if (p.transposed_layers & 1) {
+            // AGENT_DIRECTION (:547-552): the marked cells hold dir + 1, not 1.  Patched after every 0/1 store of
+            // the workgroup has completed (full barrier: vmcnt), one thread per (agent, image row) as in P7.
+            __syncthreads();
+            for (int w = tid; w < nea * WIN; w += T) {
+                const int i = w / WIN, r = w - i * WIN;
+                const int e = rw_div18(i, mN);
+                const int ax = s_ax[i], ay = s_ay[i], d = p.directional ? s_dir[i] : DIR_UP;
+                for (int cc = 0; cc < WIN; ++cc) {
+                    int wr = r, wc = cc;
+                    if (d == DIR_DOWN) { wr = WIN - 1 - r; wc = WIN - 1 - cc; }
+                    else if (d == DIR_LEFT) { wr = WIN - 1 - cc; wc = r; }
+                    else if (d == DIR_RIGHT) { wr = cc; wc = WIN - 1 - r; }
+                    const int y = ay - R + wr, x = ax - R + wc;
+                    if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H || x >= H || y >= W) continue;
+                    const int ida = s_ga[e * HW + x * W + y] & 0x7f;
+                    if (!ida) continue;
+                    const float v = (float)(s_dir[e * N + ida - 1] + 1);
+                    for (int l = 0; l < p.n_layers; ++l)
+                        if (p.layers[l] == LAYER_AGENT_DIRECTION) out[(size_t)i * Limg + (l * WIN + r) * WIN + cc] = v;
+                }
+            }
+        }
     }
     RW_MARK(TL_OBS_STORED);
     if (kRollout) write_back();

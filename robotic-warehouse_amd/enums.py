@@ -34,8 +34,8 @@ class ImageLayer(Enum):  # rware/warehouse.py:59-70
     SHELVES = 0
     REQUESTS = 1
     AGENTS = 2
-    AGENT_DIRECTION = 3  # not accelerated: the reference writes it with transposed indices (:552)
-    AGENT_LOAD = 4       # not accelerated: same (:558)
+    AGENT_DIRECTION = 3  # the reference writes it with transposed indices, layer[ag.x, ag.y] (:552): reproduced as is
+    AGENT_LOAD = 4       # same (:558)
     GOALS = 5
     ACCESSIBLE = 6
 

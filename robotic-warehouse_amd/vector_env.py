@@ -69,10 +69,10 @@ class WarehouseVecEnv(_VectorEnvBase):
         if self.observation_type == ObservationType.DICT:
             raise NotImplementedError("ObservationType.DICT (nested Python dicts) is not accelerated; FLATTENED carries the same content")
         layers = tuple(ImageLayer(enum_value(l)) for l in (image_observation_layers or DEFAULT_IMAGE_LAYERS))
-        if self.observation_type != ObservationType.FLATTENED and any(
-                l in (ImageLayer.AGENT_DIRECTION, ImageLayer.AGENT_LOAD) for l in layers):
-            raise NotImplementedError("ImageLayer.AGENT_DIRECTION / AGENT_LOAD are written with transposed indices by the "
-                                      "reference (rware/warehouse.py:552,558) and are not accelerated")
+        # AGENT_DIRECTION / AGENT_LOAD are written with transposed indices by the reference (rware/warehouse.py:552,558):
+        # reproduced as is, including its IndexError once an agent stands at x >= grid height or y >= grid width
+        self._index_layers = self.observation_type != ObservationType.FLATTENED and any(
+            l in (ImageLayer.AGENT_DIRECTION, ImageLayer.AGENT_LOAD) for l in layers)
         if self.msg_bits and self.observation_type != ObservationType.FLATTENED:
             raise NotImplementedError("msg_bits > 0 is accelerated with FLATTENED observations only")
         self.image_observation_layers = layers
@@ -268,6 +268,8 @@ class WarehouseVecEnv(_VectorEnvBase):
         if self.output == "torch":
             v = self._torch_views()
             return {"image": v["obs"], "features": v["features"]} if self.observation_type == ObservationType.IMAGE_DICT else v["obs"]
+        if self._index_layers:
+            self.sync()  # IndexError where the reference's _make_img_obs raises it (device tensors: at sync())
         obs = self._gather("obs")
         if self.observation_type == ObservationType.IMAGE_DICT:
             return {"image": obs, "features": self._gather("features")}

@@ -59,6 +59,16 @@ CASES = [
     # communication bits (warehouse.py:255-259, 660-667, 810-812): actions are [Action, bit, bit, ...] per agent
     ("msg2-small-4ag", "rware-small-4ag-v2", {"msg_bits": 2, "max_steps": 150}, 3, 330, 13000),
     ("msg3-tiny-3ag-sr2", "rware-tiny-3ag-v2", {"msg_bits": 3, "sensor_range": 2}, 2, 200, 14000),
+    # AGENT_DIRECTION / AGENT_LOAD layers, written by the reference as layer[ag.x, ag.y] (warehouse.py:552,558): a square
+    # 10 x 10 grid keeps the transposed index in bounds (every registered layout raises IndexError within a few steps)
+    ("img-square-5ag-transposed-layers", None,
+     {"shelf_columns": 3, "column_height": 3, "shelf_rows": 2, "n_agents": 5, "msg_bits": 0, "sensor_range": 2,
+      "request_queue_size": 3, "max_inactivity_steps": None, "max_steps": 120, "reward_type": 1,
+      "observation_type": 2, "image_observation_layers": [3, 4, 0, 2]}, 3, 300, 15000),
+    ("imgdict-square-5ag-transposed-northup", None,
+     {"shelf_columns": 3, "column_height": 3, "shelf_rows": 2, "n_agents": 5, "msg_bits": 0, "sensor_range": 1,
+      "request_queue_size": 3, "max_inactivity_steps": None, "max_steps": 90, "reward_type": 2,
+      "observation_type": 3, "image_observation_directional": False, "image_observation_layers": [4, 5, 3]}, 2, 200, 16000),
 ]
 
 
@@ -71,6 +81,8 @@ def gen_case(name, env_id, extra, E, T, seed):
     kw["reward_type"] = wh.RewardType(kw_json["reward_type"])
     obs_type = int(kw_json.get("observation_type", 1))
     kw["observation_type"] = wh.ObservationType(obs_type)
+    if "image_observation_layers" in kw:
+        kw["image_observation_layers"] = [wh.ImageLayer(int(l)) for l in kw_json["image_observation_layers"]]
 
     def obs_arrays(o):
         """(obs, features) of one env in array form for the configured observation type."""

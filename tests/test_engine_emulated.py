@@ -117,9 +117,6 @@ def test_host_layer_errors_and_views():
     menv.close()
     with pytest.raises(NotImplementedError):
         rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.DICT, **kw)
-    with pytest.raises(NotImplementedError):   # transposed-index layers of the reference (:552, :558)
-        rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.IMAGE,
-                                  image_observation_layers=[rware_amd.ImageLayer.AGENTS, rware_amd.ImageLayer.AGENT_DIRECTION], **kw)
     with pytest.raises(rware_amd._capi.EngineError):
         rware_amd.WarehouseVecEnv(2, library=LIB, envs_per_workgroup=6, **kw)   # not a multiple of 4
     env.close()
@@ -276,6 +273,79 @@ def test_image_observations_match_oracle(obs_type, directional, layers, sr):
     for t in range(25, 40):
         o2, r2, d2 = orc.step_autoreset(acts[t], "next_step")
         assert np.array_equal(img[t - 25], o2[0] if isinstance(o2, tuple) else o2) and np.array_equal(rew[t - 25], r2), t
+    env.close()
+
+
+SQUARE = dict(shelf_columns=3, column_height=3, shelf_rows=2, n_agents=5, msg_bits=0, sensor_range=2,
+              request_queue_size=3, max_inactivity_steps=None, max_steps=30, reward_type=1)   # a 10 x 10 grid
+
+
+@pytest.mark.parametrize("obs_type,directional,layers", [
+    (2, True, [3, 4, 0, 2]),           # AGENT_DIRECTION, AGENT_LOAD, SHELVES, AGENTS
+    (3, False, [4, 5, 3]),             # IMAGE_DICT, north-up: AGENT_LOAD, GOALS, AGENT_DIRECTION
+])
+def test_transposed_image_layers_match_oracle(obs_type, directional, layers):
+    """AGENT_DIRECTION / AGENT_LOAD as the reference writes them, layer[ag.x, ag.y] (:552, :558); on a square
+    grid the transposed index is always in bounds."""
+    extra = dict(observation_type=obs_type, image_observation_directional=directional, image_observation_layers=layers)
+    B = 6
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=128, **SQUARE, **extra)
+    assert tuple(env.grid_size) == (10, 10)
+    orc = OracleVecEnv(B, **SQUARE, **extra)
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return np.array_equal(a["image"], b[0]) and np.array_equal(a["features"], b[1])
+        return np.array_equal(a, b)
+
+    assert same(env.reset(seed=11)[0], orc.reset(seed=11))
+    rng = np.random.default_rng(3)
+    acts = rng.choice(5, size=(70, B, 5), p=[.1, .45, .15, .15, .15])
+    seen_dir = seen_load = 0
+    for t in range(50):
+        o, r, d, _, _ = env.step(acts[t])
+        o2, r2, d2 = orc.step_autoreset(acts[t], "next_step")
+        assert same(o, o2) and np.array_equal(r, r2), t
+        img = o["image"] if isinstance(o, dict) else o
+        seen_dir += int((img[:, :, layers.index(3)] > 1).sum())
+        seen_load += int(img[:, :, layers.index(4)].sum())
+    assert seen_dir > 0 and seen_load > 0          # the layers were exercised (values 2..4, loaded agents in view)
+    img, rew, term = env.rollout(acts[50:])
+    for t in range(50, 70):
+        o2, r2, d2 = orc.step_autoreset(acts[t], "next_step")
+        assert np.array_equal(img[t - 50], o2[0] if isinstance(o2, tuple) else o2) and np.array_equal(rew[t - 50], r2), t
+    env.close()
+
+
+@pytest.mark.parametrize("layer", [3, 4])
+def test_transposed_image_layers_raise_indexerror_like_the_reference(layer):
+    """On every registered layout H > W, so the reference's layer[ag.x, ag.y] raises IndexError once an agent
+    (a loaded one for AGENT_LOAD) reaches y >= W; the engine reports it at the same step."""
+    kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
+    kw["reward_type"] = kw["reward_type"].value
+    extra = dict(observation_type=2, image_observation_layers=[2, layer])
+    B = 4
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **kw, **extra)
+    orc = OracleVecEnv(B, **kw, **extra)
+    rng = np.random.default_rng(1)
+
+    def attempt(f):
+        try:
+            return f(), False
+        except IndexError:
+            return None, True
+
+    (o, e1), (o2, e2) = attempt(lambda: env.reset(seed=2)[0]), attempt(lambda: orc.reset(seed=2))
+    assert e1 == e2
+    t = 0
+    while not e1 and t < 400:
+        a = rng.choice(5, size=(B, 2), p=[.05, .5, .15, .15, .15])
+        (res, e1), (res2, e2) = attempt(lambda: env.step(a)), attempt(lambda: orc.step_autoreset(a, "next_step"))
+        assert e1 == e2, t
+        if not e1:
+            assert np.array_equal(res[0], res2[0]), t
+        t += 1
+    assert e1, "no agent ever reached y >= W"
     env.close()
 
 

@@ -232,6 +232,71 @@ def test_image_observations_match_oracle(env_id, obs_type, directional, sr, B):
     env.close()
 
 
+SQUARE = dict(shelf_columns=3, column_height=3, shelf_rows=2, n_agents=5, msg_bits=0, sensor_range=2,
+              request_queue_size=3, max_inactivity_steps=None, max_steps=60, reward_type=1)   # a 10 x 10 grid
+
+
+@pytest.mark.parametrize("obs_type,directional,layers,B", [
+    (2, True, [3, 4, 0, 2], 2048),      # AGENT_DIRECTION, AGENT_LOAD, SHELVES, AGENTS
+    (3, False, [4, 5, 3], 1000),        # IMAGE_DICT, north-up, ragged batch
+])
+def test_transposed_image_layers_match_oracle(obs_type, directional, layers, B):
+    """AGENT_DIRECTION / AGENT_LOAD exactly as the reference writes them (layer[ag.x, ag.y], :552/:558), on a
+    square grid where that index is always in bounds; per-step and fused rollout."""
+    extra = dict(observation_type=obs_type, image_observation_directional=directional, image_observation_layers=layers)
+    env = rware_amd.WarehouseVecEnv(B, **SQUARE, **extra)
+    orc = OracleVecEnv(B, **SQUARE, **extra)
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return np.array_equal(a["image"], b[0]) and np.array_equal(a["features"], b[1])
+        return np.array_equal(a, b)
+
+    assert same(env.reset(seed=4)[0], orc.reset(seed=4))
+    acts = np.random.default_rng(7).choice(5, size=(150, B, 5), p=[.1, .45, .15, .15, .15])
+    for t in range(110):
+        o, r, d, _, _ = env.step(acts[t])
+        o2, r2, d2 = orc.step_autoreset(acts[t], "next_step")
+        assert same(o, o2) and np.array_equal(r, r2) and np.array_equal(d, d2.astype(bool)), t
+    img, rew, term = env.rollout(acts[110:])
+    for t in range(110, 150):
+        o2, r2, d2 = orc.step_autoreset(acts[t], "next_step")
+        assert np.array_equal(img[t - 110], o2[0] if isinstance(o2, tuple) else o2) and np.array_equal(rew[t - 110], r2), t
+    env.close()
+
+
+@pytest.mark.parametrize("layer", [3, 4])
+def test_transposed_image_layers_raise_indexerror_like_the_reference(layer):
+    """Registered layouts have H > W: the reference's transposed write raises IndexError once an agent (a loaded
+    one for AGENT_LOAD) stands at y >= W; the engine reports it for the same reset()/step() call."""
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    kw["reward_type"] = kw["reward_type"].value
+    extra = dict(observation_type=2, image_observation_layers=[2, layer])
+    B = 64 if layer == 3 else 8
+    env = rware_amd.WarehouseVecEnv(B, **kw, **extra)
+    orc = OracleVecEnv(B, **kw, **extra)
+    rng = np.random.default_rng(1)
+
+    def attempt(f):
+        try:
+            return f(), False
+        except IndexError:
+            return None, True
+
+    (o, e1), (o2, e2) = attempt(lambda: env.reset(seed=2)[0]), attempt(lambda: orc.reset(seed=2))
+    assert e1 == e2
+    t = 0
+    while not e1 and t < 600:
+        a = rng.choice(5, size=(B, 4), p=[.05, .5, .15, .15, .15])
+        (res, e1), (res2, e2) = attempt(lambda: env.step(a)), attempt(lambda: orc.step_autoreset(a, "next_step"))
+        assert e1 == e2, t
+        if not e1:
+            assert np.array_equal(res[0], res2[0]), t
+        t += 1
+    assert e1, "no agent ever reached y >= W"
+    env.close()
+
+
 def test_headline_batch_soak_every_env_against_oracle():
     """BASELINE config 3 at full size for 1100 steps (two mass autoresets): EVERY env's rewards and done
     flags each step, observations every 25 steps, and the complete final state, against the oracle."""

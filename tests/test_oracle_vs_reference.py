@@ -41,3 +41,45 @@ def test_registry_has_228_ids_and_v2_suffix():
     import gymnasium, rware  # noqa
     ids = [k for k in gymnasium.registry if k.startswith("rware-")]
     assert len(ids) == 228 and all(i.endswith("-v2") for i in ids)
+
+
+@pytest.mark.parametrize("env_id,layer", [
+    ("rware-tiny-2ag-v2", 3), ("rware-small-4ag-v2", 3), ("rware-small-4ag-v2", 4), ("rware-medium-6ag-hard-v2", 4),
+])
+def test_transposed_image_layers_raise_indexerror_at_the_same_step(env_id, layer):
+    """AGENT_DIRECTION (3) / AGENT_LOAD (4) are written as layer[ag.x, ag.y] on an (H, W) array (:552, :558): on the
+    registered layouts (H > W) the reference raises IndexError as soon as an agent — a loaded one for AGENT_LOAD —
+    stands at y >= W.  The oracle reports it for the same reset()/step() call and matches every obs before it."""
+    wh = rr.load_reference()
+    hit = 0
+    for seed in range(6):
+        kw = rr.registry_kwargs(env_id)
+        kw.update(observation_type=wh.ObservationType.IMAGE,
+                  image_observation_layers=[wh.ImageLayer.AGENTS, wh.ImageLayer(layer)])
+        env = wh.Warehouse(**kw)
+        okw = {k: getattr(v, "value", v) for k, v in kw.items()}
+        okw["image_observation_layers"] = [2, layer]
+        orc = OracleVecEnv(1, **okw)
+
+        def attempt(f):
+            try:
+                return f(), False
+            except IndexError:
+                return None, True
+
+        (obs, e1), (o2, e2) = attempt(lambda: env.reset(seed=seed)[0]), attempt(lambda: orc.reset(seed=seed))
+        assert e1 == e2, ("reset", seed)
+        rng = np.random.default_rng(seed)
+        t = 0
+        while not e1 and t < 300:
+            assert np.array_equal(np.stack(obs)[None], o2), (seed, t)
+            a = rng.integers(0, 5, size=env.n_agents)
+            (res, e1), (r2, e2) = attempt(lambda: rr.ref_step(env, list(a))), attempt(lambda: (orc.step(a[None].astype(np.int32)), orc.obs()))
+            assert e1 == e2, (seed, t)
+            if not e1:
+                obs, o2 = res[0], r2[1]
+                if res[2]:
+                    break
+            t += 1
+        hit += int(e1)
+    assert hit >= 3   # the IndexError is the common case, not a corner
