@@ -53,7 +53,8 @@ enum rw_direction { RW_UP = 0, RW_DOWN = 1, RW_DIR_LEFT = 2, RW_DIR_RIGHT = 3 };
 /* rware/warehouse.py:46-49 */
 enum rw_reward_type { RW_REWARD_GLOBAL = 0, RW_REWARD_INDIVIDUAL = 1, RW_REWARD_TWO_STAGE = 2 };
 
-/* rware/warehouse.py:52-56.  DICT is not accelerated (Python-object output). */
+/* rware/warehouse.py:52-56.  DICT (nested Python objects) is FLATTENED at this boundary: the host layer
+ * un-flattens the same vector (rware/warehouse.py:432-443). */
 enum rw_observation_type { RW_OBS_FLATTENED = 1, RW_OBS_IMAGE = 2, RW_OBS_IMAGE_DICT = 3 };
 /* rware/warehouse.py:59-70.  AGENT_DIRECTION and AGENT_LOAD are reproduced as the reference writes them:
  * with transposed indices (`layer[ag.x, ag.y]` on an (H, W) array, :552/:558), i.e. the value lands on the

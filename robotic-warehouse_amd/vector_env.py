@@ -66,14 +66,17 @@ class WarehouseVecEnv(_VectorEnvBase):
             raise ValueError("msg_bits must be in 0..16")
         self.msg_bits = int(msg_bits)
         self.observation_type = ObservationType(enum_value(observation_type))
-        if self.observation_type == ObservationType.DICT:
-            raise NotImplementedError("ObservationType.DICT (nested Python dicts) is not accelerated; FLATTENED carries the same content")
+        # DICT (rware/warehouse.py:676-720): the engine produces the FLATTENED vector — spaces.flatten() of exactly that
+        # nested dict (:432-443, :505-522) — and the host hands out the batched dict as views / casts of it.
+        self._dict_obs = self.observation_type == ObservationType.DICT
+        engine_obs_type = ObservationType.FLATTENED if self._dict_obs else self.observation_type
         layers = tuple(ImageLayer(enum_value(l)) for l in (image_observation_layers or DEFAULT_IMAGE_LAYERS))
         # AGENT_DIRECTION / AGENT_LOAD are written with transposed indices by the reference (rware/warehouse.py:552,558):
         # reproduced as is, including its IndexError once an agent stands at x >= grid height or y >= grid width
-        self._index_layers = self.observation_type != ObservationType.FLATTENED and any(
+        image = self.observation_type in (ObservationType.IMAGE, ObservationType.IMAGE_DICT)
+        self._index_layers = image and any(
             l in (ImageLayer.AGENT_DIRECTION, ImageLayer.AGENT_LOAD) for l in layers)
-        if self.msg_bits and self.observation_type != ObservationType.FLATTENED:
+        if self.msg_bits and image:
             raise NotImplementedError("msg_bits > 0 is accelerated with FLATTENED observations only")
         self.image_observation_layers = layers
         self.image_observation_directional = bool(image_observation_directional)
@@ -124,8 +127,8 @@ class WarehouseVecEnv(_VectorEnvBase):
                 max_steps=max_steps, reward_type=self.reward_type.value,
                 normalised_coordinates=normalised_coordinates, autoreset_mode=autoreset_mode, device_id=dev,
                 envs_per_workgroup=envs_per_workgroup, threads_per_workgroup=threads_per_workgroup,
-                stream=stream, library=library, observation_type=self.observation_type.value,
-                image_layers=[l.value for l in layers] if self.observation_type != ObservationType.FLATTENED else (),
+                stream=stream, library=library, observation_type=engine_obs_type.value,
+                image_layers=[l.value for l in layers] if image else (),
                 image_directional=image_observation_directional, msg_bits=self.msg_bits))
         self._bounds = [b for b in self._bounds if b[1] > b[0]]
         self.devices = devices[: len(self.engines)]
@@ -136,7 +139,7 @@ class WarehouseVecEnv(_VectorEnvBase):
     # ------------------------------------------------------------------------------- spaces
     def _make_spaces(self):
         n, l, b = self.n_agents, self.obs_length, self.num_envs
-        if self.observation_type != ObservationType.FLATTENED:
+        if self.observation_type in (ObservationType.IMAGE, ObservationType.IMAGE_DICT):
             win = 2 * self.sensor_range + 1
             shape = (len(self.image_observation_layers), win, win)
             self.single_observation_space = tuple(_Space(shape, np.float32) for _ in range(n))
@@ -266,14 +269,64 @@ class WarehouseVecEnv(_VectorEnvBase):
         """FLATTENED: (B, N, L).  IMAGE: (B, N, C, 2r+1, 2r+1).  IMAGE_DICT: {"image": ..., "features": (B, N, 6)}
         (the batched form of the reference's per-agent dicts, rware/warehouse.py:739-742)."""
         if self.output == "torch":
+            if self._dict_obs:
+                raise NotImplementedError("DICT observations are host-side views of the FLATTENED batch: use output='numpy' "
+                                          "(or FLATTENED with output='torch')")
             v = self._torch_views()
             return {"image": v["obs"], "features": v["features"]} if self.observation_type == ObservationType.IMAGE_DICT else v["obs"]
         if self._index_layers:
             self.sync()  # IndexError where the reference's _make_img_obs raises it (device tensors: at sync())
         obs = self._gather("obs")
+        if self._dict_obs:
+            return self.dict_from_flat(obs)
         if self.observation_type == ObservationType.IMAGE_DICT:
             return {"image": obs, "features": self._gather("features")}
         return obs
+
+    def dict_from_flat(self, flat):
+        """The DICT observation (rware/warehouse.py:676-720) of every agent, batched: same nesting and keys as the
+        reference's per-agent dict, every leaf an array with leading (B, N) — `location` (B,N,2) int32, the
+        MultiBinary(1) fields (B,N,1), `direction` (B,N), `local_message` (B,N,M) or None, `sensors` a tuple of
+        (2r+1)^2 dicts in the reference's row-major window order.  `flat` is the FLATTENED batch (B, N, L)."""
+        M, cells = self.msg_bits, (2 * self.sensor_range + 1) ** 2
+        i8 = lambda a: a.astype(np.int64)
+        out = {"self": {
+            "location": flat[..., 0:2].astype(np.int32),  # np.array([x, y], dtype=np.int32) — truncates normalised coordinates too (:685)
+            "carrying_shelf": i8(flat[..., 2:3]),
+            "direction": i8(flat[..., 3:7].argmax(-1)),
+            "on_highway": i8(flat[..., 7:8]),
+        }}
+        sensors = []
+        for c in range(cells):
+            o = 8 + (7 + M) * c
+            sensors.append({
+                "has_agent": i8(flat[..., o:o + 1]),
+                "direction": i8(flat[..., o + 1:o + 5].argmax(-1)),  # 0 for an empty cell (:697)
+                "local_message": i8(flat[..., o + 5:o + 5 + M]) if M else None,
+                "has_shelf": i8(flat[..., o + 5 + M:o + 6 + M]),
+                "shelf_requested": i8(flat[..., o + 6 + M:o + 7 + M]),
+            })
+        out["sensors"] = tuple(sensors)
+        return out
+
+    @staticmethod
+    def unbatch_dict_obs(obs, b):
+        """Env b of a batched DICT observation in the reference's own form: a tuple of N per-agent dicts with
+        lists / ints / arrays exactly as `_get_default_obs` builds them (:676-720)."""
+        n = obs["self"]["direction"].shape[1]
+
+        def agent(i):
+            s = obs["self"]
+            return {
+                "self": {"location": s["location"][b, i].copy(), "carrying_shelf": [int(s["carrying_shelf"][b, i, 0])],
+                         "direction": int(s["direction"][b, i]), "on_highway": [int(s["on_highway"][b, i, 0])]},
+                "sensors": tuple({
+                    "has_agent": [int(c["has_agent"][b, i, 0])], "direction": int(c["direction"][b, i]),
+                    "local_message": None if c["local_message"] is None else [int(v) for v in c["local_message"][b, i]],
+                    "has_shelf": [int(c["has_shelf"][b, i, 0])], "shelf_requested": [int(c["shelf_requested"][b, i, 0])],
+                } for c in obs["sensors"]),
+            }
+        return tuple(agent(i) for i in range(n))
 
     def _torch_views(self):
         if self._tviews is None:

@@ -115,8 +115,15 @@ def test_host_layer_errors_and_views():
     with pytest.raises(AssertionError):               # [Action, bit, bit] per agent
         menv.step(np.zeros((4, 2), int))
     menv.close()
-    with pytest.raises(NotImplementedError):
-        rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.DICT, **kw)
+    denv = rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.DICT, **kw)
+    dobs, _ = denv.reset(seed=5)                      # DICT: the batched nested dict of :676-720
+    flat, _ = rware_amd.WarehouseVecEnv(2, library=LIB, **kw).reset(seed=5)
+    assert dobs["self"]["location"].dtype == np.int32 and np.array_equal(dobs["self"]["location"], flat[..., :2].astype(np.int32))
+    assert len(dobs["sensors"]) == 9 and dobs["sensors"][4]["has_agent"].all()   # the centre cell is the agent itself
+    assert list(dobs["sensors"][0]) == ["has_agent", "direction", "local_message", "has_shelf", "shelf_requested"]
+    per_agent = denv.unbatch_dict_obs(dobs, 1)
+    assert len(per_agent) == kw["n_agents"] and per_agent[0]["self"]["direction"] in (0, 1, 2, 3)
+    denv.close()
     with pytest.raises(rware_amd._capi.EngineError):
         rware_amd.WarehouseVecEnv(2, library=LIB, envs_per_workgroup=6, **kw)   # not a multiple of 4
     env.close()

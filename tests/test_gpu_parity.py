@@ -297,6 +297,33 @@ def test_transposed_image_layers_raise_indexerror_like_the_reference(layer):
     env.close()
 
 
+def test_dict_observations_are_the_unflattened_oracle_vector():
+    """ObservationType.DICT: host views of the FLATTENED batch (whose equality with the reference's flatten(DICT)
+    the golden replay establishes; the dict itself is checked against the live reference in the CPU suite)."""
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    kw["reward_type"] = kw["reward_type"].value
+    B = 512
+    env = rware_amd.WarehouseVecEnv(B, observation_type=rware_amd.ObservationType.DICT, **kw)
+    orc = OracleVecEnv(B, **kw)
+    d, _ = env.reset(seed=9)
+    flat = orc.reset(seed=9)
+    rng = np.random.default_rng(2)
+    for t in range(40):
+        if t:
+            a = rng.integers(0, 5, size=(B, 4))
+            d = env.step(a)[0]
+            flat = orc.step_autoreset(a, "next_step")[0]
+        assert np.array_equal(d["self"]["location"], flat[..., :2].astype(np.int32))
+        assert np.array_equal(d["self"]["direction"], flat[..., 3:7].argmax(-1))
+        assert np.array_equal(d["self"]["carrying_shelf"][..., 0], flat[..., 2]) and np.array_equal(d["self"]["on_highway"][..., 0], flat[..., 7])
+        for c, cell in enumerate(d["sensors"]):
+            o = 8 + 7 * c
+            assert np.array_equal(cell["has_agent"][..., 0], flat[..., o]) and np.array_equal(cell["direction"], flat[..., o + 1:o + 5].argmax(-1))
+            assert np.array_equal(cell["has_shelf"][..., 0], flat[..., o + 5]) and np.array_equal(cell["shelf_requested"][..., 0], flat[..., o + 6])
+            assert cell["local_message"] is None
+    env.close()
+
+
 def test_headline_batch_soak_every_env_against_oracle():
     """BASELINE config 3 at full size for 1100 steps (two mass autoresets): EVERY env's rewards and done
     flags each step, observations every 25 steps, and the complete final state, against the oracle."""

@@ -83,3 +83,54 @@ def test_transposed_image_layers_raise_indexerror_at_the_same_step(env_id, layer
             t += 1
         hit += int(e1)
     assert hit >= 3   # the IndexError is the common case, not a corner
+
+
+@pytest.mark.parametrize("env_id,extra", [
+    ("rware-tiny-2ag-v2", {}),
+    ("rware-small-4ag-v2", {"msg_bits": 2, "sensor_range": 2}),
+    ("rware-tiny-3ag-v2", {"normalised_coordinates": True}),
+])
+def test_dict_observations_of_the_engine_match_the_reference(env_id, extra):
+    """ObservationType.DICT (:676-720) end to end: the product engine (host-thread emulation build) against the
+    live reference, every key and leaf of every agent's nested dict."""
+    import engine_backend as eb
+    import rware_amd
+
+    wh = rr.load_reference()
+    kw = rr.registry_kwargs(env_id)
+    kw.update(extra)
+    B, seed = 3, 77
+    refs = [wh.Warehouse(**dict(kw, observation_type=wh.ObservationType.DICT)) for _ in range(B)]
+    ekw = {k: getattr(v, "value", v) for k, v in kw.items()}
+    env = rware_amd.WarehouseVecEnv(B, library=eb.build_emu(), observation_type=rware_amd.ObservationType.DICT,
+                                    autoreset_mode="disabled", envs_per_workgroup=4, threads_per_workgroup=64, **ekw)
+    M = kw["msg_bits"]
+
+    def check(got, want):
+        assert type(got) is type(want) and set(got) == set(want)
+        for part in ("self",):
+            for k, v in want[part].items():
+                g = got[part][k]
+                assert (np.array_equal(g, v) and g.dtype == v.dtype) if isinstance(v, np.ndarray) else g == v, k
+        assert len(got["sensors"]) == len(want["sensors"])
+        for cg, cw in zip(got["sensors"], want["sensors"]):
+            assert list(cg) == list(cw)          # same keys in the same order
+            for k, v in cw.items():
+                assert cg[k] == (list(v) if isinstance(v, np.ndarray) else v), k
+
+    obs, _ = env.reset(seed=seed)
+    for b, r in enumerate(refs):
+        want, _ = r.reset(seed=seed + b)
+        for g, w in zip(env.unbatch_dict_obs(obs, b), want):
+            check(g, w)
+    rng = np.random.default_rng(0)
+    for t in range(60):
+        a = rng.integers(0, 5, size=(B, refs[0].n_agents))
+        full = a if not M else np.concatenate([a[..., None], rng.integers(0, 2, size=(B, refs[0].n_agents, M))], axis=-1)
+        obs, rew, term, trunc, _ = env.step(full)
+        for b, r in enumerate(refs):
+            want, rr_, d, _, _ = rr.ref_step(r, [list(x) for x in full[b]] if M else list(full[b]))
+            for g, w in zip(env.unbatch_dict_obs(obs, b), want):
+                check(g, w)
+            assert np.array_equal(np.asarray(rr_, np.float32), rew[b])
+    env.close()
