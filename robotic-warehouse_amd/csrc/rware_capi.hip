@@ -5,6 +5,7 @@
 // without a usable HIP device rw_create fails with RW_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -82,6 +83,9 @@ using step_kernel_t = void (*)(const rw::Params *, const int32_t *, const int32_
 
 template <int R, bool kRollout>
 step_kernel_t generic_kernel(bool wide, bool image, bool msg) {
+    if (msg && image)
+        return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg, kRollout, rw::OBS_IMAGE_MSG>
+                    : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg, kRollout, rw::OBS_IMAGE_MSG>;
     if (msg)
         return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg, kRollout, rw::OBS_FLATTENED_MSG>
                     : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg, kRollout, rw::OBS_FLATTENED_MSG>;
@@ -236,8 +240,6 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         }
     }
     if (cfg->msg_bits < 0 || cfg->msg_bits > 16) return fail(nullptr, RW_ERR_INVALID_ARG, "msg_bits %d not in 0..16", cfg->msg_bits);
-    if (cfg->msg_bits > 0 && obs_type != RW_OBS_FLATTENED)
-        return fail(nullptr, RW_ERR_UNSUPPORTED, "msg_bits > 0 is accelerated with FLATTENED observations only");
     const int HW = H * W;
     if (HW > 10000) return fail(nullptr, RW_ERR_UNSUPPORTED, "H*W > 10000 (numpy switches choice() algorithm)");
     if (N > HW) return fail(nullptr, RW_ERR_INVALID_ARG, "more agents than cells");
@@ -284,7 +286,9 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     eng->msg_bits = cfg->msg_bits;
     const int AM = 1 + cfg->msg_bits;
     eng->L = eng->image ? n_layers * CELLS : 8 + (7 + cfg->msg_bits) * CELLS;  // floats per agent in RW_BUF_OBS
-    eng->OW = (8 + (7 + cfg->msg_bits) * CELLS + 31) / 32;                      // LDS bit-string words per agent
+    // LDS bit-string words per agent (must equal the kernel's OW): the flattened row, or n_layers image planes
+    eng->OW = eng->image ? std::max((8 + 7 * CELLS + 31) / 32, (n_layers * CELLS + 31) / 32)
+                         : (8 + (7 + cfg->msg_bits) * CELLS + 31) / 32;
     const int SW = (S + 32) / 32;
 
     RW_HIP_C(hipSetDevice(cfg->device_id));

@@ -65,7 +65,7 @@ enum : int { STATUS_INVALID_ACTION = 1,
              // an AGENT_DIRECTION / AGENT_LOAD image layer of the reference would have raised IndexError (:552, :558)
              STATUS_IMAGE_INDEX = 2 };
 enum : int { MAX_GOALS = 16, MAX_IMAGE_LAYERS = 8 };
-enum : int { OBS_FLATTENED = 0, OBS_IMAGE = 1, OBS_FLATTENED_MSG = 2 };  // _MSG: FLATTENED with msg_bits > 0
+enum : int { OBS_FLATTENED = 0, OBS_IMAGE = 1, OBS_FLATTENED_MSG = 2, OBS_IMAGE_MSG = 3 };  // _MSG: msg_bits > 0
 // ImageLayer values of the reference (rware/warehouse.py:59-70); 3 and 4 are rejected by the host
 enum : int { LAYER_SHELVES = 0, LAYER_REQUESTS = 1, LAYER_AGENTS = 2, LAYER_AGENT_DIRECTION = 3, LAYER_AGENT_LOAD = 4,
              LAYER_GOALS = 5, LAYER_ACCESSIBLE = 6 };
@@ -245,7 +245,8 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
 template <int R, typename CellT, typename Cfg, bool kRollout, int kObs = OBS_FLATTENED>
 __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L0 = 8 + 7 * CELLS, OW0 = (L0 + 31) / 32;
-    constexpr bool kMsg = (kObs == OBS_FLATTENED_MSG);
+    constexpr bool kImage = (kObs == OBS_IMAGE || kObs == OBS_IMAGE_MSG);
+    constexpr bool kMsg = (kObs == OBS_FLATTENED_MSG || kObs == OBS_IMAGE_MSG);  // actions are [Action, message bits...]
     const Params &p = *cp;  // constant per engine, device-resident, L2-warm
     const LaunchArgs la{la_actions, la_op, la_n_steps, la_obs, la_rewards, la_terminated, la_reset_mask, la_timeline,
                         la_act_stride, la_obs_stride, la_rew_stride, la_term_stride};
@@ -253,7 +254,9 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const bool tl_on = (la.op & OP_FLAG_TIMELINE) != 0;  // the flag is preloaded; la.timeline itself is fetched only when set
     // observation row length: a compile-time constant except with communication bits
     const int M = kMsg ? p.msg_bits : 0, AM = 1 + M, CW = 7 + M;
-    const int L = kMsg ? 8 + CW * CELLS : L0, OW = kMsg ? (L + 31) / 32 : OW0;
+    const int L = kMsg ? 8 + CW * CELLS : L0;
+    // words of the observation bit string per agent (the image string holds n_layers * CELLS bits per agent)
+    const int OW = kImage ? max(OW0, (p.n_layers * CELLS + 31) / 32) : kMsg ? (L + 31) / 32 : OW0;
     extern __shared__ __align__(16) int32_t smem[];
 
     int tid = threadIdx.x;
@@ -690,7 +693,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             p.acarry[gi] = 0; p.adeliv[gi] = 0;
             if (kMsg) { s_msg[i] = 0; p.amsg[gi] = 0; }  // fresh Agent objects: message = zeros (:89)
             rew_t[gi] = s_rew[i];
-            if (kObs != OBS_IMAGE) {
+            if (!kImage) {
                 s_fx[i] = coordf(0, s_ax[i]);
                 s_fy[i] = coordf(1, s_ay[i]);
                 const uint32_t self = (2u << s_dir[i]) | (on_highway(s_ay[i] * W + s_ax[i]) ? 32u : 0u);
@@ -783,7 +786,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // wavefronts 0..2 first.
     for (int role = wave; role < 4; role += nw) {  // wave-uniform
         if (role != 3) continue;
-        if (kObs != OBS_IMAGE) {  // self part of the observation, k = 2..7 (:643-647), and the float coordinates k = 0,1
+        if (!kImage) {  // self part of the observation, k = 2..7 (:643-647), and the float coordinates k = 0,1
             for (int i = lane; i < nea; i += 64) {
                 if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
                 const int x = s_ax[i], y = s_ay[i];
@@ -815,7 +818,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // ---------------------------------------------------------------- P7: observation bits (:598-674)
     // One contiguous bit string per workgroup: bit (i*L + k) == obs[agent i][k] for k >= 2; the two
     // coordinate slots k = 0,1 stay 0 here and are filled in as floats during expansion.
-    if constexpr (kMsg) {
+    if constexpr (kMsg && !kImage) {
         // with communication bits a cell code is 7 + M bits wide: [has_agent, dir x4, message x M, has_shelf,
         // requested] (:655-673); gathered per (agent, cell)
         for (int w = tid; w < nea * CELLS; w += T) {
@@ -936,7 +939,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     RW_MARK(TL_OBS_BITS);
 
     // ---------------------------------------------------------------- ST: obs, float4 #q == nibble #q
-    if constexpr (kObs != OBS_IMAGE) {
+    if constexpr (!kImage) {
         const int nf = nea * L;
         const int nf4 = nf >> 2;
         float *out = obs_t + (size_t)e0 * N * L;  // 16-byte aligned: e0 is a multiple of 4

@@ -76,8 +76,6 @@ class WarehouseVecEnv(_VectorEnvBase):
         image = self.observation_type in (ObservationType.IMAGE, ObservationType.IMAGE_DICT)
         self._index_layers = image and any(
             l in (ImageLayer.AGENT_DIRECTION, ImageLayer.AGENT_LOAD) for l in layers)
-        if self.msg_bits and image:
-            raise NotImplementedError("msg_bits > 0 is accelerated with FLATTENED observations only")
         self.image_observation_layers = layers
         self.image_observation_directional = bool(image_observation_directional)
         if output not in ("numpy", "torch"):

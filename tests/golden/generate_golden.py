@@ -65,6 +65,10 @@ CASES = [
      {"shelf_columns": 3, "column_height": 3, "shelf_rows": 2, "n_agents": 5, "msg_bits": 0, "sensor_range": 2,
       "request_queue_size": 3, "max_inactivity_steps": None, "max_steps": 120, "reward_type": 1,
       "observation_type": 2, "image_observation_layers": [3, 4, 0, 2]}, 3, 300, 15000),
+    # image observations together with communication bits: actions [Action, bit, bit], messages are stored but not shown (:527-596)
+    ("img-msg2-tiny-3ag-8layers", "rware-tiny-3ag-v2",
+     {"observation_type": 2, "msg_bits": 2, "sensor_range": 2, "max_steps": 80,
+      "image_observation_layers": [0, 1, 2, 5, 6, 0, 2, 6]}, 2, 180, 17000),
     ("imgdict-square-5ag-transposed-northup", None,
      {"shelf_columns": 3, "column_height": 3, "shelf_rows": 2, "n_agents": 5, "msg_bits": 0, "sensor_range": 1,
       "request_queue_size": 3, "max_inactivity_steps": None, "max_steps": 90, "reward_type": 2,

@@ -105,8 +105,10 @@ def test_host_layer_errors_and_views():
     o, r, term, trunc, info = env.step([[rware_amd.Action.FORWARD, rware_amd.Action.NOOP]] * 4)
     assert r.shape == (4, 2) and term.dtype == bool and not trunc.any() and info == {}
     assert env.shelf_xy().shape == (4, env.n_shelves, 2)
-    with pytest.raises(NotImplementedError):   # communication bits only with FLATTENED observations
-        rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.IMAGE, **dict(kw, msg_bits=1))
+    ienv = rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.IMAGE, **dict(kw, msg_bits=1))
+    io, _ = ienv.reset(seed=0)                        # communication bits with image observations: actions (B, N, 2)
+    assert io.shape == (2, 2, 5, 3, 3) and ienv.step(np.zeros((2, 2, 2), int))[0].shape == io.shape
+    ienv.close()
     menv = rware_amd.WarehouseVecEnv(4, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **dict(kw, msg_bits=2))
     mo, _ = menv.reset(seed=0)
     assert mo.shape == (4, 2, 8 + 9 * 9)              # L = 8 + (7 + M)(2r+1)^2
