@@ -125,7 +125,7 @@ typedef struct rw_config {
     int32_t n_image_layers;       /* 0 == the reference default list (:160-166)                  */
     int32_t image_layers[8];      /* rw_image_layer values, channel order                        */
     int32_t msg_bits;             /* M communication bits (:152): an agent's action is then
-                                     [Action, bit_0..bit_{M-1}], L = 8 + (7+M)(2r+1)^2; FLATTENED only */
+                                     [Action, bit_0..bit_{M-1}]; FLATTENED L = 8 + (7+M)(2r+1)^2      */
     int32_t reserved_;
     const uint8_t *highways;      /* host, [H*W], 1 == highway (no shelf spawns, no unloading)   */
     const int32_t *goals_xy;      /* host, [n_goals][2] = (x, y), list order == reward order     */
