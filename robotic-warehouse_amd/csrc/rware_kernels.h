@@ -271,6 +271,11 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int H = Cfg::kH ? Cfg::kH : p.H, W = Cfg::kW ? Cfg::kW : p.W, HW = H * W;
     const int S = Cfg::kS ? Cfg::kS : p.S, SW = (S + 32) / 32, B = p.B;
     const int nea = ne * N;
+    // wavefront 3 = service wave after the agent phases (see WB); pays off while the observation of a workgroup is
+    // small enough that three wavefronts expand it as fast as the stores drain (measured: small-4ag 8.91 -> 8.79 us,
+    // fused 4.93 -> 4.56; medium-6ag-hard 8.56 -> 8.40; large-16ag r=2 with 23 K floats per workgroup 43.6 -> 46.1, so not there)
+    const bool split = nw == 4 && nea * (kImage ? p.n_layers * CELLS : L) <= 8192;
+    const int TW = split ? T - 64 : T;        // threads that gather window rows and expand the observation
     const uint32_t mN = Cfg::kN ? rw_magic18(Cfg::kN) : p.magic_n;
     // optional per-workgroup phase stamps (100 MHz wall clock); one scalar branch per mark when off
 #define RW_MARK(k) do { if (tl_on && tid == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + (k)] = wall_clock64(); } while (0)
@@ -412,6 +417,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         lane = tid & 63;
         wave = tid >> 6;
     }
+    const bool worker = !split || wave < 3;
     const int32_t *act_t = la.actions + (size_t)t * la.act_stride;
     float *obs_t = la.obs + (size_t)t * la.obs_stride;
     float *rew_t = la.rewards + (size_t)t * la.rew_stride;
@@ -728,8 +734,13 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     //                  18 MB observation stream they queue behind it and hold every wavefront ~0.8 us longer
     //   fused rollout  after the observation stores: the next step's compute hides them, and the stream
     //                  starts 0.4 us earlier (5.62 -> 5.44 us per step)
-    auto write_back = [&]() {
-    for (int role = wave; role < 4; role += nw) {  // wave-uniform
+    // With 4 wavefronts the workgroup splits after the agent phases ("split"): wavefront 3 is the service wave — it
+    // writes the self bits while wavefronts 0..2 gather the window rows, and after the barrier it does ALL the state
+    // write-back while wavefronts 0..2 expand and store the observation.  The observation stream — what the step
+    // ends with — then starts one write-back earlier, and the small state stores go out beside its head instead of
+    // behind its tail.
+    auto write_back = [&](int first_role, int role_step) {
+    for (int role = first_role; role < 3; role += role_step) {  // wave-uniform
         if (role == 0) {  // per-env counters and flags, request queue
             if (op == OP_STEP)
                 for (int e = lane; e < ne; e += 64) {
@@ -779,7 +790,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         }
     }
     };
-    if (!kRollout) write_back();
+    if (!split && !kRollout) write_back(wave, nw);
 
     // ---------------------------------------------------------------- OS: self part of the observation
     // Runs on the LAST role slot (wavefront 3 of 4), side by side with the window rows below, which fill
@@ -821,7 +832,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     if constexpr (kMsg && !kImage) {
         // with communication bits a cell code is 7 + M bits wide: [has_agent, dir x4, message x M, has_shelf,
         // requested] (:655-673); gathered per (agent, cell)
-        for (int w = tid; w < nea * CELLS; w += T) {
+        if (worker)
+        for (int w = tid; w < nea * CELLS; w += TW) {
             const int i = w / CELLS, cidx = w - i * CELLS;
             const int e = rw_div18(i, mN);
             const int x = s_ax[i] + cidx % WIN - R, y = s_ay[i] + cidx / WIN - R;
@@ -840,7 +852,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     } else if constexpr (kObs == OBS_FLATTENED) {
     // one thread per (agent, window row): the agent's position is read once, the row's WIN cells are
     // gathered with independent LDS reads, and the row's 7*WIN bits go out in one or two LDS atomics
-    for (int w = tid; w < nea * WIN; w += T) {
+    if (worker)
+    for (int w = tid; w < nea * WIN; w += TW) {
         const int i = w / WIN, row = w - i * WIN;
         const int e = rw_div18(i, mN);
         const int ax = s_ax[i], y = s_ay[i] + row - R;
@@ -889,7 +902,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // thread per (agent, image row): the row's WIN cells are read once and give one WIN-bit mask per
         // property; every requested layer is then one of those masks.
         const int Limg = p.n_layers * CELLS;
-        for (int w = tid; w < nea * WIN; w += T) {
+        if (worker)
+        for (int w = tid; w < nea * WIN; w += TW) {
             const int i = w / WIN, r = w - i * WIN;
             const int e = rw_div18(i, mN);
             const int ax = s_ax[i], ay = s_ay[i], d = p.directional ? s_dir[i] : DIR_UP;
@@ -937,6 +951,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     }
     lds_barrier();
     RW_MARK(TL_OBS_BITS);
+    if (split && wave == 3) write_back(0, 1);  // all three roles, beside the head of the observation stream
 
     // ---------------------------------------------------------------- ST: obs, float4 #q == nibble #q
     if constexpr (!kImage) {
@@ -968,21 +983,22 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // t, t + T, ...: its nibble position inside the word (t & 7) and its word column (t >> 3) never change
         // (T % 8 == 0), and m = (4 q + 3) mod L — the float4 holds a coordinate slot iff m < 5 — advances by
         // a constant, so an iteration is a ds_read at a constant offset, ~10 VALU ops and the store.
-        {
-            const int shift = (tid & 7) << 2, words_per_pass = T >> 3;
+        if (worker) {
+            const int shift = (tid & 7) << 2, words_per_pass = TW >> 3;  // (TW % 8 == 0)
             const uint32_t *wp = s_obits + (tid >> 3);
-            const int dm = (4 * T) % L;
+            const int dm = (4 * TW) % L;
             int m = (4 * tid + 3) % L;
-            const int passes = (nf4 + T - 1) / T;  // a compile-time constant in the specialised builds (full unroll)
+            const int passes = (nf4 + TW - 1) / TW;  // a compile-time constant in the specialised builds (full unroll)
             for (int k = 0; k < passes; ++k) {
-                const int q4 = tid + k * T;
+                const int q4 = tid + k * TW;
                 if (q4 < nf4 && m >= 5) store4((uint32_t)q4 << 4, spread((wp[k * words_per_pass] >> shift) & 0xFu));
                 m += dm;
                 m = (m >= L) ? m - L : m;
             }
         }
         // coordinate pass: per agent, the one or two float4s that hold its x (element i*L) and y (i*L + 1)
-        for (int i = tid; i < nea; i += T) {
+        if (worker)
+        for (int i = tid; i < nea; i += TW) {
             const int g = i * L, q4 = g >> 2, pos = g & 3;
             const float fx = s_fx[i], fy = s_fy[i];
             if (q4 < nf4) {
@@ -999,7 +1015,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 out4[q4 + 1] = v;
             }
         }
-        for (int g = (nf4 << 2) + tid; g < nf; g += T) {  // < 4 leftover floats (partial last workgroup)
+        if (worker)
+        for (int g = (nf4 << 2) + tid; g < nf; g += TW) {  // < 4 leftover floats (partial last workgroup)
             const int i = g / L, k = g - i * L;
             out[g] = (k >= 2) ? (((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f)
                               : (k == 0 ? s_fx[i] : s_fy[i]);
@@ -1009,12 +1026,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         const int Limg = p.n_layers * CELLS;
         const int nf = nea * Limg, nf4 = nf >> 2;
         float *out = obs_t + (size_t)e0 * N * Limg;  // 16-byte aligned: e0 is a multiple of 4
-        {
-            const int shift = (tid & 7) << 2, words_per_pass = T >> 3;  // (see the FLATTENED bulk pass)
+        if (worker) {
+            const int shift = (tid & 7) << 2, words_per_pass = TW >> 3;  // (see the FLATTENED bulk pass)
             const uint32_t *wp = s_obits + (tid >> 3);
-            const int passes = (nf4 + T - 1) / T;
+            const int passes = (nf4 + TW - 1) / TW;
             for (int k = 0; k < passes; ++k) {
-                const int q4 = tid + k * T;
+                const int q4 = tid + k * TW;
                 if (q4 >= nf4) break;
                 const uint32_t b = opaque((((wp[k * words_per_pass] >> shift) & 0xFu) * 0x00204081u) & 0x01010101u);  // 4 bits -> 4 bytes
                 float4 v;
@@ -1025,12 +1042,14 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 *reinterpret_cast<float4 *>(reinterpret_cast<char *>(out) + (size_t)opaque((uint32_t)q4 << 4)) = v;
             }
         }
-        for (int g = (nf4 << 2) + tid; g < nf; g += T) out[g] = ((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f;
+        if (worker)
+        for (int g = (nf4 << 2) + tid; g < nf; g += TW) out[g] = ((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f;
         if (p.transposed_layers & 1) {
             // AGENT_DIRECTION (:547-552): the marked cells hold dir + 1, not 1.  Patched after every 0/1 store of
             // the workgroup has completed (full barrier: vmcnt), one thread per (agent, image row) as in P7.
             __syncthreads();
-            for (int w = tid; w < nea * WIN; w += T) {
+            if (worker)
+            for (int w = tid; w < nea * WIN; w += TW) {
                 const int i = w / WIN, r = w - i * WIN;
                 const int e = rw_div18(i, mN);
                 const int ax = s_ax[i], ay = s_ay[i], d = p.directional ? s_dir[i] : DIR_UP;
@@ -1051,7 +1070,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         }
     }
     RW_MARK(TL_OBS_STORED);
-    if (kRollout) write_back();
+    if (!split && kRollout) write_back(wave, nw);
     }  // fused-rollout step loop
     RW_MARK(TL_END);
     if (tl_on && lane == 0) {  // where each wavefront ran: slot 10 = 4 x 16 bits of HW_ID, slot 11 = XCC id
