@@ -11,21 +11,27 @@
 //       read at all — it is rebuilt in LDS from the agent coordinates.  The int32 grid
 //       [B][2][H][W] stays current in HBM (patched below) as the buffer callers see.
 //   AG  the per-agent phases, one lane per (env, agent), all agents of an env inside ONE
-//       wavefront, ordered by wave-local LDS syncs (no workgroup barrier):
+//       wavefront, ordered by wave-local LDS syncs (no workgroup barrier); written branch-free
+//       (a wavefront holds every action and heading at once); a wave-uniform ballot skips the
+//       chain bookkeeping when nobody steps onto an occupied cell:
 //         P1  move intent + shelf-block cancel              (:825-846, Agent.req_location :102-116)
 //         P2  collision resolution in closed form            (:848-876; notes below)
 //         P3  apply (move / turn / load / unload) + incremental grid update instead of
 //             _recalc_grid                                   (:880-901, :749-755)
 //         P5  goals, request replacement (numpy-exact PCG64 draw), rewards, termination (:903-942)
 //   RS  on-device reset for autoreset / rw_reset, numpy-exact draws (rare path)   (:757-802)
-//   WB  write-back, one role per wavefront so that the four jobs run side by side: per-env
-//       counters/flags + queue; agent SoA + rewards (coalesced); the grid/shadow patch of the
-//       <= 2N cells per layer that changed; the self part of the observation.
+//   WB  state write-back in three roles: per-env counters/flags + queue; agent SoA + rewards
+//       (coalesced); the grid/shadow patch of the <= 2N cells per layer that changed.
+//   OS  the self part of the observation (own coordinates, load, heading, on-highway).
 //   P7  observation (:598-674): per (agent, window row) the 7-bit cell codes are OR-ed into ONE
 //       contiguous bit string per workgroup (bit g == obs element g of the chunk), so float4 #q is
 //       nibble #q; dwordx4 stores, the two coordinate floats per agent in a small second pass.
-//       IMAGE / IMAGE_DICT observations (:527-596) use the same bit string (kObs == OBS_IMAGE).
-//       The barriers after P0 wait on LDS only, so the WB stores drain underneath P7.
+//       IMAGE / IMAGE_DICT observations (:527-596) use the same bit string (kImage).
+//   Order after AG.  With 4 wavefronts and a small observation chunk, wavefront 3 is a service
+//   wave: OS while wavefronts 0..2 gather P7, then all of WB while they expand and store, so the
+//   observation stream — what the step ends with — starts as early as possible.  Otherwise
+//   WB -> OS/P7 -> stores, one role per wavefront (the barriers after P0 wait on LDS only, so
+//   the WB stores drain underneath P7).
 //   The rollout variant (kRollout) wraps AG..P7 in a step loop: the chunk stays in LDS for T steps.
 //
 // Roofline: integer/indexing work, no MFMA; bound by HBM bytes.  Algorithmic bytes per
