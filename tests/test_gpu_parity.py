@@ -324,11 +324,19 @@ def test_dict_observations_are_the_unflattened_oracle_vector():
     env.close()
 
 
-def test_headline_batch_soak_every_env_against_oracle():
-    """BASELINE config 3 at full size for 1100 steps (two mass autoresets): EVERY env's rewards and done
-    flags each step, observations every 25 steps, and the complete final state, against the oracle."""
-    B, N, T = 16384, 4, 1100
-    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+@pytest.mark.parametrize("env_id,extra,B,T", [
+    ("rware-small-4ag-v1", {}, 16384, 1100),                          # BASELINE config 3 (headline): two mass autoresets
+    ("rware-tiny-2ag-v1", {}, 4096, 560),                             # config 2
+    ("rware-medium-6ag-hard-v1", {}, 8192, 560),                      # config 4, per-GPU shard of 65536 / 8
+    ("rware-large-16ag-v1", {"sensor_range": 2}, 16384, 520),         # config 5, per-GPU shard of 131072 / 8
+])
+def test_full_batch_soak_every_env_against_oracle(env_id, extra, B, T):
+    """Every BASELINE config at its full per-GPU batch: EVERY env's rewards and done flags each step,
+    observations every 25 steps, and the complete final state, against the oracle; per-step launches
+    interleaved with fused 40-step rollouts, across the mass autoreset at step 500."""
+    kw = rware_amd.env_kwargs(env_id)
+    kw.update(extra)
+    N = kw["n_agents"]
     env = rware_amd.WarehouseVecEnv(B, **kw)
     assert env.engines[0].info.specialised == 1
     orc = OracleVecEnv(B, **dict(kw, reward_type=kw["reward_type"].value))
