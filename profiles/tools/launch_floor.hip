@@ -21,7 +21,7 @@ __global__ void sleep_store(float4 *out, int n4_per_wg, int sleeps) {
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 int main() {
-    const int n_wg = 1024, n4 = 1136, iters = 2000;
+    const int n_wg = 1024, n4 = 1136, iters = 1000;
     float4 *buf; CK(hipMalloc(&buf, (size_t)n_wg * n4 * sizeof(float4)));
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -49,6 +49,10 @@ int main() {
         timeit("store_only 96 MB (2048 wg)", [&] { hipLaunchKernelGGL(store_only, dim3(2048), dim3(256), 0, s, big, 2928); });
         timeit("store_only 74 MB = 4x small-4ag", [&] { hipLaunchKernelGGL(store_only, dim3(4096), dim3(256), 0, s, big, 1136); });
         hipFree(big);
+        // beyond the 256 MiB Infinity Cache: B = 262144 of small-4ag (16384 workgroups x 18 176 B = 298 MB)
+        float4 *huge; CK(hipMalloc(&huge, (size_t)16384 * 1136 * sizeof(float4)));
+        timeit("store_only 298 MB (16384 wg)", [&] { hipLaunchKernelGGL(store_only, dim3(16384), dim3(256), 0, s, huge, 1136); });
+        hipFree(huge);
     }
     for (int sl : {0, 3, 6, 9, 12, 15})
         { char nm[64]; snprintf(nm, 64, "sleep(%d x1024clk)+store", sl);
