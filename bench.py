@@ -66,8 +66,8 @@ def cpu_baseline(seconds: float = 12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="envs per GPU (headline: 16384)")
     ap.add_argument("--env-id", default=ENV_ID)
     ap.add_argument("--sensor-range", type=int, default=0, help="override sensor_range (BASELINE config 5 uses 2)")
