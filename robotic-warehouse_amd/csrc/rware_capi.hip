@@ -115,6 +115,11 @@ const StaticEntry kStatic[] = {
     RW_STATIC(20, 10, 4, 4, 80, 1, 16, 256, 0),    // rware-small-4ag (headline)
     RW_STATIC(20, 16, 6, 3, 144, 1, 16, 256, 0),   // rware-medium-6ag-hard
     RW_STATIC(29, 16, 16, 16, 224, 2, 8, 256, 0),  // rware-large-16ag, sensor_range = 2
+    // the other tasks of the RWARE benchmark suite (Papoudakis et al. 2021: tiny/small, 2-4 agents, normal/hard)
+    RW_STATIC(11, 10, 4, 4, 32, 1, 16, 256, 0),    // rware-tiny-4ag
+    RW_STATIC(11, 10, 2, 1, 32, 1, 16, 256, 0),    // rware-tiny-2ag-hard
+    RW_STATIC(11, 10, 4, 2, 32, 1, 16, 256, 0),    // rware-tiny-4ag-hard
+    RW_STATIC(20, 10, 4, 2, 80, 1, 16, 256, 0),    // rware-small-4ag-hard
     // size-static builds (N == 0: any agent count / queue length): every other registered id, sensor_range 1
     RW_STATIC(11, 10, 0, 0, 32, 1, 16, 256, 0),    // rware-tiny-*
     RW_STATIC(20, 10, 0, 0, 80, 1, 16, 256, 0),    // rware-small-*

@@ -40,6 +40,11 @@ CASES = [
     # the default geometry picks the half-size-workgroup builds at these batch sizes; pin the E = 16 builds too
     ("rware-small-4ag-v1", {}, 2048, 260, (16, 256)),
     ("rware-medium-6ag-hard-v1", {}, 1024, 200, (16, 256)),
+    # further exact-shape builds (the tiny / small tasks of the RWARE benchmark suite)
+    ("rware-tiny-4ag-v1", {}, 1024, 200, (0, 0)),
+    ("rware-tiny-2ag-hard-v1", {}, 512, 200, (0, 0)),
+    ("rware-tiny-4ag-hard-v1", {}, 512, 200, (0, 0)),
+    ("rware-small-4ag-hard-v1", {}, 1024, 200, (0, 0)),
     ("rware-large-16ag-v1", {"sensor_range": 2}, 512, 200, (0, 0)),
     ("rware-small-19ag-v1", {"reward_type": 0, "max_inactivity_steps": 50}, 256, 200, (4, 128)),
     ("rware-tiny-4ag-easy-v1", {"reward_type": 2, "max_steps": 60}, 512, 200, (16, 256)),
