@@ -862,24 +862,37 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     for (int w = tid; w < nea * WIN; w += TW) {
         const int i = w / WIN, row = w - i * WIN;
         const int e = rw_div18(i, mN);
-        const int ax = s_ax[i], y = s_ay[i] + row - R;
+        const int ax = s_ax[i], ay = s_ay[i], y = ay + row - R;
         const bool row_ok = (unsigned)y < (unsigned)H;
-        const int rowbase = e * HW + y * W;
+        const int rowbase = e * HW + y * W, own = e * HW + ay * W + ax;
+        // Two LDS read batches, no read inside a branch (hipcc waits for each predicated read on its own, which
+        // costs a full LDS round trip per cell): out-of-map cells read the agent's own cell and are masked after.
         int ida[WIN], ids[WIN];
+        bool ok[WIN];
 #pragma unroll
         for (int k = 0; k < WIN; ++k) {
             const int x = ax + k - R;
-            const bool ok = row_ok && (unsigned)x < (unsigned)W;
-            ida[k] = ok ? (s_ga[rowbase + x] & 0x7f) : 0;
-            ids[k] = ok ? (int)s_gs[rowbase + x] : 0;
+            ok[k] = row_ok && (unsigned)x < (unsigned)W;
+            const int c = ok[k] ? rowbase + x : own;
+            ida[k] = s_ga[c] & 0x7f;
+            ids[k] = (int)s_gs[c];
+        }
+        int dirv[WIN];
+        uint32_t reqw[WIN];
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            ida[k] = ok[k] ? ida[k] : 0;
+            ids[k] = ok[k] ? ids[k] : 0;
+            dirv[k] = s_dir[e * N + (ida[k] ? ida[k] - 1 : 0)];
+            reqw[k] = s_req[e * SW + (ids[k] >> 5)];
         }
         uint64_t bits = 0;  // 7 * WIN <= 77 bits for R <= 5: R <= 4 fits 64; R == 5 handled by the split below
         uint32_t hi = 0;    // bits 64.. of the row (only R == 5)
 #pragma unroll
         for (int k = 0; k < WIN; ++k) {
-            uint32_t code = 2u;  // empty / off-map cell: has_agent 0, direction one-hot [1,0,0,0] (:659)
-            if (ida[k]) code = 1u | (2u << s_dir[e * N + ida[k] - 1]);
-            if (ids[k]) code |= 32u | (((s_req[e * SW + (ids[k] >> 5)] >> (ids[k] & 31)) & 1u) << 6);
+            // empty / off-map cell: has_agent 0, direction one-hot [1,0,0,0] (:659)
+            uint32_t code = ida[k] ? (1u | (2u << dirv[k])) : 2u;
+            code |= ids[k] ? (32u | (((reqw[k] >> (ids[k] & 31)) & 1u) << 6)) : 0u;
             if (7 * k < 64) bits |= (uint64_t)code << (7 * k);
             if (7 * k + 7 > 64) hi |= (7 * k >= 64) ? (code << (7 * k - 64)) : (code >> (64 - 7 * k));
         }
