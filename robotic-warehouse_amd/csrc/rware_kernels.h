@@ -594,9 +594,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 const int cell = p.goal_cells[gi];
                 const int sid = gS[cell];
                 if (!sid) continue;
-                int slot = -1;
-                for (int k = 0; k < Q; ++k)
-                    if (q[k] == sid) { slot = k; break; }
+                int slot = -1;  // first queue slot holding sid; all Q entries read in one LDS batch (no early exit)
+                for (int k = Q - 1; k >= 0; --k) slot = (q[k] == sid) ? k : slot;
                 if (slot < 0) continue;
                 delivered = true;
                 // candidates = shelves not in the queue, id order; one bounded draw (:915-916)
@@ -842,14 +841,18 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         for (int w = tid; w < nea * CELLS; w += TW) {
             const int i = w / CELLS, cidx = w - i * CELLS;
             const int e = rw_div18(i, mN);
-            const int x = s_ax[i] + cidx % WIN - R, y = s_ay[i] + cidx / WIN - R;
-            uint32_t code = 2u;  // empty / off-map: direction one-hot [1,0,0,0], message skipped (zeros)
-            if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
-                const int c = e * HW + y * W + x;
-                const int ida = s_ga[c] & 0x7f, ids = s_gs[c];
-                if (ida) code = 1u | (2u << s_dir[e * N + ida - 1]) | ((uint32_t)s_msg[e * N + ida - 1] << 5);
-                if (ids) code |= (1u << (5 + M)) | (((s_req[e * SW + (ids >> 5)] >> (ids & 31)) & 1u) << (6 + M));
-            }
+            const int ax = s_ax[i], ay = s_ay[i];
+            const int x = ax + cidx % WIN - R, y = ay + cidx / WIN - R;
+            // (two unconditional LDS read batches; an off-map cell reads the agent's own cell and is masked)
+            const bool ok = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
+            const int c = e * HW + (ok ? y * W + x : ay * W + ax);
+            const int ida = ok ? (s_ga[c] & 0x7f) : 0, ids = ok ? (int)s_gs[c] : 0;
+            const int j = e * N + (ida ? ida - 1 : 0);
+            const int dj = s_dir[j], mj = s_msg[j];
+            const uint32_t rq = s_req[e * SW + (ids >> 5)];
+            // empty / off-map: direction one-hot [1,0,0,0], message skipped (zeros)
+            uint32_t code = ida ? (1u | (2u << dj) | ((uint32_t)mj << 5)) : 2u;
+            code |= ids ? ((1u << (5 + M)) | (((rq >> (ids & 31)) & 1u) << (6 + M))) : 0u;
             const int bit = i * L + 8 + CW * cidx;
             const int wd = bit >> 5, sh = bit & 31;
             atomicOr(&s_obits[wd], code << sh);
@@ -928,6 +931,11 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             const int ax = s_ax[i], ay = s_ay[i], d = p.directional ? s_dir[i] : DIR_UP;
             uint32_t m_shelf = 0, m_req = 0, m_agent = 0, m_goal = 0, m_map = 0;
             uint32_t m_tagent = 0, m_tload = 0;  // the transposed layers: an agent / a loaded agent with (x, y) == (row, col)
+            // LDS reads in unconditional batches (an off-map cell reads the agent's own cell and is masked): a
+            // predicated read costs a full LDS round trip of its own
+            const int own = e * HW + ay * W + ax;
+            int cellv[WIN], gav[WIN], gsv[WIN], gtv[WIN];
+            bool okv[WIN];
 #pragma unroll
             for (int cc = 0; cc < WIN; ++cc) {
                 int wr = r, wc = cc;  // (r, cc) indexes the rotated image, (wr, wc) the north-up window
@@ -935,23 +943,29 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 else if (d == DIR_LEFT) { wr = WIN - 1 - cc; wc = r; }        // k = 3
                 else if (d == DIR_RIGHT) { wr = cc; wc = WIN - 1 - r; }       // k = 1
                 const int y = ay - R + wr, x = ax - R + wc;
-                if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {  // outside: np.pad zeros (:573)
-                    const int cell = y * W + x, c = e * HW + cell;
-                    const int ida = s_ga[c] & 0x7f, ids = s_gs[c];
-                    m_map |= 1u << cc;
-                    if (ida) m_agent |= 1u << cc;
-                    if (ids) {
-                        m_shelf |= 1u << cc;
-                        m_req |= ((s_req[e * SW + (ids >> 5)] >> (ids & 31)) & 1u) << cc;
-                    }
-                    for (int g = 0; g < p.n_goals; ++g)
-                        if (p.goal_cells[g] == cell) m_goal |= 1u << cc;
-                    if (p.transposed_layers && x < H && y < W) {  // layer[ag.x, ag.y]: the agent standing at (x', y') = (y, x)
-                        const int t = s_ga[e * HW + x * W + y];
-                        if (t & 0x7f) m_tagent |= 1u << cc;
-                        if (t & 0x80) m_tload |= 1u << cc;
-                    }
+                okv[cc] = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;  // outside: np.pad zeros (:573)
+                cellv[cc] = y * W + x;
+                const int c = okv[cc] ? e * HW + cellv[cc] : own;
+                gav[cc] = s_ga[c];
+                gsv[cc] = (int)s_gs[c];
+                gtv[cc] = 0;
+                if (p.transposed_layers) {  // layer[ag.x, ag.y]: the agent standing at (x', y') = (y, x)
+                    const bool tok = okv[cc] && x < H && y < W;
+                    gtv[cc] = tok ? (int)s_ga[tok ? e * HW + x * W + y : own] : 0;
                 }
+            }
+#pragma unroll
+            for (int cc = 0; cc < WIN; ++cc) {
+                const int ida = okv[cc] ? (gav[cc] & 0x7f) : 0, ids = okv[cc] ? gsv[cc] : 0;
+                const uint32_t rq = s_req[e * SW + (ids >> 5)];
+                m_map |= (okv[cc] ? 1u : 0u) << cc;
+                m_agent |= (ida ? 1u : 0u) << cc;
+                m_shelf |= (ids ? 1u : 0u) << cc;
+                m_req |= (ids ? ((rq >> (ids & 31)) & 1u) : 0u) << cc;
+                for (int g = 0; g < p.n_goals; ++g)
+                    if (okv[cc] && p.goal_cells[g] == cellv[cc]) m_goal |= 1u << cc;
+                m_tagent |= ((gtv[cc] & 0x7f) ? 1u : 0u) << cc;
+                m_tload |= ((gtv[cc] & 0x80) ? 1u : 0u) << cc;
             }
             for (int l = 0; l < p.n_layers; ++l) {
                 const int layer = p.layers[l];
