@@ -1022,11 +1022,21 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             const int dm = (4 * TW) % L;
             int m = (4 * tid + 3) % L;
             const int passes = (nf4 + TW - 1) / TW;  // a compile-time constant in the specialised builds (full unroll)
-            for (int k = 0; k < passes; ++k) {
-                const int q4 = tid + k * TW;
-                if (q4 < nf4 && m >= 5) store4((uint32_t)q4 << 4, spread((wp[k * words_per_pass] >> shift) & 0xFu));
-                m += dm;
-                m = (m >= L) ? m - L : m;
+            // in groups of 8 passes: first the 8 LDS words in one unconditional batch (a read past the string still
+            // lands inside the workgroup's LDS), then the 8 predicated expansions — a read inside the predicate
+            // would cost one LDS round trip per pass
+            for (int k0 = 0; k0 < passes; k0 += 8) {
+                uint32_t wv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wv[j] = (k0 + j < passes) ? wp[(k0 + j) * words_per_pass] : 0u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (k0 + j >= passes) break;
+                    const int q4 = tid + (k0 + j) * TW;
+                    if (q4 < nf4 && m >= 5) store4((uint32_t)q4 << 4, spread((wv[j] >> shift) & 0xFu));
+                    m += dm;
+                    m = (m >= L) ? m - L : m;
+                }
             }
         }
         // coordinate pass: per agent, the one or two float4s that hold its x (element i*L) and y (i*L + 1)
