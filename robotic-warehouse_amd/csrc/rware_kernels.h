@@ -480,7 +480,6 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         wave_sync();
         // ------------------------------------------------------------ P1: intent (:825-846)
         int tg = st, nxt = -2, shelf_here = 0, tx = x, ty = y;
-        bool hw_st = false;
         if (stepping) {
             if ((unsigned)a > 4u) {  // Action(a) raises in the reference (:814); flagged, runs as NOOP
                 atomicOr(p.status, STATUS_INVALID_ACTION);
@@ -495,7 +494,6 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             tg = ty * W + tx;
             const int sh_tg = gS[tg], ag_tg = gA[tg];
             shelf_here = gS[st];
-            hw_st = on_highway(st);  // (needed by the unload rule in P3; read here, with the rest of the batch)
             // a standing shelf blocks a loaded agent (:836-846)
             const bool blocked = (carry != 0) & (tg != st) & (sh_tg != 0) & ((ag_tg & 0x80) == 0);
             a = blocked ? (int)ACT_NOOP : a;
@@ -574,7 +572,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             d = (a == ACT_RIGHT) ? right : ((a == ACT_LEFT) ? left : d);
             // TOGGLE_LOAD (:886-899): pick up the shelf under the agent, or put the carried one down off the highways
             const bool toggle = (a == ACT_TOGGLE);
-            const bool drop = toggle & (carry != 0) & !hw_st;
+            const bool drop = toggle & (carry != 0) & !on_highway(st);
             const bool pick = toggle & (carry == 0) & (shelf_here != 0);
             rew = (drop & (deliv != 0) & (p.reward_type == REW_TWO_STAGE)) ? 0.5f : 0.0f;
             deliv = drop ? 0 : deliv;
@@ -592,11 +590,9 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         if (stepping && a_idx == 0) {
             int32_t *q = s_queue + e * Q;
             bool delivered = false;
-            // (the shelf ids under the first two goals are read as one LDS batch; nothing below moves a shelf)
-            const int sid_g0 = gS[p.goal_cells[0]], sid_g1 = gS[p.goal_cells[p.n_goals > 1 ? 1 : 0]];
             for (int gi = 0; gi < p.n_goals; ++gi) {  // in list order (:904)
                 const int cell = p.goal_cells[gi];
-                const int sid = gi == 0 ? sid_g0 : gi == 1 ? sid_g1 : (int)gS[cell];
+                const int sid = gS[cell];
                 if (!sid) continue;
                 int slot = -1;  // first queue slot holding sid; all Q entries read in one LDS batch (no early exit)
                 for (int k = Q - 1; k >= 0; --k) slot = (q[k] == sid) ? k : slot;
