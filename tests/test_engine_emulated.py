@@ -205,6 +205,29 @@ def test_wide_sensor_ranges(sensor_range):
     env.close()
 
 
+@pytest.mark.parametrize("n_agents", [40, 64])
+def test_many_agents_one_env_per_wavefront(n_agents):
+    """N > 32: one env per wavefront in the agent phases (64 / N == 1), agent ids up to the 7-bit limit of the
+    LDS agent layer, crowded enough that chains and cycles happen every step."""
+    kw = rware_amd.env_kwargs("rware-medium-19ag-v1")
+    kw.update(n_agents=n_agents, request_queue_size=n_agents, max_steps=25)
+    kw["reward_type"] = kw["reward_type"].value
+    B = 5
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, **kw)
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=3)[0], orc.reset(seed=3))
+    rng = np.random.default_rng(8)
+    for t in range(60):
+        a = rng.choice(5, size=(B, n_agents), p=[.05, .65, .1, .1, .1])
+        o, r, d, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(o, o2) and np.array_equal(r, r2) and np.array_equal(d, d2.astype(bool)), t
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    env.close()
+
+
 def test_wide_shelf_ids_use_the_uint16_shadow():
     """More than 255 shelves (the reference's __main__ smoke layout, 29x28): shelf shadow is uint16."""
     kw = dict(shelf_columns=9, column_height=8, shelf_rows=3, n_agents=10, sensor_range=1, request_queue_size=5,

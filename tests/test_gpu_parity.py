@@ -45,6 +45,8 @@ CASES = [
     ("rware-tiny-2ag-hard-v1", {}, 512, 200, (0, 0)),
     ("rware-tiny-4ag-hard-v1", {}, 512, 200, (0, 0)),
     ("rware-small-4ag-hard-v1", {}, 1024, 200, (0, 0)),
+    # N > 32: one env per wavefront in the agent phases, 7-bit agent ids, crowded (chains and cycles every step)
+    ("rware-medium-19ag-v1", {"n_agents": 64, "request_queue_size": 64, "max_steps": 70}, 256, 160, (0, 0)),
     ("rware-large-16ag-v1", {"sensor_range": 2}, 512, 200, (0, 0)),
     ("rware-small-19ag-v1", {"reward_type": 0, "max_inactivity_steps": 50}, 256, 200, (4, 128)),
     ("rware-tiny-4ag-easy-v1", {"reward_type": 2, "max_steps": 60}, 512, 200, (16, 256)),
