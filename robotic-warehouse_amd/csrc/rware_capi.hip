@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/rware_hip.h"
+#include "rware_kernel_table.h"
 #include "rware_kernels.h"
 
 namespace {
@@ -79,22 +80,7 @@ int fail(rw_engine *eng, int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
-using step_kernel_t = void (*)(const rw::Params *, const int32_t *, const int32_t, const int32_t, float *, float *, uint8_t *, const uint8_t *, uint64_t *, const int64_t, const int64_t, const int64_t, const int64_t);
-
-template <int R, bool kRollout>
-step_kernel_t generic_kernel(bool wide, bool image, bool msg) {
-    if (msg && image)
-        return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg, kRollout, rw::OBS_IMAGE_MSG>
-                    : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg, kRollout, rw::OBS_IMAGE_MSG>;
-    if (msg)
-        return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg, kRollout, rw::OBS_FLATTENED_MSG>
-                    : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg, kRollout, rw::OBS_FLATTENED_MSG>;
-    if (image)
-        return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg, kRollout, rw::OBS_IMAGE>
-                    : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg, kRollout, rw::OBS_IMAGE>;
-    return wide ? (step_kernel_t)rw::rware_step_kernel<R, uint16_t, rw::DynamicCfg, kRollout>
-                : (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::DynamicCfg, kRollout>;
-}
+using rw_tab::step_kernel_t;
 
 // Specialised builds for the BASELINE.json tasks at their default launch geometry:
 //   {H, W, N, Q, S, R}  ->  kernel with those shapes (and E, T) folded in at compile time.
@@ -330,12 +316,13 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             return bail(RW_ERR_INVALID_ARG);
         }
     }
-    switch (R) {
-        case 1: eng->kernel = generic_kernel<1, false>(eng->wide, eng->image, eng->msg_bits > 0); eng->kernel_rollout = generic_kernel<1, true>(eng->wide, eng->image, eng->msg_bits > 0); break;
-        case 2: eng->kernel = generic_kernel<2, false>(eng->wide, eng->image, eng->msg_bits > 0); eng->kernel_rollout = generic_kernel<2, true>(eng->wide, eng->image, eng->msg_bits > 0); break;
-        case 3: eng->kernel = generic_kernel<3, false>(eng->wide, eng->image, eng->msg_bits > 0); eng->kernel_rollout = generic_kernel<3, true>(eng->wide, eng->image, eng->msg_bits > 0); break;
-        case 4: eng->kernel = generic_kernel<4, false>(eng->wide, eng->image, eng->msg_bits > 0); eng->kernel_rollout = generic_kernel<4, true>(eng->wide, eng->image, eng->msg_bits > 0); break;
-        default: eng->kernel = generic_kernel<5, false>(eng->wide, eng->image, eng->msg_bits > 0); eng->kernel_rollout = generic_kernel<5, true>(eng->wide, eng->image, eng->msg_bits > 0); break;
+    {   // the generic build for this sensor range (rware_generic.hip); an exact-shape build may replace it below
+        using pick_t = step_kernel_t (*)(bool, bool, bool, bool);
+        static const pick_t kGeneric[5] = {rw_tab::generic_r1, rw_tab::generic_r2, rw_tab::generic_r3, rw_tab::generic_r4,
+                                           rw_tab::generic_r5};
+        const pick_t pick = kGeneric[(R < 1 ? 1 : R > 5 ? 5 : R) - 1];
+        eng->kernel = pick(false, eng->wide, eng->image, eng->msg_bits > 0);
+        eng->kernel_rollout = pick(true, eng->wide, eng->image, eng->msg_bits > 0);
     }
     if (!eng->image && eng->msg_bits == 0) {  // (the image / message kernels are generic builds)
         // Pick a specialised build: exact-shape entries before size-static ones, first match wins.

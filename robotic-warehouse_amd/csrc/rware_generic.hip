@@ -1,0 +1,34 @@
+// rware_generic.hip — instantiates the generic (DynamicCfg) step kernels of ONE sensor range, RW_GENERIC_R.
+// Compiled five times (see the Makefile); the exact-shape builds live in rware_capi.hip.
+#include <hip/hip_runtime.h>
+
+#include "rware_kernel_table.h"
+
+#ifndef RW_GENERIC_R
+#error "compile with -DRW_GENERIC_R=1..5"
+#endif
+#define RW_CAT2(a, b) a##b
+#define RW_CAT(a, b) RW_CAT2(a, b)
+
+namespace rw_tab {
+namespace {
+
+template <bool kRollout, typename CellT>
+step_kernel_t pick(bool image, bool msg) {
+    constexpr int R = RW_GENERIC_R;
+    if (msg && image) return (step_kernel_t)rw::rware_step_kernel<R, CellT, rw::DynamicCfg, kRollout, rw::OBS_IMAGE_MSG>;
+    if (msg) return (step_kernel_t)rw::rware_step_kernel<R, CellT, rw::DynamicCfg, kRollout, rw::OBS_FLATTENED_MSG>;
+    if (image) return (step_kernel_t)rw::rware_step_kernel<R, CellT, rw::DynamicCfg, kRollout, rw::OBS_IMAGE>;
+    return (step_kernel_t)rw::rware_step_kernel<R, CellT, rw::DynamicCfg, kRollout>;
+}
+
+}  // namespace
+
+step_kernel_t RW_CAT(generic_r, RW_GENERIC_R)(bool rollout, bool wide, bool image, bool msg) {
+    if (rollout) return wide ? pick<true, uint16_t>(image, msg) : pick<true, uint8_t>(image, msg);
+    return wide ? pick<false, uint16_t>(image, msg) : pick<false, uint8_t>(image, msg);
+}
+
+}  // namespace rw_tab
+#undef RW_CAT
+#undef RW_CAT2

@@ -134,6 +134,9 @@ struct LaunchArgs {
         float *la_rewards, uint8_t *la_terminated, const uint8_t *la_reset_mask, uint64_t *la_timeline,    \
         const int64_t la_act_stride, const int64_t la_obs_stride, const int64_t la_rew_stride,             \
         const int64_t la_term_stride
+#define RW_LAUNCH_PARAMS_TYPES                                                                              \
+    const rw::Params *, const int32_t *, const int32_t, const int32_t, float *, float *, uint8_t *, const uint8_t *,  \
+        uint64_t *, const int64_t, const int64_t, const int64_t, const int64_t
 #define RW_LAUNCH_ARGS(la)                                                                                  \
     (la).actions, (la).op, (la).n_steps, (la).obs, (la).rewards, (la).terminated, (la).reset_mask,         \
         (la).timeline, (la).act_stride, (la).obs_stride, (la).rew_stride, (la).term_stride

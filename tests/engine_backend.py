@@ -13,7 +13,7 @@ EMU_LIB = os.path.join(EMU_DIR, "librware_emu.so")
 
 
 def build_emu() -> str:
-    subprocess.check_call(["make", "-s", "-C", EMU_DIR], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-s", "-j8", "-C", EMU_DIR], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return EMU_LIB
 
 
