@@ -5,7 +5,7 @@
 #include "rware_kernel_table.h"
 
 #ifndef RW_GENERIC_R
-#error "compile with -DRW_GENERIC_R=1..5"
+#define RW_GENERIC_R 1  // a plain `hipcc -c rware_generic.hip` builds the sensor_range 1 object
 #endif
 #define RW_CAT2(a, b) a##b
 #define RW_CAT(a, b) RW_CAT2(a, b)
