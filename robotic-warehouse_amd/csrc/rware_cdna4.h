@@ -30,6 +30,13 @@ __device__ __forceinline__ uint32_t hw_id() { return __builtin_amdgcn_s_getreg((
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20); }
 // wave_any(v): true in every lane iff v holds in some active lane of the wavefront (one s_cmp on the ballot)
 __device__ __forceinline__ bool wave_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0; }
+// keep_sgpr(a, b, ...): the (wave-uniform) values must sit in scalar registers at this point — pins where
+// their loads have to have been issued and waited for
+__device__ __forceinline__ void keep_sgpr1(int v) { asm volatile("" ::"s"(v)); }
+template <typename... Ts>
+__device__ __forceinline__ void keep_sgpr(Ts... v) {
+    (keep_sgpr1((int)v), ...);
+}
 // opaque(x): the value, with everything the optimiser knew about its bits forgotten
 __device__ __forceinline__ uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
 // uniform(x): tells the compiler a value is wave-uniform (v_readfirstlane), so tests on it become scalar branches

@@ -324,6 +324,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     };
     clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
     RW_MARK(TL_ZEROED);
+    // The per-config scalars the agent phases need (P3, P5) are fetched HERE, so their latency hides under the
+    // stage-in; hipcc would otherwise issue each s_load where it is first used — in the middle of the agent
+    // phases, which run on one wavefront and cannot hide it.  keep_sgpr() pins the values before the barrier.
+    const int k_reward_type = p.reward_type, k_max_inactivity = p.max_inactivity, k_max_steps = p.max_steps;
+    const int k_autoreset = p.autoreset, k_n_goals = p.n_goals;
+    const int k_goal0 = p.goal_cells[0], k_goal1 = p.goal_cells[1];
     const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : p.need_reset;  // OP_RESET: all-ones when no mask was given
     if constexpr (Cfg::kE != 0) {
         // Static build: every DMA destination is contiguous in LDS and every source chunk is a whole
@@ -409,6 +415,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         RW_MARK(TL_ENV_LOADED);
         __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
     }
+    keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1);
     RW_MARK(TL_LOADED);
 
     // kRollout == false is the single-step kernel (rw_step / rw_reset / rw_refresh_obs): no loop at all.
@@ -437,7 +444,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         lds_barrier();
         for (int e = tid; e < ne; e += T) {
             int32_t *ev = s_envi + e * ENVI_W;
-            const int rs = (p.autoreset == AR_NEXT_STEP) ? ev[ENVI_DONE] : 0;
+            const int rs = (k_autoreset == AR_NEXT_STEP) ? ev[ENVI_DONE] : 0;
             ev[ENVI_RESET] = rs;
             ev[ENVI_SKIP] = rs;
             ev[ENVI_DONE] = 0;
@@ -577,7 +584,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             const bool toggle = (a == ACT_TOGGLE);
             const bool drop = toggle & (carry != 0) & !on_highway(st);
             const bool pick = toggle & (carry == 0) & (shelf_here != 0);
-            rew = (drop & (deliv != 0) & (p.reward_type == REW_TWO_STAGE)) ? 0.5f : 0.0f;
+            rew = (drop & (deliv != 0) & (k_reward_type == REW_TWO_STAGE)) ? 0.5f : 0.0f;
             deliv = drop ? 0 : deliv;
             carry = drop ? 0 : (pick ? shelf_here : carry);
             s_ax[i] = x; s_ay[i] = y; s_dir[i] = d; s_carry[i] = carry; s_deliv[i] = deliv;
@@ -593,8 +600,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         if (stepping && a_idx == 0) {
             int32_t *q = s_queue + e * Q;
             bool delivered = false;
-            for (int gi = 0; gi < p.n_goals; ++gi) {  // in list order (:904)
-                const int cell = p.goal_cells[gi];
+            for (int gi = 0; gi < k_n_goals; ++gi) {  // in list order (:904)
+                const int cell = gi == 0 ? k_goal0 : gi == 1 ? k_goal1 : p.goal_cells[gi];
                 const int sid = gS[cell];
                 if (!sid) continue;
                 int slot = -1;  // first queue slot holding sid; all Q entries read in one LDS batch (no early exit)
@@ -615,12 +622,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     cand = nc;
                 }
                 q[slot] = cand;
-                if (p.reward_type == REW_GLOBAL) {
+                if (k_reward_type == REW_GLOBAL) {
                     for (int k = 0; k < N; ++k) s_rew[base + k] += 1.0f;
                 } else {
                     const int aid = gA[cell] & 0x7f;
                     const int ai = aid > 0 ? aid - 1 : N - 1;  // rewards[-1] when nobody stands there
-                    if (p.reward_type == REW_INDIVIDUAL) {
+                    if (k_reward_type == REW_INDIVIDUAL) {
                         s_rew[base + ai] += 1.0f;
                     } else {
                         s_deliv[base + ai] = 1;
@@ -630,10 +637,10 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             }
             ev[ENVI_INACTIVE] = delivered ? 0 : ev[ENVI_INACTIVE] + 1;
             ev[ENVI_STEPS] += 1;
-            const int done = ((p.max_inactivity && ev[ENVI_INACTIVE] >= p.max_inactivity) ||
-                              (p.max_steps && ev[ENVI_STEPS] >= p.max_steps)) ? 1 : 0;
+            const int done = ((k_max_inactivity && ev[ENVI_INACTIVE] >= k_max_inactivity) ||
+                              (k_max_steps && ev[ENVI_STEPS] >= k_max_steps)) ? 1 : 0;
             ev[ENVI_DONE] = done;
-            if (done && p.autoreset == AR_SAME_STEP) {
+            if (done && k_autoreset == AR_SAME_STEP) {
                 ev[ENVI_RESET] = 1;
                 s_misc[0] = 1;
             }

@@ -23,6 +23,7 @@ inline bool wave_any(bool v) {  // every thread of the wave calls this (wave-uni
     pthread_barrier_wait(emu_wave_barrier);
     return r;
 }
+template <typename... Ts> inline void keep_sgpr(const Ts &...) {}
 inline uint32_t opaque(uint32_t x) { return x; }
 inline int uniform(int x) { return x; }
 inline void lds_barrier() { pthread_barrier_wait(emu_barrier); }
