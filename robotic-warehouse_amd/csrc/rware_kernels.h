@@ -744,7 +744,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     RW_MARK(TL_RESET);
 
     // ---------------------------------------------------------------- WB: state write-back, one role per wavefront
-    // (envs flagged for reset were written by RS).  Where it runs is a measured choice:
+    // (envs flagged for reset were written by RS).  Where it runs is a measured choice.  Without the split below
+    // (fewer than 4 wavefronts, or a large observation chunk), one role per wavefront:
     //   single step    before the observation: its small stores then drain underneath P7; issued after the
     //                  18 MB observation stream they queue behind it and hold every wavefront ~0.8 us longer
     //   fused rollout  after the observation stores: the next step's compute hides them, and the stream
