@@ -386,3 +386,27 @@ class WarehouseVecEnv(_VectorEnvBase):
 
     def close_extras(self, **kwargs):
         self.close()
+
+    # ------------------------------------------------------------------------------- VectorEnv conveniences
+    @property
+    def unwrapped(self):
+        return self
+
+    def get_attr(self, name):
+        """Gymnasium VectorEnv.get_attr: the attribute of every sub-env — all envs share one configuration."""
+        v = getattr(self, name)
+        return tuple(v for _ in range(self.num_envs))
+
+    def call(self, name, *args, **kwargs):
+        """Gymnasium VectorEnv.call: method (or attribute) `name` evaluated once, returned per sub-env."""
+        v = getattr(self, name)
+        r = v(*args, **kwargs) if callable(v) else v
+        return tuple(r for _ in range(self.num_envs))
+
+    def set_attr(self, name, values):
+        raise NotImplementedError("the batched envs share one compiled configuration; construct a new WarehouseVecEnv instead")
+
+    def render(self):
+        """The reference renders with pyglet (rware/rendering.py) — outside the accelerated path.  get_state() has
+        everything a renderer needs (grid, agents, queue)."""
+        raise NotImplementedError("rendering is outside the accelerated step path; use get_state() with the reference renderer")

@@ -105,6 +105,9 @@ def test_host_layer_errors_and_views():
     o, r, term, trunc, info = env.step([[rware_amd.Action.FORWARD, rware_amd.Action.NOOP]] * 4)
     assert r.shape == (4, 2) and term.dtype == bool and not trunc.any() and info == {}
     assert env.shelf_xy().shape == (4, env.n_shelves, 2)
+    assert env.unwrapped is env and env.get_attr("n_agents") == (2, 2, 2, 2) and len(env.call("shelf_xy")) == 4
+    with pytest.raises(NotImplementedError):
+        env.render()
     ienv = rware_amd.WarehouseVecEnv(2, library=LIB, observation_type=rware_amd.ObservationType.IMAGE, **dict(kw, msg_bits=1))
     io, _ = ienv.reset(seed=0)                        # communication bits with image observations: actions (B, N, 2)
     assert io.shape == (2, 2, 5, 3, 3) and ienv.step(np.zeros((2, 2, 2), int))[0].shape == io.shape
