@@ -69,6 +69,15 @@ CASES = [
     ("img-msg2-tiny-3ag-8layers", "rware-tiny-3ag-v2",
      {"observation_type": 2, "msg_bits": 2, "sensor_range": 2, "max_steps": 80,
       "image_observation_layers": [0, 1, 2, 5, 6, 0, 2, 6]}, 2, 180, 17000),
+    # widest window (11 x 11, 77 bits per row), many agents, a non-default column height, TWO_STAGE rewards
+    ("sr5-12ag-colheight5-twostage", None,
+     {"shelf_columns": 5, "column_height": 5, "shelf_rows": 2, "n_agents": 12, "msg_bits": 0, "sensor_range": 5,
+      "request_queue_size": 6, "max_inactivity_steps": None, "max_steps": 150, "reward_type": 2}, 2, 320, 18000),
+    # every image layer type at once (square grid: the transposed layers stay in bounds), communication bit on top
+    ("img-square-all7-msg1", None,
+     {"shelf_columns": 3, "column_height": 3, "shelf_rows": 2, "n_agents": 4, "msg_bits": 1, "sensor_range": 1,
+      "request_queue_size": 2, "max_inactivity_steps": 40, "max_steps": 100, "reward_type": 0,
+      "observation_type": 2, "image_observation_layers": [0, 1, 2, 3, 4, 5, 6]}, 3, 240, 19000),
     ("imgdict-square-5ag-transposed-northup", None,
      {"shelf_columns": 3, "column_height": 3, "shelf_rows": 2, "n_agents": 5, "msg_bits": 0, "sensor_range": 1,
       "request_queue_size": 3, "max_inactivity_steps": None, "max_steps": 90, "reward_type": 2,

@@ -29,6 +29,11 @@ pytestmark = pytest.mark.timeout(600)
     ("imgdict-medium-6ag-hard", (8, 128)),
     ("msg2-small-4ag", (0, 0)),
     ("msg3-tiny-3ag-sr2", (4, 64)),
+    ("img-square-5ag-transposed-layers", (0, 0)),
+    ("imgdict-square-5ag-transposed-northup", (4, 128)),
+    ("img-msg2-tiny-3ag-8layers", (0, 0)),
+    ("sr5-12ag-colheight5-twostage", (0, 0)),
+    ("img-square-all7-msg1", (4, 64)),
 ])
 def test_emulated_engine_matches_reference_golden(name, geom):
     meta, z = gu.load_fixture(name)
