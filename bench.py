@@ -1,23 +1,32 @@
 #!/usr/bin/env python
 """Headline benchmark: agent-steps/s of the HIP step engine on rware-small-4ag, batch 16384 per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1: spawns one process per GPU itself
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # or under a launcher
 
 One "step" = one pass of the hot path (Warehouse.step + FLATTENED obs, rware/warehouse.py:804-946)
 over the whole env batch resident in HBM: one `rw_step_device` call, actions read from a
-device-resident tape, NEXT_STEP autoreset on (all envs reset on-device every 500 steps, inside
-the timed region).  Multi-GPU: one process per GPU, each with its own 16384-env shard (weak
-scaling), seeds offset by the global env index, NO data-path collective (envs are independent;
-SURVEY.md §8(e)); torch.distributed is used only for the barrier and the MAX over ranks.
+device-resident tape, NEXT_STEP autoreset on (all envs reset on-device every 500 steps).
+Multi-GPU: one process per GPU, each with its own 16384-env shard (weak scaling), seeds offset by
+the global env index, NO data-path collective and NO RCCL (envs are independent);
+the only communication is a barrier and a MAX over ranks of the timings, on CPU tensors over gloo.
 
-The printed JSON line carries `roofline` (algorithmic bytes per launch / HIP-event time per launch
-on the engine's stream vs 8 TB/s HBM) and, at N=1, `cpu_baseline` (the C oracle — a port of the
-reference step — timed on one host core over a bounded sample of the same workload).
+The printed JSON line carries
+  value / ms_per_step   exactly K steps after W warm-up steps, barrier + device sync on both sides
+  sustained             the same launches for a fixed 2000 steps after 100 warm-up steps (SURVEY.md §8(d) protocol,
+                        spans 4 mass resets) — the steady state, whatever K and W the caller chose
+  roofline              algorithmic bytes per launch / HIP-event time per launch on the engine's stream, vs the 8 TB/s
+                        HBM peak and the 6.29 TB/s measured copy ceiling; `traffic` = physical bytes per launch from
+                        the rocprofv3 PMC passes (profiles/pmc_traffic.json, tied to the kernel sources by hash)
+  cpu_baseline (N = 1)  the reference's pure-Python step on the host cores when /root/reference exists, else the C port
+                        of it, 1 process and one per core, with the core count and CPU model
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,42 +34,47 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 ENV_ID = "rware-small-4ag-v1"
 BATCH_PER_GPU = 16384
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_MEASURED_GBPS = 6290.0   # same guide: measured float4 copy ceiling
 TAPE_STEPS = int(os.environ.get("RWARE_BENCH_TAPE_STEPS", "256"))
+SUSTAINED_STEPS, SUSTAINED_WARMUP = 2000, 100
+KERNEL_SOURCES = ("rware_kernels.h", "rware_cdna4.h", "rware_pcg64.h", "rware_capi.hip")
 
 
-def cpu_baseline(seconds: float = 12.0):
-    """Oracle (C port of the reference step + obs) on ONE host core, bounded sample."""
-    import rware_amd
-    from rware_oracle import OracleVecEnv
+def kernel_sources_sha() -> str:
+    """Identifies the kernel a PMC traffic figure was measured on (profiles/pmc_traffic.json carries the same hash)."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "robotic-warehouse_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
-    kw = rware_amd.env_kwargs(ENV_ID)
-    kw["reward_type"] = kw["reward_type"].value
-    b = 512
-    env = OracleVecEnv(b, **kw)
-    env.reset(seed=0)
-    rng = np.random.default_rng(12345)
-    acts = rng.integers(0, 5, size=(64, b, kw["n_agents"]), dtype=np.int32)
-    for t in range(8):
-        env.step_autoreset(acts[t % 64], "next_step")
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        for t in range(16):
-            env.step_autoreset(acts[(n + t) % 64], "next_step")
-        n += 16
-    dt = time.perf_counter() - t0
-    return {
-        "value": b * kw["n_agents"] * n / dt,
-        "unit": "agent-steps/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{ENV_ID}, {b} envs x {n} steps (~{dt:.0f} s), uniform random actions, step+obs, next_step autoreset, "
-                  "oracle/rware_oracle.c single thread",
-    }
+
+def cpu_baseline(env_id: str):
+    """CPU legs in a fresh interpreter (it forks workers; this process holds an initialised HIP runtime)."""
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), env_id]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        return {"error": out.stderr[-500:]}
+    return json.loads(out.stdout)
+
+
+def spawn_ranks(n: int):
+    """`python bench.py --gpus N` without a launcher: this process becomes rank 0 and starts ranks 1..N-1."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    children = []
+    for r in range(1, n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.DEVNULL))
+    os.environ.update(base, RANK="0", LOCAL_RANK="0")
+    return children
 
 
 def main():
@@ -72,6 +86,7 @@ def main():
     ap.add_argument("--env-id", default=ENV_ID)
     ap.add_argument("--sensor-range", type=int, default=0, help="override sensor_range (BASELINE config 5 uses 2)")
     ap.add_argument("--observation-type", type=int, default=1, help="1 FLATTENED (headline), 2 IMAGE, 3 IMAGE_DICT")
+    ap.add_argument("--msg-bits", type=int, default=0)
     ap.add_argument("--envs-per-wg", type=int, default=0)
     ap.add_argument("--threads-per-wg", type=int, default=0)
     ap.add_argument("--many", type=int, default=0,
@@ -79,122 +94,139 @@ def main():
                          "env chunk resident in LDS across the steps; open-loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-rollout measurement (profiling runs)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the fixed 2000-step sustained leg (profiling runs)")
     args = ap.parse_args()
 
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver stack (RCCL across processes)
-    import torch
-
-    import rware_amd
-
+    children = []
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        children = spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
+    import rware_amd
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    # Test hooks (tests/test_gpu_parity.py runs the N > 1 path on a 1-GPU box): RWARE_BENCH_BACKEND=gloo replaces
-    # RCCL for the barrier / MAX-over-ranks, RWARE_BENCH_SHARE_GPU=1 lets several ranks share one device.
-    backend = os.environ.get("RWARE_BENCH_BACKEND", "nccl")
-    if os.environ.get("RWARE_BENCH_SHARE_GPU") == "1":
-        local_rank %= torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if os.environ.get("RWARE_BENCH_SHARE_GPU") == "1":  # test hook: several ranks on one device (1-GPU test box)
+        local_rank %= n_dev
+    elif local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: --gpus {args.gpus} but only {n_dev} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
+        # barrier + MAX of three floats: CPU tensors over gloo — the data path has no collective, so no RCCL at all
+        import datetime
+
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
 
     kw = rware_amd.env_kwargs(args.env_id)
     if args.sensor_range:
         kw["sensor_range"] = args.sensor_range
     if args.observation_type != 1:
         kw["observation_type"] = args.observation_type
-    B, N = args.batch, kw["n_agents"]
+    if args.msg_bits:
+        kw["msg_bits"] = args.msg_bits
+    B, N, AM = args.batch, kw["n_agents"], 1 + args.msg_bits
     env = rware_amd.WarehouseVecEnv(B, devices=[local_rank], envs_per_workgroup=args.envs_per_wg,
                                     threads_per_workgroup=args.threads_per_wg, **kw)
     eng = env.engines[0]
     info = eng.info
     # env i of rank r is global env r*B + i -> SeedSequence(r*B + i): results independent of the GPU count
-    eng.reset(seeds=np.arange(rank * B, (rank + 1) * B, dtype=np.uint64))
-    tape = torch.from_numpy(
-        np.random.default_rng(12345 + rank).integers(0, 5, size=(TAPE_STEPS, B, N), dtype=np.int32)
-    ).to(f"cuda:{local_rank}")
-    base, stride = tape.data_ptr(), B * N * 4
+    eng.reset(seeds=rware_amd.shard_seeds(rank, B))
+    acts = np.random.default_rng(12345 + rank).integers(0, 5, size=(TAPE_STEPS, B, N, AM), dtype=np.int32)
+    if AM > 1:
+        acts[..., 1:] &= 1  # message bits
+    tape = torch.from_numpy(acts).to(f"cuda:{local_rank}")
+    base, stride = tape.data_ptr(), B * N * AM * 4
 
-    def run(n, t_start):
-        if args.many > 0:
+    def run(n, t_start, many=args.many):
+        if many > 0:
             t = t_start
             while t < t_start + n:
-                c = min(args.many, t_start + n - t, TAPE_STEPS - (t % TAPE_STEPS))
+                c = min(many, t_start + n - t, TAPE_STEPS - (t % TAPE_STEPS))
                 eng.step_many_device(base + (t % TAPE_STEPS) * stride, c)
                 t += c
         else:
             for t in range(t_start, t_start + n):
                 eng.step_device(base + (t % TAPE_STEPS) * stride)
 
-    def barrier():
+    def fence():  # barrier + device sync, both sides of every timed region
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+        torch.cuda.synchronize()
 
-    run(args.warmup, 0)
-    eng.sync()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.event_record(0)
-    run(args.steps, args.warmup)
-    eng.event_record(1)
-    eng.sync()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = eng.event_elapsed_ms(0, 1) / max(args.steps, 1)  # avg per launch on the engine's stream
+    def timed(n, t_start, many=args.many):
+        fence()
+        t0 = time.perf_counter()
+        eng.event_record(0)
+        run(n, t_start, many)
+        eng.event_record(1)
+        fence()
+        dt = time.perf_counter() - t0
+        return dt, eng.event_elapsed_ms(0, 1) / max(n, 1)  # wall seconds; HIP-event ms per step on the engine's stream
+
+    t_next = 0
+    run(args.warmup, t_next)
+    t_next += args.warmup
+    elapsed, kernel_ms = timed(args.steps, t_next)
+    t_next += args.steps
+    eng.sync()  # surfaces a sticky device-side error (invalid action) outside the timed region
+
+    sus = None
+    if not args.no_sustained:
+        run(SUSTAINED_WARMUP, t_next)
+        t_next += SUSTAINED_WARMUP
+        sus = timed(SUSTAINED_STEPS, t_next)
+        t_next += SUSTAINED_STEPS
 
     # Extra (reported beside the headline, never as `value`): the same K steps through the fused rollout
     # API, rw_step_many_device — one launch per 64 steps, env chunk resident in LDS (open-loop).
-    fused_elapsed = None
+    fused = None
     if not args.many and not args.no_fused_extra:
-        chunk = 64
-        def run_fused(n, t_start):
-            t = t_start
-            while t < t_start + n:
-                c = min(chunk, t_start + n - t, TAPE_STEPS - (t % TAPE_STEPS))
-                eng.step_many_device(base + (t % TAPE_STEPS) * stride, c)
-                t += c
-        run_fused(min(args.warmup, 64), 0)
-        eng.sync()
-        torch.cuda.synchronize()
-        barrier()
-        tf = time.perf_counter()
-        run_fused(args.steps, args.warmup)
-        eng.sync()
-        torch.cuda.synchronize()
-        barrier()
-        fused_elapsed = time.perf_counter() - tf
+        run(64, t_next, many=64)
+        t_next += 64
+        fused = timed(args.steps, t_next, many=64)
+    eng.sync()
 
+    vals = [elapsed, kernel_ms, sus[0] if sus else 0.0, sus[1] if sus else 0.0, fused[0] if fused else 0.0]
     if dist is not None:
-        tt = torch.tensor([elapsed, kernel_ms, fused_elapsed or 0.0], dtype=torch.float64,
-                          device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        tt = torch.tensor(vals, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(tt[0]), float(tt[1])
-        fused_elapsed = float(tt[2]) or None
+        vals = [float(v) for v in tt]
+    elapsed, kernel_ms, sus_s, sus_kernel_ms, fused_s = vals
 
     if rank == 0:
         a_bytes = int(info.algorithmic_bytes_per_env_step)
         per_launch = a_bytes * B
-        achieved = per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from the rocprofv3 --pmc passes
+        k_ms = kernel_ms  # HIP-event time per step (== per launch unless --many fuses several steps into one launch)
+        achieved = per_launch / (k_ms * 1e-3) / 1e9
+        sha = kernel_sources_sha()
+        traffic, traffic_note = None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from the rocprofv3 --pmc passes (profiles/tools/sweep.sh)
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"{args.env_id}:{B}")
-            except Exception:
-                traffic = None
+                rec = json.load(open(pmc))
+                key = f"{args.env_id}:{B}" + (f":r{args.sensor_range}" if args.sensor_range else "") \
+                      + (f":obs{args.observation_type}" if args.observation_type != 1 else "") + (f":m{args.msg_bits}" if args.msg_bits else "")
+                ent = rec.get("entries", {}).get(key)
+                if ent is None:
+                    traffic_note = f"no PMC traffic recorded for {key}"
+                elif rec.get("kernel_sources_sha") != sha:
+                    traffic_note = (f"stale: profiles/pmc_traffic.json was measured at kernel sources {rec.get('kernel_sources_sha')}, "
+                                    f"this build is {sha}; re-run profiles/tools/sweep.sh")
+                else:
+                    traffic = int(ent["bytes_per_launch"])
+            except Exception as exc:  # noqa: BLE001
+                traffic_note = f"unreadable pmc_traffic.json: {exc}"
         out = {
             "metric": "agent-steps/sec (agents*envs*steps/s)",
             "value": world * B * N * args.steps / elapsed,
@@ -213,7 +245,7 @@ def main():
                             "step+FLATTENED obs, on-device next_step autoreset every 500 steps",
                 "envs_per_gpu": B, "n_agents": N, "obs_length": int(info.obs_length),
                 "grid": [int(info.grid_h), int(info.grid_w)],
-                "parallelism": f"env-shard x{world} (no collective)",
+                "parallelism": f"env-shard x{world} (no collective, no RCCL; gloo barrier + MAX of the timings only)",
                 "submit": f"rw_step_many_device x{args.many} (fused rollout, one launch per chunk)" if args.many
                           else "rw_step_device per step (one launch per step, closed-loop capable)",
                 "envs_per_workgroup": int(info.envs_per_workgroup), "threads_per_workgroup": int(info.threads_per_workgroup),
@@ -223,23 +255,42 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": "rw::rware_step_kernel", "kernel_ms_per_launch": kernel_ms,
-                "algorithmic_bytes_per_launch": per_launch,
+                "peak_measured": HBM_MEASURED_GBPS, "frac_of_measured_peak": achieved / HBM_MEASURED_GBPS,
+                "frac_physical": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                "kernel": "rw::rware_step_kernel", "kernel_ms_per_launch": k_ms,
+                "algorithmic_bytes_per_launch": per_launch, "kernel_sources_sha": sha,
             },
         }
-        if fused_elapsed:
+        if traffic_note:
+            out["roofline"]["traffic_note"] = traffic_note
+        if sus_s:
+            s_ach = per_launch / (sus_kernel_ms * 1e-3) / 1e9
+            out["sustained"] = {
+                "value": world * B * N * SUSTAINED_STEPS / sus_s, "unit": "agent-steps/s",
+                "steps": SUSTAINED_STEPS, "warmup": SUSTAINED_WARMUP, "ms_per_step": sus_s / SUSTAINED_STEPS * 1e3,
+                "kernel_ms_per_launch": sus_kernel_ms, "roofline_achieved": s_ach, "roofline_frac": s_ach / HBM_PEAK_GBPS,
+                "roofline_frac_physical": (traffic / (sus_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                "what": "same launches as `value`, fixed length (SURVEY.md §8(d): 2000 steps after 100 warm-up, spans 4 mass resets)",
+            }
+        if fused_s:
             out["fused_rollout"] = {
-                "value": world * B * N * args.steps / fused_elapsed, "unit": "agent-steps/s",
-                "ms_per_step": fused_elapsed / args.steps * 1e3,
+                "value": world * B * N * args.steps / fused_s, "unit": "agent-steps/s",
+                "ms_per_step": fused_s / args.steps * 1e3,
                 "submit": "rw_step_many_device x64: one launch per 64 steps, env chunk resident in LDS across steps "
                           "(open-loop rollout from the same device action tape; identical results)",
             }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.env_id)
         print(json.dumps(out), flush=True)
     env.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    rc = 0
+    for c in children:
+        rc |= c.wait(timeout=120)
+    if rc:
+        raise SystemExit(f"a spawned rank exited with status {rc}")
 
 
 if __name__ == "__main__":

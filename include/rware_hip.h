@@ -72,6 +72,14 @@ enum rw_autoreset {
     RW_AUTORESET_SAME_STEP = 2  /* the terminating step returns the reset observation             */
 };
 
+/* How `rw_config.stream` is read.  A hipStream_t of NULL is also the handle of the device's default
+ * ("null") stream — the stream frameworks such as PyTorch run on unless told otherwise — so "NULL == make
+ * your own" cannot express "enqueue on the default stream".  RW_STREAM_USE_GIVEN takes the handle
+ * literally: NULL then means the default stream, and the engine's launches are ordered with everything
+ * else the caller enqueues there (a policy writing the action tensor before, a learner reading the
+ * observation tensor after) without any explicit synchronisation. */
+enum rw_stream_flags { RW_STREAM_USE_GIVEN = 1 };
+
 /* Device buffers (all env-major, C-contiguous).  Replaces the attributes callers read off the
  * reference object: env.grid (:302), env.agents[i].{x,y,dir,carrying_shelf,has_delivered}
  * (:82-93), env.request_queue (:263), env._cur_steps/_cur_inactive_steps (:249-250),
@@ -126,10 +134,11 @@ typedef struct rw_config {
     int32_t image_layers[8];      /* rw_image_layer values, channel order                        */
     int32_t msg_bits;             /* M communication bits (:152): an agent's action is then
                                      [Action, bit_0..bit_{M-1}]; FLATTENED L = 8 + (7+M)(2r+1)^2      */
-    int32_t reserved_;
+    int32_t stream_flags;         /* rw_stream_flags                                              */
     const uint8_t *highways;      /* host, [H*W], 1 == highway (no shelf spawns, no unloading)   */
     const int32_t *goals_xy;      /* host, [n_goals][2] = (x, y), list order == reward order     */
-    void *stream;                 /* hipStream_t to enqueue on; NULL == engine creates its own   */
+    void *stream;                 /* hipStream_t to enqueue on; NULL == engine creates its own
+                                     (non-blocking) stream, unless RW_STREAM_USE_GIVEN is set     */
 } rw_config;
 
 /* -- lifetime ------------------------------------------------------------------------- */
@@ -149,8 +158,9 @@ const char *rw_last_error(const rw_engine *eng);
 int rw_reset(rw_engine *eng, const uint64_t *seeds, const uint8_t *mask);
 
 /* replaces Warehouse.step(actions) (:804-946) for all B envs.
- *   rw_step:        actions is a HOST array int32 [B][N] ([B][N][1+M] with msg_bits = M); copied to
- *                   RW_BUF_ACTIONS, then launched.
+ *   rw_step:        actions is a HOST array int32 [B][N] ([B][N][1+M] with msg_bits = M); copied into a
+ *                   pinned staging buffer owned by the engine before the call returns (the caller may
+ *                   free or overwrite its array immediately), from there to RW_BUF_ACTIONS, then launched.
  *   rw_step_device: actions is a DEVICE array of the same shape (e.g. the policy's output tensor);
  *                   no copy.  Must stay valid until the step has executed.
  * Results land in RW_BUF_OBS / REWARDS / TERMINATED / TRUNCATED. */

@@ -26,6 +26,8 @@ BUF_DTYPE = {
     "rng": np.uint64, "need_reset": np.uint8, "features": np.float32,
 }
 
+RW_STREAM_USE_GIVEN = 1  # rw_stream_flags: `stream` is taken literally, NULL == the device's default stream
+
 AUTORESET = {"disabled": 0, None: 0, "next_step": 1, "same_step": 2}
 
 
@@ -35,7 +37,7 @@ class RwConfig(C.Structure):
         "request_queue_size", "max_inactivity_steps", "max_steps", "reward_type",
         "normalised_coordinates", "autoreset_mode", "n_goals", "device_id",
         "envs_per_workgroup", "threads_per_workgroup", "observation_type", "image_directional",
-        "n_image_layers")] + [("image_layers", C.c_int32 * 8), ("msg_bits", C.c_int32), ("reserved_", C.c_int32),
+        "n_image_layers")] + [("image_layers", C.c_int32 * 8), ("msg_bits", C.c_int32), ("stream_flags", C.c_int32),
         ("highways", C.c_void_p), ("goals_xy", C.c_void_p), ("stream", C.c_void_p)]
 
 
@@ -155,7 +157,7 @@ class Engine:
                  max_inactivity_steps, max_steps, reward_type, normalised_coordinates=False,
                  autoreset_mode="next_step", device_id=0, envs_per_workgroup=0,
                  threads_per_workgroup=0, stream=None, library=None, observation_type=1,
-                 image_layers=(), image_directional=True, msg_bits=0):
+                 image_layers=(), image_directional=True, msg_bits=0, use_given_stream=False):
         self.lib = load(library)
         self._h = C.c_void_p()
         hw = np.ascontiguousarray(layout.highways, dtype=np.uint8)
@@ -166,7 +168,7 @@ class Engine:
             int(reward_type), int(bool(normalised_coordinates)), AUTORESET[autoreset_mode], len(layout.goals),
             int(device_id), int(envs_per_workgroup), int(threads_per_workgroup),
             int(observation_type), int(bool(image_directional)), len(image_layers),
-            (C.c_int32 * 8)(*[int(l) for l in image_layers]), int(msg_bits), 0,
+            (C.c_int32 * 8)(*[int(l) for l in image_layers]), int(msg_bits), RW_STREAM_USE_GIVEN if use_given_stream else 0,
             hw.ctypes.data, goals.ctypes.data, C.c_void_p(stream or 0))
         rc = self.lib.rw_create(C.byref(cfg), C.byref(self._h))
         if rc != RW_OK:

@@ -41,6 +41,8 @@ struct rw_engine {
     uint32_t *d_highway_bits = nullptr;
     int32_t *d_shelf_init = nullptr;
     uint8_t *d_mask = nullptr;
+    int32_t *h_actions = nullptr;      // pinned staging buffer of rw_step (host actions)
+    hipEvent_t h_actions_free = nullptr;  // recorded after the staging buffer's copy to the device
     void (*kernel)(const rw::Params *, const int32_t *, const int32_t, const int32_t, float *, float *, uint8_t *, const uint8_t *, uint64_t *, const int64_t, const int64_t, const int64_t, const int64_t) = nullptr;  // the step kernel instance this engine launches
     void (*kernel_rollout)(const rw::Params *, const int32_t *, const int32_t, const int32_t, float *, float *, uint8_t *, const uint8_t *, uint64_t *, const int64_t, const int64_t, const int64_t, const int64_t) = nullptr;  // its fused multi-step (rollout) sibling
     rw::Params *d_prm = nullptr;  // device copy of `prm` (constant for the engine's lifetime)
@@ -284,8 +286,8 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
 
     RW_HIP_C(hipSetDevice(cfg->device_id));
     RW_HIP_C(hipGetDeviceProperties(&eng->prop, cfg->device_id));
-    if (cfg->stream) {
-        eng->stream = (hipStream_t)cfg->stream;
+    if (cfg->stream || (cfg->stream_flags & RW_STREAM_USE_GIVEN)) {
+        eng->stream = (hipStream_t)cfg->stream;  // with RW_STREAM_USE_GIVEN, NULL is the device's default stream
     } else {
         RW_HIP_C(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
         eng->own_stream = true;
@@ -400,10 +402,15 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     for (int k = 0; k < RW_BUF_KIND_COUNT; ++k) eng->buf[k].ptr = (char *)eng->slab + off[k];
     eng->d_shadow = (char *)eng->slab + eng->shadow_off;
     const int HWW = (HW + 31) / 32;
-    RW_HIP_C(hipMalloc(&eng->d_highway_bits, sizeof(uint32_t) * HWW));
+    // the static kernels stage the bitmap in whole 16-byte pieces: allocate (and zero) the rounded-up size
+    const size_t hw_bytes = sizeof(uint32_t) * (size_t)rw::rw_up4(HWW);
+    RW_HIP_C(hipMalloc(&eng->d_highway_bits, hw_bytes));
+    RW_HIP_C(hipMemsetAsync(eng->d_highway_bits, 0, hw_bytes, eng->stream));
     RW_HIP_C(hipMalloc(&eng->d_shelf_init, sizeof(int32_t) * HW));
     RW_HIP_C(hipMalloc(&eng->d_mask, szB + 64));
     RW_HIP_C(hipMalloc(&eng->d_status, sizeof(int32_t)));
+    RW_HIP_C(hipHostMalloc((void **)&eng->h_actions, n_elems[RW_BUF_ACTIONS] * sizeof(int32_t)));
+    RW_HIP_C(hipEventCreate(&eng->h_actions_free));
     std::vector<int32_t> shelf_init(HW, 0);
     std::vector<uint32_t> hw_bits(HWW, 0u);
     for (int i = 0; i < HW; ++i)
@@ -488,6 +495,8 @@ int rw_destroy(rw_engine *eng) {
     if (eng->d_mask) (void)hipFree(eng->d_mask);
     if (eng->d_prm) (void)hipFree(eng->d_prm);
     if (eng->d_status) (void)hipFree(eng->d_status);
+    if (eng->h_actions) (void)hipHostFree(eng->h_actions);
+    if (eng->h_actions_free) (void)hipEventDestroy(eng->h_actions_free);
     for (auto &ev : eng->events)
         if (ev) (void)hipEventDestroy(ev);
     if (eng->own_stream && eng->stream) (void)hipStreamDestroy(eng->stream);
@@ -533,8 +542,13 @@ int rw_step_device(rw_engine *eng, const int32_t *actions_dev) {
 int rw_step(rw_engine *eng, const int32_t *actions_host) {
     if (!eng || !actions_host) return RW_ERR_INVALID_ARG;
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
-    RW_HIP(eng, hipMemcpyAsync(eng->buf[RW_BUF_ACTIONS].ptr, actions_host, eng->buf[RW_BUF_ACTIONS].bytes,
+    // `actions_host` is caller-owned pageable memory that may be gone when this returns: stage it through the
+    // engine's pinned buffer (re-used only once its previous copy has left it)
+    RW_HIP(eng, hipEventSynchronize(eng->h_actions_free));
+    memcpy(eng->h_actions, actions_host, eng->buf[RW_BUF_ACTIONS].bytes);
+    RW_HIP(eng, hipMemcpyAsync(eng->buf[RW_BUF_ACTIONS].ptr, eng->h_actions, eng->buf[RW_BUF_ACTIONS].bytes,
                                hipMemcpyHostToDevice, eng->stream));
+    RW_HIP(eng, hipEventRecord(eng->h_actions_free, eng->stream));
     return launch(eng, eng->la, rw::OP_STEP);
 }
 

@@ -371,8 +371,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 if (t < pieces) lds_dma_b128(g, smem + lo.gs + 4 * b);
             }
         }
-        // (rounding pieces at the tail of hw / dflag read a few bytes past the logical end of their
-        //  source; both live inside the engine's slab, whose sub-buffers are padded)
+        // (rounding pieces at the tail of hw / dflag read a few bytes past the logical end of their source:
+        //  the bitmap is allocated rounded up to 16 bytes, the flags sit in the padded slab / the +64 mask buffer)
         RW_MARK(TL_DMA_ISSUED);
         RW_MARK(TL_ENV_LOADED);
         __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well

@@ -38,6 +38,17 @@ def all_ids(versions=("v1", "v2")):
     return [f"rware-{s}-{a}ag{d}-{v}" for v in versions for s in _SIZES for d in _DIFFICULTY for a in range(1, 20)]
 
 
+def shard_seeds(rank: int, envs_per_rank: int, seed: int = 0):
+    """Seeds of rank `rank`'s contiguous env shard when a batch is split over one process per GPU: env i of the
+    rank is GLOBAL env rank*envs_per_rank + i and gets `seed + global index` — the Gymnasium vector convention
+    (`reset(seed=s)` seeds env i with s + i) applied to the whole job, so the trajectories do not depend on how
+    many GPUs the batch is spread over.  Pass to `Engine.reset(seeds=...)` / `WarehouseVecEnv.reset(seed=...)`."""
+    import numpy as np
+
+    lo = np.uint64(int(seed)) + np.uint64(int(rank) * int(envs_per_rank))
+    return lo + np.arange(int(envs_per_rank), dtype=np.uint64)
+
+
 def make_vec(env_id: str, num_envs: int, **kwargs):
     """`gym.make_vec(id, num_envs=B)` analogue that works without gymnasium installed."""
     from .vector_env import WarehouseVecEnv

@@ -118,6 +118,9 @@ class WarehouseVecEnv(_VectorEnvBase):
                 import torch
 
                 self._torch = torch
+                # enqueue on torch's current stream of that device; its handle is 0 (NULL) for the default stream,
+                # which is why the engine is told to take the handle literally (RW_STREAM_USE_GIVEN): launches are
+                # then ordered with the policy / learner ops around them and need no sync
                 stream = torch.cuda.current_stream(dev).cuda_stream
             self.engines.append(_capi.Engine(
                 num_envs=hi - lo, layout=self.layout, n_agents=self.n_agents, sensor_range=self.sensor_range,
@@ -125,7 +128,8 @@ class WarehouseVecEnv(_VectorEnvBase):
                 max_steps=max_steps, reward_type=self.reward_type.value,
                 normalised_coordinates=normalised_coordinates, autoreset_mode=autoreset_mode, device_id=dev,
                 envs_per_workgroup=envs_per_workgroup, threads_per_workgroup=threads_per_workgroup,
-                stream=stream, library=library, observation_type=engine_obs_type.value,
+                stream=stream, use_given_stream=(output == "torch"), library=library,
+                observation_type=engine_obs_type.value,
                 image_layers=[l.value for l in layers] if image else (),
                 image_directional=image_observation_directional, msg_bits=self.msg_bits))
         self._bounds = [b for b in self._bounds if b[1] > b[0]]

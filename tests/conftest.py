@@ -9,3 +9,25 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver via gpurun)")
+
+
+def _hip_device_visible() -> bool:
+    try:
+        import torch
+
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests are skipped (not failed) where no HIP device is visible — e.g. a plain `pytest tests` in the
+    GPU-less build container.  On a GPU box nothing is skipped: a missing librware_hip.so then FAILS the tests."""
+    import pytest
+
+    gpu_items = [it for it in items if "gpu" in it.keywords]
+    if not gpu_items or _hip_device_visible():
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible (the engine has no CPU fallback)")
+    for it in gpu_items:
+        it.add_marker(skip)

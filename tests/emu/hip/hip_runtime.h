@@ -86,6 +86,8 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
 }
 inline hipError_t hipMalloc(void **p, size_t n) { return posix_memalign(p, 256, n ? n : 16) ? 1 : hipSuccess; }
 template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
+inline hipError_t hipHostMalloc(void **p, size_t n) { return hipMalloc(p, n); }
+inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }

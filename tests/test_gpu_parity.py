@@ -122,6 +122,49 @@ def test_torch_zero_copy_views_and_device_actions():
     tenv.close(); nenv.close()
 
 
+def test_torch_stream_ordering_without_sync():
+    """output="torch": the engine enqueues on torch's CURRENT stream (RW_STREAM_USE_GIVEN; the default stream's handle
+    is NULL), so a policy op producing the action tensor, the step, and a learner op consuming the observation tensor
+    are ordered by the stream alone — no env.sync() anywhere.  A long chain of dependent steps would expose a race."""
+    import torch
+    B, T = 4096, 60
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    tenv = rware_amd.WarehouseVecEnv(B, output="torch", **kw)
+    nenv = rware_amd.WarehouseVecEnv(B, **kw)
+    tenv.reset(seed=3)
+    nenv.reset(seed=3)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    tape = torch.randint(0, 5, (T, B, 4), generator=g, dtype=torch.int32)
+    tape_dev = tape.cuda()
+    torch.cuda.synchronize()
+    sums, keep = [], []
+    for t in range(T):
+        # "policy": a torch op on the current stream writes the action tensor right before the step reads it
+        a = (tape_dev[t] + torch.zeros((B, 4), dtype=torch.int32, device="cuda")).contiguous()
+        keep.append(a)
+        ot, rt, tt, _, _ = tenv.step(a)
+        # "learner": torch ops on the same stream read the zero-copy views right after the step wrote them
+        sums.append(torch.stack([ot.sum(dtype=torch.float64), rt.sum(dtype=torch.float64), tt.sum(dtype=torch.float64)]))
+    got = torch.stack(sums).cpu().numpy()      # the only synchronisation: this copy
+    for t in range(T):
+        on, rn, tn, _, _ = nenv.step(tape[t].numpy())
+        assert got[t, 0] == on.sum(dtype=np.float64) and got[t, 1] == rn.sum(dtype=np.float64) and got[t, 2] == tn.sum(), t
+    # and on a non-default current stream
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        senv = rware_amd.WarehouseVecEnv(B, output="torch", **kw)
+        senv.reset(seed=3)
+        acc = []
+        for t in range(20):
+            a = (tape_dev[t] + 0).contiguous()
+            keep.append(a)
+            ot, rt, tt, _, _ = senv.step(a)
+            acc.append(ot.sum(dtype=torch.float64))
+        got2 = torch.stack(acc).cpu().numpy()
+    assert np.array_equal(got2, got[:20, 0])
+    tenv.close(); nenv.close(); senv.close()
+
+
 def test_full_size_headline_batch_properties():
     """BASELINE config 3 at full size (small-4ag, B=16384): size-independent invariants + an
     oracle spot-check of a strided subset of envs."""
@@ -373,25 +416,47 @@ def test_full_batch_soak_every_env_against_oracle(env_id, extra, B, T):
     env.close()
 
 
-def test_bench_two_ranks_through_torchrun():
-    """The driver's N > 1 invocation of bench.py (torch.distributed.run, one rank per GPU), exercised on this
-    1-GPU box: both ranks share the device and gloo stands in for RCCL (bench.py test hooks).  Checks the
-    contract of the JSON line and that rank 0 reports the whole-job rate."""
+def _check_bench_line(out, n_gpus, steps, warmup, batch):
     import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RWARE_BENCH_BACKEND="gloo", RWARE_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "200", "--warmup", "20", "--batch", "4096"]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 200 and d["warmup"] == 20 and d["scaling"] == "weak"
+    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "weak"
     assert d["unit"] == "agent-steps/s" and d["higher_is_better"] is True and "cpu_baseline" not in d
-    expect = 2 * 4096 * 4 * 200 / (d["ms_per_step"] * 1e-3 * 200)
-    assert abs(d["value"] - expect) / expect < 1e-6     # whole-job aggregate over both ranks
+    expect = n_gpus * batch * 4 * steps / (d["ms_per_step"] * 1e-3 * steps)
+    assert abs(d["value"] - expect) / expect < 1e-6     # whole-job aggregate over all ranks
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 2
+    assert d["roofline"]["peak_measured"] == 6290.0 and "frac_physical" in d["roofline"]
+    sus = d["sustained"]                                 # the fixed-length steady-state leg rides in the same line
+    assert sus["steps"] == 2000 and sus["warmup"] == 100 and sus["ms_per_step"] > 0 and sus["kernel_ms_per_launch"] > 0
+    assert "RCCL" not in d["config"]["parallelism"] or "no RCCL" in d["config"]["parallelism"]
+    return d
+
+
+def test_bench_two_ranks_self_spawned():
+    """`python bench.py --gpus 2` with NO launcher (how the driver starts N = 1): bench.py spawns the second rank
+    itself; barrier + MAX over gloo.  Both ranks share this box's single device (test hook)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RWARE_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "20", "--batch", "4096"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    _check_bench_line(out, 2, 200, 20, 4096)
+
+
+def test_bench_two_ranks_through_torchrun():
+    """The driver's N > 1 invocation of bench.py (torch.distributed.run, one rank per GPU), exercised on this
+    1-GPU box: both ranks share the device (test hook).  Checks the contract of the JSON line and that rank 0
+    reports the whole-job rate."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RWARE_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "200", "--warmup", "20", "--batch", "4096"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    _check_bench_line(out, 2, 200, 20, 4096)

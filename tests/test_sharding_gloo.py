@@ -1,8 +1,9 @@
 """N>1 path on CPU: world_size-2 `gloo` processes.  Each rank owns a contiguous env shard seeded by
 GLOBAL env index (no data-path collective — envs are independent), and the only communication is
-bench.py's barrier + MAX-over-ranks of the elapsed time.  The shard engines here are the oracle
-(tests may use it as a stand-in backend); the claim under test is the sharding arithmetic: the
-concatenation of the shards equals the unsharded run."""
+bench.py's barrier + MAX-over-ranks of the elapsed time.  The shard engines are the PRODUCT — the
+engine sources built for host threads (tests/emu), driven through `WarehouseVecEnv` and seeded with
+`rware_amd.shard_seeds(rank, B)` exactly as bench.py does — and the claim under test is that the
+concatenation of the shards equals the UNSHARDED oracle run, i.e. results do not depend on the GPU count."""
 import os
 import socket
 import sys
@@ -31,15 +32,16 @@ def _actions(world):
 
 
 def _run_shard(rank, world):
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from rware_oracle import OracleVecEnv, seed_state
-    env = OracleVecEnv(B_PER_RANK, **_kw())
-    for i in range(B_PER_RANK):                       # bench.py: seeds = arange(rank*B, (rank+1)*B)
-        env.rng[i] = seed_state(rank * B_PER_RANK + i)
-    env.reset()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rware_amd
+    from engine_backend import EMU_LIB
+    env = rware_amd.WarehouseVecEnv(B_PER_RANK, library=EMU_LIB, envs_per_workgroup=4, threads_per_workgroup=64, **_kw())
+    env.engines[0].reset(seeds=rware_amd.shard_seeds(rank, B_PER_RANK))   # the very line bench.py seeds its shard with
     acts = _actions(world)[:, rank * B_PER_RANK:(rank + 1) * B_PER_RANK]
-    out = [env.step_autoreset(a, "next_step") for a in acts]
-    return np.stack([o[0] for o in out]), np.stack([o[1] for o in out]), env.get_state()
+    out = [env.step(a) for a in acts]
+    st = env.get_state()
+    env.close()
+    return np.stack([o[0] for o in out]), np.stack([o[1] for o in out]), st
 
 
 def _worker(rank, world, port, q):
@@ -59,6 +61,9 @@ def _worker(rank, world, port, q):
 @pytest.mark.timeout(300)
 def test_two_rank_shards_equal_the_unsharded_batch():
     world = 2
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from engine_backend import build_emu
+    build_emu()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
