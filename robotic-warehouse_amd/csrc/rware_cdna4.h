@@ -41,6 +41,38 @@ __device__ __forceinline__ void keep_sgpr(Ts... v) {
 __device__ __forceinline__ uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
 // uniform(x): tells the compiler a value is wave-uniform (v_readfirstlane), so tests on it become scalar branches
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// wave_lds_order(): LDS writes issued before it land before LDS writes issued after it, for all lanes of the wavefront.
+// The DS unit executes one wavefront's instructions in issue order, so on the GPU this only has to stop the compiler
+// from reordering or merging the stores around it; no s_waitcnt, nothing is emitted.
+__device__ __forceinline__ void wave_lds_order() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+// env_gather<N>(v, lane_base, out): out[k] = v held by agent k of this lane's env, where the N agents of an env sit in N
+// consecutive lanes starting at `lane_base` (a multiple of N).  All 64 lanes must be active (call it outside divergent
+// control flow).  N = 4 / 2: DPP quad_perm moves, no LDS hardware involved; other N: ds_bpermute_b32, one per agent,
+// issued back to back (one wait for the batch).
+template <int SEL0, int SEL1, int SEL2, int SEL3>
+__device__ __forceinline__ int quad_perm(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, SEL0 | (SEL1 << 2) | (SEL2 << 4) | (SEL3 << 6), 0xf, 0xf, false);
+}
+template <int N>
+__device__ __forceinline__ void env_gather(int v, int lane_base, int (&out)[N]) {
+    if constexpr (N == 1) {
+        out[0] = v;
+    } else if constexpr (N == 2) {
+        out[0] = quad_perm<0, 0, 2, 2>(v);
+        out[1] = quad_perm<1, 1, 3, 3>(v);
+    } else if constexpr (N == 4) {
+        out[0] = quad_perm<0, 0, 0, 0>(v);
+        out[1] = quad_perm<1, 1, 1, 1>(v);
+        out[2] = quad_perm<2, 2, 2, 2>(v);
+        out[3] = quad_perm<3, 3, 3, 3>(v);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) out[k] = __builtin_amdgcn_ds_bpermute((lane_base + k) << 2, v);
+    }
+}
 __device__ __forceinline__ void wave_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();

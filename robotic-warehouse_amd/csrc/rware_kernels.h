@@ -453,8 +453,255 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         lds_barrier();
     }
     // ---------------------------------------------------------------- AG: per-agent phases, wave-local
-    // Lane -> (env group g, agent a): all N agents of an env sit in one wavefront, so the sub-phases
-    // below exchange data through LDS under wave_sync() only.
+    // Lane -> (env group g, agent a): all N agents of an env sit in one wavefront.  Two implementations:
+    //   kRegAG  (exact-shape builds, N <= 8)  the agents of an env exchange intent, chain links, follower depth and
+    //           winners through cross-lane moves (env_gather: DPP quad_perm for N = 4 / 2, ds_bpermute otherwise) and
+    //           everything else stays in registers; LDS is read twice (own record; the shelf cells the agent looks at)
+    //           and written once (the results).  The common step has no LDS round trip after those two reads.
+    //   else    the sub-phases exchange through LDS arrays under wave_sync() (any N up to 64, run-time shapes).
+    constexpr bool kRegAG = Cfg::kN >= 1 && Cfg::kN <= 8;
+    if constexpr (kRegAG) {
+    constexpr int KN = Cfg::kN, KG = 64 / KN, KQ = Cfg::kQ, QS = (KQ + KN - 1) / KN;
+    static_assert(Cfg::kH * Cfg::kW < 0x8000, "cell indices are packed into 16 bits");
+    auto sel = [](const int (&arr)[KN], int idx) -> int {  // arr[idx] with the array in registers
+        int r = arr[0];
+#pragma unroll
+        for (int k = 1; k < KN; ++k) r = (idx == k) ? arr[k] : r;
+        return r;
+    };
+    for (int eb = wave * KG; eb < ne; eb += nw * KG) {  // wave-uniform
+        const int g = lane / KN, a_idx = lane - g * KN;
+        const bool mine = (g < KG) && (eb + g < ne);
+        const int lane_base = (g < KG ? g : KG - 1) * KN;  // (the 64 % N idle tail lanes gather from the last group)
+        const int e = mine ? eb + g : eb;  // keep every address in range for idle lanes
+        const int base = e * KN, i = base + (mine ? a_idx : 0);
+        CellT *gS = s_gs + e * HW;
+        uint8_t *gA = s_ga + e * HW;
+        int32_t *ev = s_envi + e * ENVI_W;
+        const int ge = e0 + e;  // global env index
+        // ---- LDS read batch 1: own record, env flags and counters, the queue slots this lane publishes
+        const int ev_skip = ev[ENVI_SKIP], ev_reset = ev[ENVI_RESET];
+        const int ev_steps = ev[ENVI_STEPS], ev_inact = ev[ENVI_INACTIVE];
+        int x = s_ax[i], y = s_ay[i], d = s_dir[i], carry = s_carry[i], deliv = s_deliv[i];
+        const int a_lds = (t == 0) ? s_act[i * AM] : (int)ACT_NOOP;
+        int qv[QS > 0 ? QS : 1];
+#pragma unroll
+        for (int q = 0; q < QS; ++q) qv[q] = s_queue[e * KQ + min(a_idx + q * KN, KQ - 1)];
+        const bool stepping = (op == OP_STEP) && mine && !ev_skip;
+        int a = ACT_NOOP;
+        if (mine) {
+            if (stepping) a = (t == 0) ? a_lds : (act_prefetch ? a_pref : act_t[((size_t)ge * KN + a_idx) * AM]);
+            if (kMsg && stepping) {  // agent.message[:] = action[1:] — for every agent, whatever its move does (:812)
+                int msg = 0;
+                for (int k = 0; k < M; ++k) {
+                    const int v = (t == 0) ? s_act[i * AM + 1 + k] : act_t[((size_t)ge * KN + a_idx) * AM + 1 + k];
+                    if ((unsigned)v > 1u) atomicOr(p.status, STATUS_INVALID_ACTION);  // MultiDiscrete([5, 2, 2, ...])
+                    msg |= (v & 1) << k;
+                }
+                s_msg[i] = msg;
+            }
+            if (act_prefetch && t + 1 < n_steps) a_pref = (act_t + la.act_stride)[(size_t)ge * KN + a_idx];
+        }
+        if (stepping && (unsigned)a > 4u) atomicOr(p.status, STATUS_INVALID_ACTION);  // Action(a) raises (:814); runs as NOOP
+        a = (stepping && (unsigned)a <= 4u) ? a : (int)ACT_NOOP;
+        // ------------------------------------------------------------ P1: intent (:825-846), branch-free
+        const int st = y * W + x;
+        const int fwd = (a == ACT_FORWARD) ? 1 : 0;
+        const int dx = fwd & ((d == DIR_RIGHT) ? 1 : 0), dxn = fwd & ((d == DIR_LEFT) ? 1 : 0);
+        const int dy = fwd & ((d == DIR_DOWN) ? 1 : 0), dyn = fwd & ((d == DIR_UP) ? 1 : 0);
+        const int tx0 = min(max(x + dx - dxn, 0), W - 1);  // clamped at the walls (:105-112)
+        const int ty0 = min(max(y + dy - dyn, 0), H - 1);
+        const int tg0 = ty0 * W + tx0;
+        // ---- LDS read batch 2 (the last one of the common step): the shelf layer at the target, under the agent and
+        // on the first two goal cells (start-of-step values), the highway word of the agent's cell
+        const int sh_tg = gS[tg0], shelf_here = gS[st], sh_g0 = gS[k_goal0], sh_g1 = gS[k_goal1];
+        const uint32_t hw_word = s_hw[st >> 5];
+        // who stands on my target cell, and is it loaded: every agent's (cell | loaded << 16)
+        int pkv[KN];
+        env_gather<KN>(st | (carry ? 0x10000 : 0), lane_base, pkv);
+        int occ = -1, occ_loaded = 0;
+#pragma unroll
+        for (int k = 0; k < KN; ++k) {
+            const bool hit = (pkv[k] & 0xffff) == tg0;
+            occ = hit ? k : occ;
+            occ_loaded = hit ? (pkv[k] >> 16) : occ_loaded;
+        }
+        // a standing shelf blocks a loaded agent (:836-846)
+        const bool blocked = (carry != 0) & (tg0 != st) & (sh_tg != 0) & (occ_loaded == 0);
+        a = blocked ? (int)ACT_NOOP : a;
+        const int tg = blocked ? st : tg0, tx = blocked ? x : tx0, ty = blocked ? y : ty0;
+        // successor on the chain: agent index on the target cell, -1 empty, -2 == this agent is stationary
+        const int nxt = (tg == st) ? -2 : occ;
+        // Chains (an agent stepping onto a cell another agent stands on) are rare; when the wavefront has none, every
+        // follower depth is 0 and a mover commits iff it wins its cell.
+        const bool chains = wave_any(nxt >= 0);  // wave-uniform
+        // ------------------------------------------------------------ P2a: follower depth (longest chain of movers behind me)
+        int depth = 0;
+        int nxv[KN];
+        if (chains) {
+            env_gather<KN>(nxt, lane_base, nxv);
+            for (int it = 1; it < KN; ++it) {  // relaxation; a chain of movers has at most N - 1 links
+                int dv[KN];
+                env_gather<KN>(depth, lane_base, dv);
+                int nd = 0;
+#pragma unroll
+                for (int k = 0; k < KN; ++k) nd = max(nd, (nxv[k] == a_idx) ? dv[k] + 1 : 0);
+                nd = (nxt != -2) ? nd : 0;  // only movers carry a depth
+                const bool changed = nd != depth;
+                depth = nd;
+                if (!wave_any(changed)) break;  // wave-uniform (agents on a cycle never settle: their depth is not used)
+            }
+        }
+        // ------------------------------------------------------------ P2b: winner per contested cell
+        // larger follower depth wins, then the LOWER agent id; only movers compete
+        int kv[KN];
+        env_gather<KN>((nxt != -2) ? (tg | (depth << 16)) : -1, lane_base, kv);
+        int lose = 0;
+#pragma unroll
+        for (int k = 0; k < KN; ++k) {  // (bitwise on purpose: no short-circuit branches)
+            const int tk = kv[k] & 0xffff, dk = kv[k] >> 16;
+            lose |= ((kv[k] != -1) & (tk == tg) & (k != a_idx) & ((dk > depth) | ((dk == depth) & (k < a_idx)))) ? 1 : 0;
+        }
+        lose = (nxt != -2) ? lose : 0;
+        // ------------------------------------------------------------ P2c: commit (:871-876)
+        int commit = (nxt == -1) ? (lose ^ 1) : ((nxt == -2) ? 1 : 0);
+        if (chains) {  // walk the chain ahead: i -> nxt(i) -> ... on the gathered links
+            int wv[KN];
+            env_gather<KN>(lose ^ 1, lane_base, wv);
+            int j = a_idx, hops = 0, ok = 1, cm = 0;
+            bool done = nxt < 0;
+#pragma unroll
+            for (int h = 0; h < KN; ++h) {
+                const int nj = sel(nxv, j);
+                ok &= sel(wv, j);
+                ++hops;
+                const int nnj = sel(nxv, nj);                      // (any value when nj < 0: not used then)
+                const bool to_empty = nj == -1;                     // drains into an empty cell
+                const bool back = nj == a_idx;                      // a cycle through me; the 2-swap is refused
+                const bool stuck = (nj >= 0) & (nnj == -2);         // blocked by a stationary agent
+                cm = (!done & to_empty) ? ok : cm;
+                cm = (!done & !to_empty & back) ? ((hops >= 3) ? 1 : 0) : cm;
+                done = done | to_empty | back | stuck | (hops >= KN);  // hops == N: feeds a cycle it is not part of
+                j = (nj >= 0) ? nj : j;
+            }
+            commit = (nxt >= 0) ? cm : commit;
+        }
+        // ------------------------------------------------------------ P3: apply (:878-899)
+        a = commit ? a : (int)ACT_NOOP;  // a failed mover does nothing (:875)
+        const bool moved = (a == ACT_FORWARD) & (tg != st);
+        x = moved ? tx : x;
+        y = moved ? ty : y;
+        // wraplist [UP, RIGHT, DOWN, LEFT] (:119): RIGHT 0->3->1->2->0, LEFT 0->2->1->3->0
+        const int right = (0x1023 >> (4 * d)) & 0xF;  // d: 0->3, 1->2, 2->0, 3->1
+        const int left = (0x0132 >> (4 * d)) & 0xF;   // d: 0->2, 1->3, 2->1, 3->0
+        d = (a == ACT_RIGHT) ? right : ((a == ACT_LEFT) ? left : d);
+        // TOGGLE_LOAD (:886-899): pick up the shelf under the agent, or put the carried one down off the highways
+        const bool toggle = (a == ACT_TOGGLE);
+        const bool drop = toggle & (carry != 0) & (((hw_word >> (st & 31)) & 1u) == 0u);
+        const bool pick = toggle & (carry == 0) & (shelf_here != 0);
+        const float rew = (drop & (deliv != 0) & (k_reward_type == REW_TWO_STAGE)) ? 0.5f : 0.0f;
+        const bool mcar = moved & (carry != 0);  // a loaded mover drags its shelf along the shelf layer
+        deliv = drop ? 0 : deliv;
+        carry = drop ? 0 : (pick ? shelf_here : carry);
+        // ---- results to LDS (stores only; nothing below waits for them on the common path)
+        if (stepping) { s_ax[i] = x; s_ay[i] = y; s_dir[i] = d; s_carry[i] = carry; s_deliv[i] = deliv; }
+        if (mine) s_rew[i] = rew;  // every agent of the chunk gets its reward slot
+        if (mine) s_mv[i] = moved ? (st | (tg << 16)) : -1;  // which two cells changed (write-back hand-off)
+        if (mcar) gS[st] = 0;  // incremental _recalc_grid (:749-755): clear phase ...
+        wave_lds_order();
+        if (mcar) gS[tg] = (CellT)carry;  // ... then set phase, for the whole wavefront in this order
+        // the agent layer was zeroed at the start of the step: final position only (id | 0x80 if loaded)
+        if (mine && !ev_reset) gA[moved ? tg : st] = (uint8_t)((a_idx + 1) | (carry ? 0x80 : 0));
+        // ------------------------------------------------------------ P5: goals, rewards, termination (:903-942)
+        // Is there a shelf on a goal cell after the moves?  From registers: a loaded mover that arrived there, or the
+        // start-of-step shelf unless a loaded mover took it away.  (More than two goal cells: always take the LDS path.)
+        int mvv[KN];
+        env_gather<KN>(mcar ? (st | (tg << 16)) : -1, lane_base, mvv);
+        bool stay0 = sh_g0 != 0, stay1 = sh_g1 != 0, in0 = false, in1 = false;
+#pragma unroll
+        for (int k = 0; k < KN; ++k) {
+            const bool v = mvv[k] != -1;
+            const int from = mvv[k] & 0xffff, to = mvv[k] >> 16;
+            in0 |= v & (to == k_goal0);
+            in1 |= v & (to == k_goal1);
+            stay0 &= !(v & (from == k_goal0));
+            stay1 &= !(v & (from == k_goal1));
+        }
+        const bool goal_hit = (k_n_goals > 2) | in0 | stay0 | ((k_n_goals > 1) & (in1 | stay1));
+        const bool leader = stepping && a_idx == 0;
+        if (wave_any(leader && goal_hit)) {  // wave-uniform; a delivery may be due: the LDS path
+            wave_sync();
+            if (leader) {
+                int32_t *q = s_queue + e * Q;
+                bool delivered = false;
+                for (int gi = 0; gi < k_n_goals; ++gi) {  // in list order (:904)
+                    const int cell = gi == 0 ? k_goal0 : gi == 1 ? k_goal1 : p.goal_cells[gi];
+                    const int sid = gS[cell];
+                    if (!sid) continue;
+                    int slot = -1;  // first queue slot holding sid; all Q entries read in one LDS batch (no early exit)
+                    for (int k = Q - 1; k >= 0; --k) slot = (q[k] == sid) ? k : slot;
+                    if (slot < 0) continue;
+                    delivered = true;
+                    // candidates = shelves not in the queue, id order; one bounded draw (:915-916)
+                    Pcg64 rg;
+                    rng_load(rg, p.rng, B, ge);
+                    const int idx = (int)pcg_bounded(rg, (uint32_t)(S - Q - 1));
+                    rng_store(rg, p.rng, B, ge);
+                    int cand = idx + 1;  // idx-th id (0-based) among ids 1..S that are not queued
+                    for (;;) {
+                        int c = 0;
+                        for (int k = 0; k < Q; ++k) c += (q[k] <= cand) ? 1 : 0;
+                        const int nc = idx + 1 + c;
+                        if (nc == cand) break;
+                        cand = nc;
+                    }
+                    q[slot] = cand;
+                    if (k_reward_type == REW_GLOBAL) {
+                        for (int k = 0; k < N; ++k) s_rew[base + k] += 1.0f;
+                    } else {
+                        const int aid = gA[cell] & 0x7f;
+                        const int ai = aid > 0 ? aid - 1 : N - 1;  // rewards[-1] when nobody stands there
+                        if (k_reward_type == REW_INDIVIDUAL) {
+                            s_rew[base + ai] += 1.0f;
+                        } else {
+                            s_deliv[base + ai] = 1;
+                            s_rew[base + ai] += 0.5f;
+                        }
+                    }
+                }
+                ev[ENVI_INACTIVE] = delivered ? 0 : ev[ENVI_INACTIVE] + 1;
+                ev[ENVI_STEPS] += 1;
+                const int done = ((k_max_inactivity && ev[ENVI_INACTIVE] >= k_max_inactivity) ||
+                                  (k_max_steps && ev[ENVI_STEPS] >= k_max_steps)) ? 1 : 0;
+                ev[ENVI_DONE] = done;
+                if (done && k_autoreset == AR_SAME_STEP) {
+                    ev[ENVI_RESET] = 1;
+                    s_misc[0] = 1;
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < QS; ++q) qv[q] = s_queue[e * KQ + min(a_idx + q * KN, KQ - 1)];  // a request may have been replaced
+        } else if (leader) {  // nothing on a goal: counters and termination from registers
+            const int inact = ev_inact + 1, steps = ev_steps + 1;
+            const int done = ((k_max_inactivity && inact >= k_max_inactivity) || (k_max_steps && steps >= k_max_steps)) ? 1 : 0;
+            ev[ENVI_INACTIVE] = inact;
+            ev[ENVI_STEPS] = steps;
+            ev[ENVI_DONE] = done;
+            if (done && k_autoreset == AR_SAME_STEP) {
+                ev[ENVI_RESET] = 1;
+                s_misc[0] = 1;
+            }
+        }
+        // requested-shelf bitmap of the (post-step) queue.  Envs that reset in this launch are included: RS clears and
+        // rebuilds their bitmap.
+        if (mine) {
+#pragma unroll
+            for (int q = 0; q < QS; ++q)
+                if (a_idx + q * KN < KQ) atomicOr(&s_req[e * SW + (qv[q] >> 5)], 1u << (qv[q] & 31));
+        }
+    }
+    } else {
     const int G = Cfg::kN ? 64 / (Cfg::kN ? Cfg::kN : 1) : p.groups_per_wave;
     for (int eb = wave * G; eb < ne; eb += nw * G) {  // wave-uniform
         const int g = rw_div18(lane, mN), a_idx = lane - g * N;
@@ -653,6 +900,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 const int sid = s_queue[e * Q + k];
                 atomicOr(&s_req[e * SW + (sid >> 5)], 1u << (sid & 31));
             }
+    }
     }
     lds_barrier();
     RW_MARK(TL_AGENTS);

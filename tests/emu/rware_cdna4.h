@@ -28,4 +28,14 @@ inline uint32_t opaque(uint32_t x) { return x; }
 inline int uniform(int x) { return x; }
 inline void lds_barrier() { pthread_barrier_wait(emu_barrier); }
 inline void wave_sync() { pthread_barrier_wait(emu_wave_barrier); }
+inline void wave_lds_order() { pthread_barrier_wait(emu_wave_barrier); }  // threads are not in lockstep here: a real barrier
+extern int emu_xlane[16][64];
+template <int N>
+inline void env_gather(int v, int lane_base, int (&out)[N]) {  // every thread of the wave calls this
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    emu_xlane[w][l] = v;
+    pthread_barrier_wait(emu_wave_barrier);
+    for (int k = 0; k < N; ++k) out[k] = emu_xlane[w][(lane_base + k) & 63];
+    pthread_barrier_wait(emu_wave_barrier);
+}
 }  // namespace rw

@@ -49,6 +49,13 @@ def test_emulated_engine_matches_reference_golden(name, geom):
     ("rware-small-8ag-v1", {"max_steps": 30, "reward_type": 0, "max_inactivity_steps": 9}, 5, (4, 128)),
     ("rware-medium-6ag-hard-v1", {"max_steps": 20, "reward_type": 2}, 9, (8, 128)),
     ("rware-large-16ag-v1", {"sensor_range": 2, "max_steps": 15}, 3, (4, 64)),
+    # exact-shape builds (default geometry): agent phases in registers — DPP pairs (N = 2), quads (N = 4), ds_bpermute (N = 6)
+    ("rware-tiny-2ag-v1", {"max_steps": 25}, 32, (0, 0)),
+    ("rware-small-4ag-v1", {"max_steps": 25, "reward_type": 2}, 16, (0, 0)),            # the 8-env build
+    ("rware-small-4ag-v1", {"max_steps": 25, "max_inactivity_steps": 11}, 32, (16, 256)),
+    ("rware-medium-6ag-hard-v1", {"max_steps": 20, "reward_type": 0}, 16, (0, 0)),      # the 8-env build
+    ("rware-medium-6ag-hard-v1", {"max_steps": 20}, 16, (16, 256)),
+    ("rware-tiny-4ag-hard-v1", {"max_steps": 20}, 16, (0, 0)),
 ])
 def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
     kw = rware_amd.env_kwargs(env_id)
@@ -57,6 +64,7 @@ def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
     env = rware_amd.WarehouseVecEnv(B, autoreset_mode=mode, library=LIB, envs_per_workgroup=geom[0],
                                     threads_per_workgroup=geom[1], **kw)
     orc = OracleVecEnv(B, **kw)
+    assert env.engines[0].info.specialised == (1 if geom in ((0, 0), (16, 256)) else 0)
     obs, _ = env.reset(seed=99)
     assert np.array_equal(obs, orc.reset(seed=99))
     rng = np.random.default_rng(3)
@@ -70,6 +78,24 @@ def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
         for k in so:
             assert np.array_equal(st[k], so[k]), (k, t)
     env.close()
+
+
+@pytest.mark.parametrize("name,geom,tile", [
+    ("small-4ag", (16, 256), 4),       # quad exchange (N = 4), 16-env workgroups
+    ("small-4ag", (0, 0), 2),          # ... and the 8-env build picked for small batches
+    ("tiny-2ag", (0, 0), 4),           # pair exchange (N = 2)
+    ("medium-6ag-hard", (0, 0), 8),    # ds_bpermute exchange (N = 6), 8-env build
+    ("large-16ag-sr2", (0, 0), 4),     # exact-shape build with the LDS exchange (N = 16)
+])
+def test_emulated_exact_shape_builds_match_reference_golden(name, geom, tile):
+    """The golden traces of the unmodified reference, replayed on the EXACT-SHAPE kernel builds (the ones the BASELINE
+    configs run): the fixture's few envs are tiled up to a whole number of workgroups."""
+    meta, z = gu.load_fixture(name)
+    be = EngineBackend(meta["E"], library=LIB, envs_per_workgroup=geom[0], threads_per_workgroup=geom[1], tile=tile,
+                       **gu.ctor_kwargs(meta))
+    assert be.env.engines[0].info.specialised == 1
+    assert gu.replay(be, meta, z, steps=300) > 0
+    be.env.close()
 
 
 def test_masked_reset_and_reseed():

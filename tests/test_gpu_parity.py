@@ -31,6 +31,20 @@ def test_engine_matches_reference_golden(name):
     be.env.close()
 
 
+@pytest.mark.parametrize("name,geom,tile", [
+    ("small-4ag", (0, 0), 4), ("small-4ag", (16, 256), 4), ("tiny-2ag", (0, 0), 4), ("medium-6ag-hard", (0, 0), 8),
+    ("medium-6ag-hard", (16, 256), 16), ("large-16ag-sr2", (0, 0), 4),
+])
+def test_exact_shape_builds_match_reference_golden(name, geom, tile):
+    """The golden traces of the unmodified reference on the EXACT-SHAPE kernel builds (what the BASELINE configs run):
+    the fixture's few envs are tiled up to a whole number of workgroups; every field, every step."""
+    meta, z = gu.load_fixture(name)
+    be = EngineBackend(meta["E"], envs_per_workgroup=geom[0], threads_per_workgroup=geom[1], tile=tile, **gu.ctor_kwargs(meta))
+    assert be.env.engines[0].info.specialised == 1
+    assert gu.replay(be, meta, z) == meta["T"]
+    be.env.close()
+
+
 CASES = [
     # id, extra kwargs, B, T, geometry (envs/wg, threads/wg)
     ("rware-tiny-2ag-v1", {}, 4096, 560, (0, 0)),

@@ -13,16 +13,26 @@ import pytest
 from kat_env import (DOWN, FORWARD, GLOBAL, INDIVIDUAL, LEFT, NOOP, RIGHT, TOGGLE, TURN_LEFT,
                      TURN_RIGHT, TWO_STAGE, UP, KatEnv)
 
-BACKENDS = ["oracle", "emu", pytest.param("gpu", marks=pytest.mark.gpu)]
+# "-static": the same scenarios on the exact-shape kernel build of rware-small-4ag (agent phases in registers, cross-lane
+# exchange) — workgroups of 16 envs, and on the GPU also the 8-env build picked for small batches
+BACKENDS = ["oracle", "emu", "emu-static", pytest.param("gpu", marks=pytest.mark.gpu),
+            pytest.param("gpu-static", marks=pytest.mark.gpu), pytest.param("gpu-static8", marks=pytest.mark.gpu)]
+GENERIC_ONLY = ["oracle", "emu", pytest.param("gpu", marks=pytest.mark.gpu)]
 
 
 def make(backend, n_agents, reward=GLOBAL, cols=3, height=8, rows=3, queue=5, max_inact=None, max_steps=None, **kw):
     lib = None
-    if backend == "emu":
+    if backend.startswith("emu"):
         from engine_backend import build_emu
         lib = build_emu()
+    static = None
+    if backend.endswith("-static") or backend.endswith("-static8"):
+        if n_agents > 4:
+            pytest.skip("the exact-shape build under test has 4 agents")
+        static = (0, 0) if backend.endswith("8") else (16, 256)
     be = "oracle" if backend == "oracle" else "engine"
-    return KatEnv(be, cols, height, rows, n_agents, 0, 1, queue, max_inact, max_steps, reward, library=lib, **kw).reset()
+    return KatEnv(be, cols, height, rows, n_agents, 0, 1, queue, max_inact, max_steps, reward, library=lib,
+                  static_geometry=static, **kw).reset()
 
 
 # (agents [(x, y, dir, carries_shelf_idx or None)], actions, expected [(x, y)])
@@ -213,7 +223,7 @@ def test_two_deliveries_in_one_step_draw_in_goal_order(backend):
     env.close()
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("backend", GENERIC_ONLY)
 @pytest.mark.parametrize("cols,height,rows", [(1, 2, 2), (3, 8, 1), (3, 8, 3), (5, 3, 2), (7, 4, 4)])
 def test_grid_size_formula(backend, cols, height, rows):
     env = make(backend, 1, cols=cols, height=height, rows=rows, queue=1)
