@@ -29,7 +29,8 @@ def main():
     for t in range(20):
         eng.step_device(acts[t].data_ptr())
     eng.sync()
-    tl = eng.debug_timeline(acts[21].data_ptr()).astype(np.int64)[:, : len(MARKS)]
+    raw = eng.debug_timeline(acts[21].data_ptr()).astype(np.int64)
+    tl = raw[:, : len(MARKS)]
     t0 = tl[:, 0].min()
     us = (tl - t0) / 100.0
     print(f"{env_id} B={B} E={eng.info.envs_per_workgroup} T={eng.info.threads_per_workgroup} wgs={tl.shape[0]}")
@@ -42,7 +43,16 @@ def main():
     for k in range(len(MARKS) - 1):
         print(f"  {MARKS[k]:>10s} -> {MARKS[k + 1]:10s} {np.median(d[:, k]):7.2f} {np.percentile(d[:, k], 90):7.2f} "
               f"{np.percentile(d[:, k], 99):7.2f} {d[:, k].max():7.2f}")
+    if raw.shape[1] >= 17 and raw[:, 12].max() > 0:  # marks inside the agent phases (register-exchange builds)
+        names = ["loaded", "record read", "cells read", "winners", "applied", "goals", "agents"]
+        cols = np.stack([raw[:, 4], raw[:, 12], raw[:, 13], raw[:, 14], raw[:, 15], raw[:, 16], raw[:, 5]], axis=1)
+        dd = np.diff((cols - t0) / 100.0, axis=1)
+        print("inside the agent phases (wavefront 0), us: median / p90 / p99 / max")
+        for k in range(len(names) - 1):
+            print(f"  {names[k]:>12s} -> {names[k + 1]:12s} {np.median(dd[:, k]):7.2f} {np.percentile(dd[:, k], 90):7.2f} "
+                  f"{np.percentile(dd[:, k], 99):7.2f} {dd[:, k].max():7.2f}")
     life = us[:, -1] - us[:, 0]
+    life = us[:, len(MARKS) - 1] - us[:, 0]
     last = np.argsort(us[:, -1])[-8:]
     print("the 8 workgroups that end last: id, start, end, lifetime, agents-phase")
     for b in last:

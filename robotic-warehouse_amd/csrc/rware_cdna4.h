@@ -37,6 +37,8 @@ template <typename... Ts>
 __device__ __forceinline__ void keep_sgpr(Ts... v) {
     (keep_sgpr1((int)v), ...);
 }
+// keep_vgpr(a, b): the values must have been computed at this point (profiling marks: pins work in front of a time stamp)
+__device__ __forceinline__ void keep_vgpr(int a, int b) { asm volatile("" ::"v"(a), "v"(b)); }
 // opaque(x): the value, with everything the optimiser knew about its bits forgotten
 __device__ __forceinline__ uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
 // uniform(x): tells the compiler a value is wave-uniform (v_readfirstlane), so tests on it become scalar branches
@@ -54,7 +56,8 @@ __device__ __forceinline__ void wave_lds_order() {
 // issued back to back (one wait for the batch).
 template <int SEL0, int SEL1, int SEL2, int SEL3>
 __device__ __forceinline__ int quad_perm(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, SEL0 | (SEL1 << 2) | (SEL2 << 4) | (SEL3 << 6), 0xf, 0xf, false);
+    // (bound_ctrl set: the "old" operand is dead, so no register has to be zeroed in front of the move)
+    return __builtin_amdgcn_mov_dpp(v, SEL0 | (SEL1 << 2) | (SEL2 << 4) | (SEL3 << 6), 0xf, 0xf, true);
 }
 template <int N>
 __device__ __forceinline__ void env_gather(int v, int lane_base, int (&out)[N]) {
@@ -71,6 +74,24 @@ __device__ __forceinline__ void env_gather(int v, int lane_base, int (&out)[N]) 
     } else {
 #pragma unroll
         for (int k = 0; k < N; ++k) out[k] = __builtin_amdgcn_ds_bpermute((lane_base + k) << 2, v);
+    }
+}
+// env_or<N>(v, lane_base): bitwise OR of v over the N agents of this lane's env, delivered to each of them.
+template <int N>
+__device__ __forceinline__ int env_or(int v, int lane_base) {
+    if constexpr (N == 1) {
+        return v;
+    } else if constexpr (N == 2) {
+        return v | quad_perm<1, 0, 3, 2>(v);
+    } else if constexpr (N == 4) {
+        v |= quad_perm<1, 0, 3, 2>(v);
+        return v | quad_perm<2, 3, 0, 1>(v);
+    } else {
+        int g[N], r = 0;
+        env_gather<N>(v, lane_base, g);
+#pragma unroll
+        for (int k = 0; k < N; ++k) r |= g[k];
+        return r;
     }
 }
 __device__ __forceinline__ void wave_sync() {

@@ -142,7 +142,9 @@ struct LaunchArgs {
         (la).timeline, (la).act_stride, (la).obs_stride, (la).rew_stride, (la).term_stride
 enum : int { OP_FLAG_TIMELINE = 0x100 };
 enum : int { TL_START = 0, TL_ZEROED, TL_DMA_ISSUED, TL_ENV_LOADED, TL_LOADED, TL_AGENTS, TL_RESET, TL_OBS_BITS,
-             TL_OBS_STORED, TL_END, TL_MARKS = 12 };
+             TL_OBS_STORED, TL_END,  // 10, 11: where the wavefronts ran
+             TL_AG_RECORD = 12, TL_AG_CELLS, TL_AG_WINNERS, TL_AG_APPLIED, TL_AG_GOALS,  // inside the agent phases (wavefront 0)
+             TL_MARKS = 20 };
 
 // LDS carve-up, in dwords.  Every sub-array starts on a 16-byte boundary.
 struct LdsLayout {
@@ -280,6 +282,9 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int H = Cfg::kH ? Cfg::kH : p.H, W = Cfg::kW ? Cfg::kW : p.W, HW = H * W;
     const int S = Cfg::kS ? Cfg::kS : p.S, SW = (S + 32) / 32, B = p.B;
     const int nea = ne * N;
+    // agent phases with cross-lane exchange in registers (see AG); kDirect: own record fetched straight into registers
+    constexpr bool kRegAG = Cfg::kN >= 1 && Cfg::kN <= 6;  // (N + 2 link codes must fit 3 bits)
+    constexpr bool kDirect = kRegAG && Cfg::kE != 0 && !kMsg;
     // wavefront 3 = service wave after the agent phases (see WB); pays off while the observation of a workgroup is
     // small enough that three wavefronts expand it as fast as the stores drain (measured: small-4ag 8.91 -> 8.79 us,
     // fused 4.93 -> 4.56; medium-6ag-hard 8.56 -> 8.40; large-16ag r=2 with 23 K floats per workgroup 43.6 -> 46.1, so not there)
@@ -322,6 +327,26 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         for (int i = tid; i < ne * SW; i += T) s_req[i] = 0u;
         if (tid == 0) s_misc[0] = 0;
     };
+    // kDirect: every agent lane fetches ITS OWN record (and its env's flags and counters) from HBM straight into registers,
+    // first thing in the kernel: the loads fly beside the clear and the stage-in DMA, are complete at the barrier that
+    // drains the DMA, and the agent phases start without an LDS read.  The LDS copies the later phases read (window
+    // gather, write-back) are written by the agent lanes together with their results.
+    const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : p.need_reset;  // OP_RESET: all-ones when no mask was given
+    int r_x = 0, r_y = 0, r_d = 0, r_carry = 0, r_deliv = 0, r_act = ACT_NOOP, r_flag = 0, r_steps = 0, r_inact = 0;
+    if constexpr (kDirect) {
+        constexpr int KN = Cfg::kN, KG = 64 / KN;
+        static_assert(Cfg::kE <= (Cfg::kT / 64) * KG, "every env of the chunk needs its own agent lanes");
+        const int g = lane / KN, a_idx = lane - g * KN, le = wave * KG + g;
+        if (g < KG && le < Cfg::kE) {
+            const int ge = e0 + le;
+            const size_t gi = (size_t)ge * KN + a_idx;
+            r_x = p.ax[gi]; r_y = p.ay[gi]; r_d = p.adir[gi]; r_carry = p.acarry[gi]; r_deliv = p.adeliv[gi];
+            if (op == OP_STEP) r_act = la.actions[gi];
+            r_flag = (op == OP_OBS) ? 0 : (int)flag_src[ge];
+            r_steps = p.steps[ge];
+            r_inact = p.inactive[ge];
+        }
+    }
     clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
     RW_MARK(TL_ZEROED);
     // The per-config scalars the agent phases need (P3, P5) are fetched HERE, so their latency hides under the
@@ -330,7 +355,6 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int k_reward_type = p.reward_type, k_max_inactivity = p.max_inactivity, k_max_steps = p.max_steps;
     const int k_autoreset = p.autoreset, k_n_goals = p.n_goals;
     const int k_goal0 = p.goal_cells[0], k_goal1 = p.goal_cells[1];
-    const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : p.need_reset;  // OP_RESET: all-ones when no mask was given
     if constexpr (Cfg::kE != 0) {
         // Static build: every DMA destination is contiguous in LDS and every source chunk is a whole
         // number of 16-byte pieces, so the chunk is ONE linear stream — thread t moves LDS piece t;
@@ -355,6 +379,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             const int wave_s = uniform(wave);
             int job = 0;
             for (int k = 0; k < 12; ++k) {  // (fully unrolled when the shapes are compile-time constants)
+                if (kDirect && ((k >= 1 && k <= 6) || k >= 9)) continue;  // agent SoA, actions, counters, flags: in registers
                 const int pieces = (seg[k + 1] - seg[k]) >> 2;
                 for (int c = 0; c < pieces; c += 64, ++job)
                     if (job % nw == wave_s && c + lane < pieces)
@@ -376,18 +401,20 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         RW_MARK(TL_DMA_ISSUED);
         RW_MARK(TL_ENV_LOADED);
         __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
-        const uint8_t *s_dflag = reinterpret_cast<const uint8_t *>(smem + lo.dflag);
-        for (int e = tid; e < ne; e += T) {
-            int32_t *ev = s_envi + e * ENVI_W;
-            const int rs = (op == OP_OBS) ? 0 : (int)s_dflag[e];
-            ev[ENVI_STEPS] = smem[lo.dsteps + e];
-            ev[ENVI_INACTIVE] = smem[lo.dinact + e];
-            ev[ENVI_RESET] = rs;
-            ev[ENVI_SKIP] = rs;
-            ev[ENVI_DONE] = 0;
-            if (rs) s_misc[0] = 1;
+        if constexpr (!kDirect) {  // (kDirect: the leader lane of each env publishes these from its registers, in AG)
+            const uint8_t *s_dflag = reinterpret_cast<const uint8_t *>(smem + lo.dflag);
+            for (int e = tid; e < ne; e += T) {
+                int32_t *ev = s_envi + e * ENVI_W;
+                const int rs = (op == OP_OBS) ? 0 : (int)s_dflag[e];
+                ev[ENVI_STEPS] = smem[lo.dsteps + e];
+                ev[ENVI_INACTIVE] = smem[lo.dinact + e];
+                ev[ENVI_RESET] = rs;
+                ev[ENVI_SKIP] = rs;
+                ev[ENVI_DONE] = 0;
+                if (rs) s_misc[0] = 1;
+            }
+            lds_barrier();
         }
-        lds_barrier();
     } else {
         dma_in(smem + lo.gs, reinterpret_cast<const int32_t *>(g_shadow + (size_t)e0 * HW),
                (ne * HW * (int)sizeof(CellT) + 3) >> 2, tid, T);
@@ -454,21 +481,16 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     }
     // ---------------------------------------------------------------- AG: per-agent phases, wave-local
     // Lane -> (env group g, agent a): all N agents of an env sit in one wavefront.  Two implementations:
-    //   kRegAG  (exact-shape builds, N <= 8)  the agents of an env exchange intent, chain links, follower depth and
+    //   kRegAG  (exact-shape builds, N <= 6)  the agents of an env exchange intent, chain links, follower depth and
     //           winners through cross-lane moves (env_gather: DPP quad_perm for N = 4 / 2, ds_bpermute otherwise) and
     //           everything else stays in registers; LDS is read twice (own record; the shelf cells the agent looks at)
     //           and written once (the results).  The common step has no LDS round trip after those two reads.
+    //           With kDirect the own record does not come from LDS either: the lane fetched it from HBM into registers
+    //           at the top of the kernel.
     //   else    the sub-phases exchange through LDS arrays under wave_sync() (any N up to 64, run-time shapes).
-    constexpr bool kRegAG = Cfg::kN >= 1 && Cfg::kN <= 8;
     if constexpr (kRegAG) {
     constexpr int KN = Cfg::kN, KG = 64 / KN, KQ = Cfg::kQ, QS = (KQ + KN - 1) / KN;
     static_assert(Cfg::kH * Cfg::kW < 0x8000, "cell indices are packed into 16 bits");
-    auto sel = [](const int (&arr)[KN], int idx) -> int {  // arr[idx] with the array in registers
-        int r = arr[0];
-#pragma unroll
-        for (int k = 1; k < KN; ++k) r = (idx == k) ? arr[k] : r;
-        return r;
-    };
     for (int eb = wave * KG; eb < ne; eb += nw * KG) {  // wave-uniform
         const int g = lane / KN, a_idx = lane - g * KN;
         const bool mine = (g < KG) && (eb + g < ne);
@@ -479,14 +501,21 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         uint8_t *gA = s_ga + e * HW;
         int32_t *ev = s_envi + e * ENVI_W;
         const int ge = e0 + e;  // global env index
-        // ---- LDS read batch 1: own record, env flags and counters, the queue slots this lane publishes
-        const int ev_skip = ev[ENVI_SKIP], ev_reset = ev[ENVI_RESET];
-        const int ev_steps = ev[ENVI_STEPS], ev_inact = ev[ENVI_INACTIVE];
-        int x = s_ax[i], y = s_ay[i], d = s_dir[i], carry = s_carry[i], deliv = s_deliv[i];
-        const int a_lds = (t == 0) ? s_act[i * AM] : (int)ACT_NOOP;
-        int qv[QS > 0 ? QS : 1];
-#pragma unroll
-        for (int q = 0; q < QS; ++q) qv[q] = s_queue[e * KQ + min(a_idx + q * KN, KQ - 1)];
+        // ---- own record, env flags and counters: from registers (kDirect, first step of the launch), else LDS read batch 1
+        int ev_skip, ev_reset, ev_steps, ev_inact, x, y, d, carry, deliv, a_lds;
+        if (kDirect && t == 0) {
+            ev_skip = ev_reset = r_flag; ev_steps = r_steps; ev_inact = r_inact;
+            x = r_x; y = r_y; d = r_d; carry = r_carry; deliv = r_deliv; a_lds = r_act;
+            if (mine && a_idx == 0) {  // the env's leader lane publishes the flags and counters the other phases read
+                ev[ENVI_STEPS] = r_steps; ev[ENVI_INACTIVE] = r_inact; ev[ENVI_RESET] = r_flag; ev[ENVI_SKIP] = r_flag;
+                ev[ENVI_DONE] = 0;
+                if (r_flag) s_misc[0] = 1;
+            }
+        } else {
+            ev_skip = ev[ENVI_SKIP]; ev_reset = ev[ENVI_RESET]; ev_steps = ev[ENVI_STEPS]; ev_inact = ev[ENVI_INACTIVE];
+            x = s_ax[i]; y = s_ay[i]; d = s_dir[i]; carry = s_carry[i]; deliv = s_deliv[i];
+            a_lds = (t == 0) ? s_act[i * AM] : (int)ACT_NOOP;
+        }
         const bool stepping = (op == OP_STEP) && mine && !ev_skip;
         int a = ACT_NOOP;
         if (mine) {
@@ -506,28 +535,31 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         a = (stepping && (unsigned)a <= 4u) ? a : (int)ACT_NOOP;
         // ------------------------------------------------------------ P1: intent (:825-846), branch-free
         const int st = y * W + x;
+        if (tl_on) { keep_vgpr(st, a); RW_MARK(TL_AG_RECORD); }
         const int fwd = (a == ACT_FORWARD) ? 1 : 0;
         const int dx = fwd & ((d == DIR_RIGHT) ? 1 : 0), dxn = fwd & ((d == DIR_LEFT) ? 1 : 0);
         const int dy = fwd & ((d == DIR_DOWN) ? 1 : 0), dyn = fwd & ((d == DIR_UP) ? 1 : 0);
         const int tx0 = min(max(x + dx - dxn, 0), W - 1);  // clamped at the walls (:105-112)
         const int ty0 = min(max(y + dy - dyn, 0), H - 1);
         const int tg0 = ty0 * W + tx0;
-        // ---- LDS read batch 2 (the last one of the common step): the shelf layer at the target, under the agent and
+        // ---- LDS read batch 2 (the only one of the common kDirect step): the shelf layer at the target, under the agent and
         // on the first two goal cells (start-of-step values), the highway word of the agent's cell
         const int sh_tg = gS[tg0], shelf_here = gS[st], sh_g0 = gS[k_goal0], sh_g1 = gS[k_goal1];
         const uint32_t hw_word = s_hw[st >> 5];
-        // who stands on my target cell, and is it loaded: every agent's (cell | loaded << 16)
-        int pkv[KN];
-        env_gather<KN>(st | (carry ? 0x10000 : 0), lane_base, pkv);
-        int occ = -1, occ_loaded = 0;
+        int qv[QS > 0 ? QS : 1];  // the queue slots this lane publishes in the requested-shelf bitmap
 #pragma unroll
-        for (int k = 0; k < KN; ++k) {
-            const bool hit = (pkv[k] & 0xffff) == tg0;
-            occ = hit ? k : occ;
-            occ_loaded = hit ? (pkv[k] >> 16) : occ_loaded;
-        }
+        for (int q = 0; q < QS; ++q) qv[q] = s_queue[e * KQ + min(a_idx + q * KN, KQ - 1)];
+        // who stands on my target cell, and is it loaded: every agent announces (cell | loaded << 16 | index << 20)
+        int pkv[KN];
+        env_gather<KN>(st | (carry ? 0x10000 : 0) | (a_idx << 20), lane_base, pkv);
+        int occ_w = -1;
+#pragma unroll
+        for (int k = 0; k < KN; ++k) occ_w = ((pkv[k] & 0xffff) == tg0) ? pkv[k] : occ_w;
+        const int occ = occ_w >> 20;  // -1: nobody there
+        const int occ_loaded = (occ_w >> 16) & 1 & ~(occ_w >> 31);
         // a standing shelf blocks a loaded agent (:836-846)
         const bool blocked = (carry != 0) & (tg0 != st) & (sh_tg != 0) & (occ_loaded == 0);
+        if (tl_on) { keep_vgpr((int)blocked, sh_g0 + sh_g1); RW_MARK(TL_AG_CELLS); }
         a = blocked ? (int)ACT_NOOP : a;
         const int tg = blocked ? st : tg0, tx = blocked ? x : tx0, ty = blocked ? y : ty0;
         // successor on the chain: agent index on the target cell, -1 empty, -2 == this agent is stationary
@@ -553,29 +585,32 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             }
         }
         // ------------------------------------------------------------ P2b: winner per contested cell
-        // larger follower depth wins, then the LOWER agent id; only movers compete
+        // larger follower depth wins, then the LOWER agent id; only movers compete.  One word per agent, target cell above
+        // the priority (depth << 4 | 15 - index): agent k beats me iff the cell fields agree and its word is the larger one.
+        // A stationary agent announces a cell nobody can target (0x7fff00 | index) and so neither beats nor is beaten.
+        const uint32_t vme = (nxt != -2) ? ((uint32_t)tg << 8) | ((uint32_t)depth << 4) | (uint32_t)(15 - a_idx)
+                                         : 0x7fff0000u | ((uint32_t)a_idx << 8);
         int kv[KN];
-        env_gather<KN>((nxt != -2) ? (tg | (depth << 16)) : -1, lane_base, kv);
+        env_gather<KN>((int)vme, lane_base, kv);
         int lose = 0;
 #pragma unroll
-        for (int k = 0; k < KN; ++k) {  // (bitwise on purpose: no short-circuit branches)
-            const int tk = kv[k] & 0xffff, dk = kv[k] >> 16;
-            lose |= ((kv[k] != -1) & (tk == tg) & (k != a_idx) & ((dk > depth) | ((dk == depth) & (k < a_idx)))) ? 1 : 0;
-        }
-        lose = (nxt != -2) ? lose : 0;
+        for (int k = 0; k < KN; ++k)  // (bitwise on purpose: no short-circuit branches)
+            lose |= ((((uint32_t)kv[k] ^ vme) < 256u) & ((uint32_t)kv[k] > vme)) ? 1 : 0;
         // ------------------------------------------------------------ P2c: commit (:871-876)
         int commit = (nxt == -1) ? (lose ^ 1) : ((nxt == -2) ? 1 : 0);
         if (chains) {  // walk the chain ahead: i -> nxt(i) -> ... on the gathered links
-            int wv[KN];
-            env_gather<KN>(lose ^ 1, lane_base, wv);
+            // every agent's (nxt + 2 | win << 3) as one nibble of a word every lane of the env holds: following a link is
+            // a shift and a mask (a register array indexed by a run-time agent index would live in scratch memory)
+            const uint32_t links = (uint32_t)env_or<KN>(((nxt + 2) | ((lose ^ 1) << 3)) << (4 * a_idx), lane_base);
             int j = a_idx, hops = 0, ok = 1, cm = 0;
             bool done = nxt < 0;
 #pragma unroll
             for (int h = 0; h < KN; ++h) {
-                const int nj = sel(nxv, j);
-                ok &= sel(wv, j);
+                const uint32_t ent = (links >> (4 * j)) & 0xFu;
+                const int nj = (int)(ent & 7u) - 2;
+                ok &= (int)(ent >> 3);
                 ++hops;
-                const int nnj = sel(nxv, nj);                      // (any value when nj < 0: not used then)
+                const int nnj = (int)((links >> (4 * (nj & 7))) & 7u) - 2;  // nxt of the successor (not used when nj < 0)
                 const bool to_empty = nj == -1;                     // drains into an empty cell
                 const bool back = nj == a_idx;                      // a cycle through me; the 2-swap is refused
                 const bool stuck = (nj >= 0) & (nnj == -2);         // blocked by a stationary agent
@@ -587,6 +622,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             commit = (nxt >= 0) ? cm : commit;
         }
         // ------------------------------------------------------------ P3: apply (:878-899)
+        if (tl_on) { keep_vgpr(commit, lose); RW_MARK(TL_AG_WINNERS); }
         a = commit ? a : (int)ACT_NOOP;  // a failed mover does nothing (:875)
         const bool moved = (a == ACT_FORWARD) & (tg != st);
         x = moved ? tx : x;
@@ -604,7 +640,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         deliv = drop ? 0 : deliv;
         carry = drop ? 0 : (pick ? shelf_here : carry);
         // ---- results to LDS (stores only; nothing below waits for them on the common path)
-        if (stepping) { s_ax[i] = x; s_ay[i] = y; s_dir[i] = d; s_carry[i] = carry; s_deliv[i] = deliv; }
+        if (kDirect ? mine : stepping) { s_ax[i] = x; s_ay[i] = y; s_dir[i] = d; s_carry[i] = carry; s_deliv[i] = deliv; }
         if (mine) s_rew[i] = rew;  // every agent of the chunk gets its reward slot
         if (mine) s_mv[i] = moved ? (st | (tg << 16)) : -1;  // which two cells changed (write-back hand-off)
         if (mcar) gS[st] = 0;  // incremental _recalc_grid (:749-755): clear phase ...
@@ -615,20 +651,13 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // ------------------------------------------------------------ P5: goals, rewards, termination (:903-942)
         // Is there a shelf on a goal cell after the moves?  From registers: a loaded mover that arrived there, or the
         // start-of-step shelf unless a loaded mover took it away.  (More than two goal cells: always take the LDS path.)
-        int mvv[KN];
-        env_gather<KN>(mcar ? (st | (tg << 16)) : -1, lane_base, mvv);
-        bool stay0 = sh_g0 != 0, stay1 = sh_g1 != 0, in0 = false, in1 = false;
-#pragma unroll
-        for (int k = 0; k < KN; ++k) {
-            const bool v = mvv[k] != -1;
-            const int from = mvv[k] & 0xffff, to = mvv[k] >> 16;
-            in0 |= v & (to == k_goal0);
-            in1 |= v & (to == k_goal1);
-            stay0 &= !(v & (from == k_goal0));
-            stay1 &= !(v & (from == k_goal1));
-        }
+        const int gflags = env_or<KN>(mcar ? ((tg == k_goal0 ? 1 : 0) | (tg == k_goal1 ? 2 : 0) | (st == k_goal0 ? 4 : 0) |
+                                               (st == k_goal1 ? 8 : 0)) : 0, lane_base);
+        const bool in0 = gflags & 1, in1 = gflags & 2;
+        const bool stay0 = (sh_g0 != 0) & !(gflags & 4), stay1 = (sh_g1 != 0) & !(gflags & 8);
         const bool goal_hit = (k_n_goals > 2) | in0 | stay0 | ((k_n_goals > 1) & (in1 | stay1));
         const bool leader = stepping && a_idx == 0;
+        if (tl_on) { keep_vgpr((int)goal_hit, (int)moved); RW_MARK(TL_AG_APPLIED); }
         if (wave_any(leader && goal_hit)) {  // wave-uniform; a delivery may be due: the LDS path
             wave_sync();
             if (leader) {
@@ -693,6 +722,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 s_misc[0] = 1;
             }
         }
+        RW_MARK(TL_AG_GOALS);
         // requested-shelf bitmap of the (post-step) queue.  Envs that reset in this launch are included: RS clears and
         // rebuilds their bitmap.
         if (mine) {

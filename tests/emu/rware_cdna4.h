@@ -24,12 +24,22 @@ inline bool wave_any(bool v) {  // every thread of the wave calls this (wave-uni
     return r;
 }
 template <typename... Ts> inline void keep_sgpr(const Ts &...) {}
+inline void keep_vgpr(int, int) {}
 inline uint32_t opaque(uint32_t x) { return x; }
 inline int uniform(int x) { return x; }
 inline void lds_barrier() { pthread_barrier_wait(emu_barrier); }
 inline void wave_sync() { pthread_barrier_wait(emu_wave_barrier); }
 inline void wave_lds_order() { pthread_barrier_wait(emu_wave_barrier); }  // threads are not in lockstep here: a real barrier
 extern int emu_xlane[16][64];
+template <int N>
+inline void env_gather(int v, int lane_base, int (&out)[N]);
+template <int N>
+inline int env_or(int v, int lane_base) {
+    int g[N], r = 0;
+    env_gather<N>(v, lane_base, g);
+    for (int k = 0; k < N; ++k) r |= g[k];
+    return r;
+}
 template <int N>
 inline void env_gather(int v, int lane_base, int (&out)[N]) {  // every thread of the wave calls this
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63u;
