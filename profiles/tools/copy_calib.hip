@@ -7,6 +7,9 @@
 __global__ void copy16(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
+__global__ void copy4(const float* __restrict__ src, float* __restrict__ dst, size_t n) {  // 4 B / lane, like the record loads
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
 int main() {
     const size_t bytes = 1ull << 30;  // 1 GiB each way, far past the 256 MiB Infinity Cache
     float4 *a, *b;
@@ -19,6 +22,13 @@ int main() {
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("copy16 %zu B read + %zu B written in %.3f ms = %.1f GB/s\n", bytes, bytes, ms, 2.0 * bytes / ms / 1e6);
+    }
+    for (int it = 0; it < 3; ++it) {
+        hipEventRecord(e0);
+        copy4<<<8192, 256>>>((const float*)a, (float*)b, bytes / 4);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("copy4  %zu B read + %zu B written in %.3f ms = %.1f GB/s\n", bytes, bytes, ms, 2.0 * bytes / ms / 1e6);
     }
     return 0;
 }
