@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--many", type=int, default=0,
                     help="fused rollout: submit steps in chunks of this many through rw_step_many_device (one launch per chunk, "
                          "env chunk resident in LDS across the steps; open-loop)")
+    ap.add_argument("--submit", choices=["native", "python"], default="native",
+                    help="who issues the per-step launches: the library's loop over the device action tape (rw_step_tape_device, "
+                         "default) or one Python -> ctypes rw_step_device call per step; the launches are identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-rollout measurement (profiling runs)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the fixed 2000-step sustained leg (profiling runs)")
@@ -154,9 +157,11 @@ def main():
                 c = min(many, t_start + n - t, TAPE_STEPS - (t % TAPE_STEPS))
                 eng.step_many_device(base + (t % TAPE_STEPS) * stride, c)
                 t += c
-        else:
+        elif args.submit == "python":
             for t in range(t_start, t_start + n):
                 eng.step_device(base + (t % TAPE_STEPS) * stride)
+        else:  # the same n launches (one rw_step_device per step), issued by the library's native loop
+            eng.step_tape_device(base, TAPE_STEPS, t_start % TAPE_STEPS, n)
 
     def fence():  # barrier + device sync, both sides of every timed region
         torch.cuda.synchronize()
@@ -247,7 +252,9 @@ def main():
                 "grid": [int(info.grid_h), int(info.grid_w)],
                 "parallelism": f"env-shard x{world} (no collective, no RCCL; gloo barrier + MAX of the timings only)",
                 "submit": f"rw_step_many_device x{args.many} (fused rollout, one launch per chunk)" if args.many
-                          else "rw_step_device per step (one launch per step, closed-loop capable)",
+                          else "one rw_step_device launch per step (closed-loop capable kernel), issued by "
+                               + ("rw_step_tape_device's native loop over the device action tape" if args.submit == "native"
+                                  else "one Python/ctypes call per step"),
                 "envs_per_workgroup": int(info.envs_per_workgroup), "threads_per_workgroup": int(info.threads_per_workgroup),
                 "kernel_specialised": bool(info.specialised),
                 "device": info.device_name.decode(), "arch": info.arch_name.decode(),

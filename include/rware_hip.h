@@ -167,6 +167,12 @@ int rw_reset(rw_engine *eng, const uint64_t *seeds, const uint8_t *mask);
 int rw_step(rw_engine *eng, const int32_t *actions_host);
 int rw_step_device(rw_engine *eng, const int32_t *actions_dev);
 
+/* n_steps consecutive rw_step_device launches (ONE kernel launch per step, each ordered behind the previous one on the
+ * engine's stream) from a device-resident action tape int32 [tape_steps][B][N][1+M]: step k reads tape row
+ * (first + k) % tape_steps.  Exactly the launches n_steps calls of rw_step_device would make, issued from one native loop:
+ * replaying recorded actions, open-loop evaluation, benchmarking without per-call host overhead. */
+int rw_step_tape_device(rw_engine *eng, const int32_t *tape_dev, int32_t tape_steps, int32_t first, int32_t n_steps);
+
 /* T consecutive steps from a device-resident action tape int32 [T][B][N] in ONE kernel launch: each
  * workgroup keeps its env chunk in LDS across the T steps, so per step only the actions are read and
  * obs / rewards / terminated written (rollout API; open-loop by construction —

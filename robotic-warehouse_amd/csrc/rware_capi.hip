@@ -89,11 +89,19 @@ using rw_tab::step_kernel_t;
 struct StaticEntry {
     int H, W, N, Q, S, R, E, T;
     int max_B;  // with the default geometry: chosen only for batches up to this size (0 = any); first match wins
+    int image;  // 1: IMAGE / IMAGE_DICT observations (any layer list), 0: FLATTENED
+    int M;      // communication bits the build was made for
     step_kernel_t fn, fn_rollout;
 };
 #define RW_STATIC(H, W, N, Q, S, R, E, T, MAXB)                                                                   \
-    {H, W, N, Q, S, R, E, T, MAXB, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
+    {H, W, N, Q, S, R, E, T, MAXB, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true>}
+#define RW_STATIC_IMAGE(H, W, N, Q, S, R, E, T, MAXB)                                                             \
+    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false, rw::OBS_IMAGE>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true, rw::OBS_IMAGE>}
+#define RW_STATIC_MSG(H, W, N, Q, S, R, E, T, MAXB, M)                                                            \
+    {H, W, N, Q, S, R, E, T, MAXB, 0, M, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, false, rw::OBS_FLATTENED_MSG>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, true, rw::OBS_FLATTENED_MSG>}
 const StaticEntry kStatic[] = {
     // half-size workgroups for batches that leave the CUs short of workgroups at E = 16 (measured:
     // medium-6ag-hard B=8192 9.44 -> 8.62 us, small-4ag B=4096 6.57 -> 6.48 us; slower above these sizes)
@@ -108,6 +116,13 @@ const StaticEntry kStatic[] = {
     RW_STATIC(11, 10, 2, 1, 32, 1, 16, 256, 0),    // rware-tiny-2ag-hard
     RW_STATIC(11, 10, 4, 2, 32, 1, 16, 256, 0),    // rware-tiny-4ag-hard
     RW_STATIC(20, 10, 4, 2, 80, 1, 16, 256, 0),    // rware-small-4ag-hard
+    // the "next" observation kinds callers hit first: IMAGE / IMAGE_DICT (any layer list, directional
+    // or not) and FLATTENED with 1 or 2 communication bits, on the two smallest BASELINE tasks
+    RW_STATIC_IMAGE(20, 10, 4, 4, 80, 1, 16, 256, 0),
+    RW_STATIC_IMAGE(11, 10, 2, 2, 32, 1, 16, 256, 0),
+    RW_STATIC_MSG(20, 10, 4, 4, 80, 1, 16, 256, 0, 1),
+    RW_STATIC_MSG(20, 10, 4, 4, 80, 1, 16, 256, 0, 2),
+    RW_STATIC_MSG(11, 10, 2, 2, 32, 1, 16, 256, 0, 2),
     // size-static builds (N == 0: any agent count / queue length): every other registered id, sensor_range 1
     RW_STATIC(11, 10, 0, 0, 32, 1, 16, 256, 0),    // rware-tiny-*
     RW_STATIC(20, 10, 0, 0, 80, 1, 16, 256, 0),    // rware-small-*
@@ -115,6 +130,8 @@ const StaticEntry kStatic[] = {
     RW_STATIC(29, 16, 0, 0, 224, 1, 16, 256, 0),   // rware-large-*
 };
 #undef RW_STATIC
+#undef RW_STATIC_IMAGE
+#undef RW_STATIC_MSG
 
 int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false) {
     la.op = op | (la.timeline ? rw::OP_FLAG_TIMELINE : 0);
@@ -326,13 +343,14 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         eng->kernel = pick(false, eng->wide, eng->image, eng->msg_bits > 0);
         eng->kernel_rollout = pick(true, eng->wide, eng->image, eng->msg_bits > 0);
     }
-    if (!eng->image && eng->msg_bits == 0) {  // (the image / message kernels are generic builds)
+    if (!(eng->image && eng->msg_bits > 0)) {  // (image + messages together: generic builds only)
         // Pick a specialised build: exact-shape entries before size-static ones, first match wins.
         const bool geom_default = cfg->envs_per_workgroup == 0 && cfg->threads_per_workgroup == 0;
         const StaticEntry *best = nullptr;
         for (int exact = 1; exact >= 0 && !best; --exact)
             for (const StaticEntry &se : kStatic) {
                 if ((se.N != 0) != (exact != 0)) continue;
+                if (se.image != (eng->image ? 1 : 0) || se.M != eng->msg_bits) continue;
                 const bool shape = se.H == H && se.W == W && se.S == S && se.R == R && (se.N == 0 || (se.N == N && se.Q == Q));
                 if (!shape || B % se.E != 0) continue;
                 if (geom_default ? (se.max_B == 0 || B <= se.max_B) : (E == se.E && T == se.T)) { best = &se; break; }
@@ -537,6 +555,22 @@ int rw_step_device(rw_engine *eng, const int32_t *actions_dev) {
     rw::LaunchArgs la = eng->la;
     la.actions = actions_dev;
     return launch(eng, la, rw::OP_STEP);
+}
+
+int rw_step_tape_device(rw_engine *eng, const int32_t *tape_dev, int32_t tape_steps, int32_t first, int32_t n_steps) {
+    // n_steps consecutive rw_step_device launches from a device-resident action tape int32 [tape_steps][B][N][1+M]: step k
+    // reads row (first + k) % tape_steps.  Same launches as n_steps calls of rw_step_device — one per step, each ordered
+    // behind the previous one on the engine's stream — issued from one native loop instead of one host call each.
+    if (!eng || !tape_dev || tape_steps < 1 || first < 0 || n_steps < 0) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    const size_t row = (size_t)eng->prm.B * eng->prm.N * (1 + eng->msg_bits);
+    rw::LaunchArgs la = eng->la;
+    for (int32_t k = 0; k < n_steps; ++k) {
+        la.actions = tape_dev + (size_t)((first + k) % tape_steps) * row;
+        const int rc = launch(eng, la, rw::OP_STEP);
+        if (rc != RW_OK) return rc;
+    }
+    return RW_OK;
 }
 
 int rw_step(rw_engine *eng, const int32_t *actions_host) {

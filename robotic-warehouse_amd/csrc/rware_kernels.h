@@ -204,11 +204,11 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
 // N_ == 0 is a "size-static" build: grid shape and geometry folded in, agent count / queue length read
 // at run time — one such build covers every registered id of a warehouse size.
 struct DynamicCfg {
-    static constexpr int kH = 0, kW = 0, kN = 0, kQ = 0, kS = 0, kE = 0, kT = 0;
+    static constexpr int kH = 0, kW = 0, kN = 0, kQ = 0, kS = 0, kE = 0, kT = 0, kM = 0;
 };
-template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_>
+template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_, int M_ = 0>  // M_: communication bits (the _MSG kernels)
 struct StaticCfg {
-    static constexpr int kH = H_, kW = W_, kN = N_, kQ = Q_, kS = S_, kE = E_, kT = T_;
+    static constexpr int kH = H_, kW = W_, kN = N_, kQ = Q_, kS = S_, kE = E_, kT = T_, kM = M_;
 };
 
 // Asynchronous flat dword copy HBM -> LDS through the LDS-DMA path.  dwordx4 pieces (1 KiB per wave
@@ -264,7 +264,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int op = la.op & 0xff;
     const bool tl_on = (la.op & OP_FLAG_TIMELINE) != 0;  // the flag is preloaded; la.timeline itself is fetched only when set
     // observation row length: a compile-time constant except with communication bits
-    const int M = kMsg ? p.msg_bits : 0, AM = 1 + M, CW = 7 + M;
+    static_assert(kMsg || Cfg::kM == 0, "communication bits need a _MSG observation kind");
+    const int M = kMsg ? (Cfg::kM ? Cfg::kM : p.msg_bits) : 0, AM = 1 + M, CW = 7 + M;
     const int L = kMsg ? 8 + CW * CELLS : L0;
     // words of the observation bit string per agent (the image string holds n_layers * CELLS bits per agent)
     const int OW = kImage ? max(OW0, (p.n_layers * CELLS + 31) / 32) : kMsg ? (L + 31) / 32 : OW0;
@@ -360,13 +361,14 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // number of 16-byte pieces, so the chunk is ONE linear stream — thread t moves LDS piece t;
         // its HBM source is picked from the segment table (all pointers fetched in one scalar batch).
         static_assert((Cfg::kE * Cfg::kN) % 4 == 0 && (Cfg::kE * Cfg::kQ) % 4 == 0 && Cfg::kE % 4 == 0, "chunk not 16-byte granular");
+        static_assert(!kMsg || Cfg::kN == 0 || Cfg::kM != 0, "an exact-shape _MSG build needs its communication bits at compile time");
         static_assert((Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0, "shelf chunk not 16-byte granular");
         const char *src[12] = {
             reinterpret_cast<const char *>(g_shadow + (size_t)e0 * HW),
             reinterpret_cast<const char *>(p.ax + (size_t)e0 * N), reinterpret_cast<const char *>(p.ay + (size_t)e0 * N),
             reinterpret_cast<const char *>(p.adir + (size_t)e0 * N), reinterpret_cast<const char *>(p.acarry + (size_t)e0 * N),
             reinterpret_cast<const char *>(p.adeliv + (size_t)e0 * N),
-            reinterpret_cast<const char *>((op == OP_STEP ? la.actions : p.ax) + (size_t)e0 * N),
+            reinterpret_cast<const char *>(op == OP_STEP ? la.actions + (size_t)e0 * N * AM : p.ax + (size_t)e0 * N),
             reinterpret_cast<const char *>(p.queue + (size_t)e0 * Q), reinterpret_cast<const char *>(p.highway_bits),
             reinterpret_cast<const char *>(p.steps + e0), reinterpret_cast<const char *>(p.inactive + e0),
             reinterpret_cast<const char *>(flag_src + e0)};
@@ -384,6 +386,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 for (int c = 0; c < pieces; c += 64, ++job)
                     if (job % nw == wave_s && c + lane < pieces)
                         lds_dma_b128(src[k] + (size_t)(c + lane) * 16, smem + seg[k] + 4 * c);
+            }
+            if constexpr (kMsg) {  // the agents' stored messages: a 13th array, outside the contiguous block
+                const int pieces = (Cfg::kE * Cfg::kN) >> 2;
+                for (int c = 0; c < pieces; c += 64, ++job)
+                    if (job % nw == wave_s && c + lane < pieces)
+                        lds_dma_b128(reinterpret_cast<const char *>(p.amsg + (size_t)e0 * N) + (size_t)(c + lane) * 16, smem + lo.msg + 4 * c);
             }
         } else {  // N, Q are run-time values: thread t moves LDS piece t, its source picked per lane
             const int pieces = (lo.dma_end - lo.gs) >> 2;

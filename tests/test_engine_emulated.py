@@ -86,6 +86,8 @@ def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
     ("tiny-2ag", (0, 0), 4),           # pair exchange (N = 2)
     ("medium-6ag-hard", (0, 0), 8),    # ds_bpermute exchange (N = 6), 8-env build
     ("large-16ag-sr2", (0, 0), 4),     # exact-shape build with the LDS exchange (N = 16)
+    ("img-small-4ag-directional", (0, 0), 16),   # exact-shape IMAGE build
+    ("msg2-small-4ag", (0, 0), 16),              # exact-shape build with 2 communication bits
 ])
 def test_emulated_exact_shape_builds_match_reference_golden(name, geom, tile):
     """The golden traces of the unmodified reference, replayed on the EXACT-SHAPE kernel builds (the ones the BASELINE
@@ -437,3 +439,32 @@ def test_communication_bits_rollout_and_state():
     for k in so:
         assert np.array_equal(st[k], so[k]), k
     env.close()
+
+
+def test_step_tape_device_equals_stepwise_calls():
+    """rw_step_tape_device: n per-step launches from a device action tape (wrapping around) == the same steps submitted
+    one host call at a time."""
+    import ctypes as C
+    kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
+    kw["max_steps"] = 9
+    B, TS = 6, 5
+    a = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **kw)
+    b = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **kw)
+    a.reset(seed=11)
+    b.reset(seed=11)
+    tape = np.random.default_rng(0).integers(0, 5, size=(TS, B, 2), dtype=np.int32)
+    eng = a.engines[0]
+    d = C.c_void_p()
+    eng._check(eng.lib.rw_device_malloc(eng._h, tape.nbytes, C.byref(d)))
+    eng._check(eng.lib.rw_copy_to_device(eng._h, d, tape.ctypes.data, tape.nbytes))
+    eng.step_tape_device(d.value, TS, 3, 12)          # rows 3, 4, 0, 1, 2, 3, ...
+    eng.sync()
+    for k in range(12):
+        obs, rew, term, _, _ = b.step(tape[(3 + k) % TS])
+    assert np.array_equal(a.observations(), obs)
+    assert np.array_equal(a.engines[0].read("rewards"), rew)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    eng.lib.rw_device_free(eng._h, d)
+    a.close(); b.close()
