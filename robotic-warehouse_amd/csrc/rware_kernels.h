@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 ev[ENVI_RESET] = rs;
                 ev[ENVI_SKIP] = rs;
                 ev[ENVI_DONE] = 0;
-                if (rs) s_misc[0] = 1;
+                if (rs) atomicOr(&s_misc[0], 1);
             }
             lds_barrier();
         }
@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             ev[ENVI_RESET] = rs;
             ev[ENVI_SKIP] = rs;  // an env that resets in this call does not step
             ev[ENVI_DONE] = 0;
-            if (rs) s_misc[0] = 1;
+            if (rs) atomicOr(&s_misc[0], 1);
         }
         RW_MARK(TL_ENV_LOADED);
         __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             ev[ENVI_RESET] = rs;
             ev[ENVI_SKIP] = rs;
             ev[ENVI_DONE] = 0;
-            if (rs) s_misc[0] = 1;
+            if (rs) atomicOr(&s_misc[0], 1);
         }
         lds_barrier();
     }
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             if (mine && a_idx == 0) {  // the env's leader lane publishes the flags and counters the other phases read
                 ev[ENVI_STEPS] = r_steps; ev[ENVI_INACTIVE] = r_inact; ev[ENVI_RESET] = r_flag; ev[ENVI_SKIP] = r_flag;
                 ev[ENVI_DONE] = 0;
-                if (r_flag) s_misc[0] = 1;
+                if (r_flag) atomicOr(&s_misc[0], 1);
             }
         } else {
             ev_skip = ev[ENVI_SKIP]; ev_reset = ev[ENVI_RESET]; ev_steps = ev[ENVI_STEPS]; ev_inact = ev[ENVI_INACTIVE];
@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 ev[ENVI_DONE] = done;
                 if (done && k_autoreset == AR_SAME_STEP) {
                     ev[ENVI_RESET] = 1;
-                    s_misc[0] = 1;
+                    atomicOr(&s_misc[0], 1);
                 }
             }
             wave_sync();
@@ -727,7 +727,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             ev[ENVI_DONE] = done;
             if (done && k_autoreset == AR_SAME_STEP) {
                 ev[ENVI_RESET] = 1;
-                s_misc[0] = 1;
+                atomicOr(&s_misc[0], 1);
             }
         }
         RW_MARK(TL_AG_GOALS);
@@ -927,7 +927,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             ev[ENVI_DONE] = done;
             if (done && k_autoreset == AR_SAME_STEP) {
                 ev[ENVI_RESET] = 1;
-                s_misc[0] = 1;
+                atomicOr(&s_misc[0], 1);
             }
         }
         wave_sync();
@@ -1079,13 +1079,16 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     const int st = mv & 0xffff, tg = mv >> 16, carry = s_carry[i];
                     const size_t ge = (size_t)(e0 + e);
                     int32_t *hA = p.grid + ge * 2 * HW, *hS = hA + HW;
-                    hA[st] = s_ga[e * HW + st] & 0x7f;
+                    // the cell it left: cleared unless a follower stepped onto it — the follower then writes that cell
+                    // itself (as its `tg`), so every grid cell has exactly one writer
+                    if ((s_ga[e * HW + st] & 0x7f) == 0) hA[st] = 0;
                     hA[tg] = (i - e * N) + 1;
                     if (carry) {
-                        const CellT s_at_st = s_gs[e * HW + st];
-                        hS[st] = s_at_st;
+                        if (s_gs[e * HW + st] == 0) {
+                            hS[st] = 0;
+                            g_shadow[ge * HW + st] = 0;
+                        }
                         hS[tg] = carry;
-                        g_shadow[ge * HW + st] = s_at_st;
                         g_shadow[ge * HW + tg] = (CellT)carry;
                     }
                 }

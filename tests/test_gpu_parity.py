@@ -431,6 +431,36 @@ def test_full_batch_soak_every_env_against_oracle(env_id, extra, B, T):
     env.close()
 
 
+def test_hip_graph_capture_of_per_step_launches():
+    """rw_step_device only enqueues a kernel, so a training loop can capture env steps (with its policy) in a HIP graph:
+    100 steps captured once and replayed == the same steps launched one by one."""
+    import torch
+    B, K = 2048, 100
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        genv = rware_amd.WarehouseVecEnv(B, output="torch", **kw)
+        penv = rware_amd.WarehouseVecEnv(B, output="torch", **kw)
+        genv.reset(seed=21)
+        penv.reset(seed=21)
+        tape = torch.randint(0, 5, (K, B, 4), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            genv.engines[0].step_tape_device(tape.data_ptr(), K, 0, K)
+        for rep in range(3):   # 300 steps, across a mass autoreset... max_steps = 500: no; replay thrice anyway
+            g.replay()
+            for t in range(K):
+                penv.engines[0].step_device(tape[t].data_ptr())
+        torch.cuda.synchronize()
+        for name in ("obs", "rewards", "terminated"):
+            assert torch.equal(genv.device_tensor(name), penv.device_tensor(name)), name
+    a, b = genv.get_state(), penv.get_state()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    genv.close(); penv.close()
+
+
 def _check_bench_line(out, n_gpus, steps, warmup, batch):
     import json
     assert out.returncode == 0, out.stderr[-2000:]
