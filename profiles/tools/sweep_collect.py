@@ -42,6 +42,32 @@ def step_kernel_trace(db):
     return best
 
 
+def step_kernel_dispatches(db):
+    """Per-dispatch view of the most-called step kernel: rocprofv3 stamps a dispatch that starts right behind its
+    predecessor with start == the predecessor's end, so its duration is the whole launch-to-launch interval; a dispatch
+    the host (slowed by the profiler) submitted late starts after an idle gap on a cold chip and runs longer.  Returns the
+    statistics of both groups."""
+    per = {}
+    for name, start, end in rows(db, "select name, start, end from kernels order by start"):
+        if "rware_step_kernel" in name:
+            per.setdefault(name, []).append((start, end))
+    if not per:
+        return None
+    name = max(per, key=lambda k: len(per[k]))
+    se = per[name][20:]  # (skip the reset launch and the first warm-up launches)
+    if len(se) < 10:
+        return None
+    dur = [(e - s) / 1000.0 for s, e in se]
+    gap = [0.0] + [(se[i + 1][0] - se[i][1]) / 1000.0 for i in range(len(se) - 1)]
+    b2b = [d for d, g in zip(dur, gap) if g < 0.2]
+    late = [d for d, g in zip(dur, gap) if g >= 0.2]
+    return {"dispatches": len(dur), "mean_us": statistics.mean(dur), "median_us": statistics.median(dur),
+            "back_to_back": {"n": len(b2b), "median_us": statistics.median(b2b) if b2b else None,
+                             "mean_us": statistics.mean(b2b) if b2b else None},
+            "after_an_idle_gap": {"n": len(late), "median_us": statistics.median(late) if late else None,
+                                  "median_gap_us": statistics.median([g for g in gap if g >= 0.2]) if late else None}}
+
+
 def step_kernel_pmc(db, counter):
     """median per-dispatch value (KiB) of `counter` over the dispatches of the most-dispatched step kernel, + its resources"""
     per = {}
@@ -51,7 +77,8 @@ def step_kernel_pmc(db, counter):
             per.setdefault(name, []).append((val, vg, sg, lds, wg, grid))
     if not per:
         return None
-    name = max(per, key=lambda k: len(per[k]))
+    step = [k for k in per if "rware_step_kernel" in k]
+    name = max(step or list(per), key=lambda k: len(per[k]))
     vals = [v[0] for v in per[name]]
     r = per[name][0]
     return {"kernel": name, "dispatches": len(vals), "median_KiB": statistics.median(vals), "min_KiB": min(vals), "max_KiB": max(vals),
@@ -107,6 +134,11 @@ def main(out, tag):
         steps_per_launch = 64 if "fused" in name else 1
         if kt:
             rec["kernel_trace"] = {"kernel": kt[0][:100], "calls": kt[1], "avg_us": kt[2], "us_per_step": kt[2] / steps_per_launch}
+            disp = step_kernel_dispatches(db)
+            if disp:
+                rec["kernel_trace"]["per_dispatch"] = disp
+                if disp["back_to_back"]["median_us"]:
+                    rec["kernel_trace"]["us_per_step_back_to_back"] = disp["back_to_back"]["median_us"] / steps_per_launch
         pm = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             db = find_db(os.path.join(d, f"pmc_{c}"))
@@ -114,6 +146,9 @@ def main(out, tag):
                 pm[c] = step_kernel_pmc(db, c)
         rec["pmc"] = pm
         us = rec.get("kernel_trace", {}).get("us_per_step")
+        us_b2b = rec.get("kernel_trace", {}).get("us_per_step_back_to_back")
+        if us_b2b:
+            rec["roofline_on_algorithmic_bytes_back_to_back"] = {"GBps": a_bytes / us_b2b / 1e3, "frac_of_8TBps": a_bytes / us_b2b / 1e3 / 8000.0}
         if us:
             rec["roofline_on_algorithmic_bytes"] = {"GBps": a_bytes / us / 1e3, "frac_of_8TBps": a_bytes / us / 1e3 / 8000.0,
                                                     "frac_of_6.29TBps": a_bytes / us / 1e3 / 6290.0}
@@ -149,7 +184,9 @@ def main(out, tag):
                             "(MI355X_MICROARCH.md, re-measured by copy_calib.hip in the same sweep)",
                    "entries": traffic}, fh, indent=1)
     lines = [f"sweep {tag}: kernel sources {sha}", f"calibration: {json.dumps({**cal, **factors})}", "",
-             f"{'config':28s} {'us/step (trace)':>15s} {'us/step (events)':>16s} {'A MB':>8s} {'phys MB':>8s} {'frac A/8T':>9s} {'frac phys/8T':>12s} {'phys/6.29T':>10s}"]
+             "us/step: 'trace avg' = rocprofv3 --stats average; 'b2b' = median of the dispatches that started right behind their predecessor",
+             "(the others were submitted late by the profiled host and ran on an idle, cold chip); 'events' = HIP events in the same profiled run.",
+             f"{'config':28s} {'trace avg':>10s} {'b2b':>8s} {'late n':>7s} {'events':>8s} {'A MB':>8s} {'phys MB':>8s} {'frac A/8T':>9s} {'frac phys/8T':>12s} {'phys/6.29T':>10s}"]
     for r in records:
         if "error" in r:
             lines.append(f"{r['config']:28s} {r['error']}")
@@ -159,7 +196,10 @@ def main(out, tag):
         fa = r.get("roofline_on_algorithmic_bytes", {}).get("frac_of_8TBps", float("nan"))
         fp = r.get("roofline_on_physical_bytes", {}).get("frac_of_8TBps", float("nan"))
         fm = r.get("roofline_on_physical_bytes", {}).get("frac_of_6.29TBps", float("nan"))
-        lines.append(f"{r['config']:28s} {us:15.3f} {r['event_ms_per_step'] * 1e3:16.3f} {r['algorithmic_bytes_per_launch'] / 1e6:8.2f} "
+        kt = r.get("kernel_trace", {})
+        b2b = kt.get("us_per_step_back_to_back", float("nan"))
+        late = kt.get("per_dispatch", {}).get("after_an_idle_gap", {}).get("n", 0)
+        lines.append(f"{r['config']:28s} {us:10.3f} {b2b:8.3f} {late:7d} {r['event_ms_per_step'] * 1e3:8.3f} {r['algorithmic_bytes_per_launch'] / 1e6:8.2f} "
                      f"{ph / 1e6:8.2f} {fa:9.3f} {fp:12.3f} {fm:10.3f}")
     with open(os.path.join(ROOT, "gpurun_out", f"{tag}_sweep.txt"), "w") as fh:
         fh.write("\n".join(lines) + "\n")

@@ -39,6 +39,13 @@ __device__ __forceinline__ void keep_sgpr(Ts... v) {
 }
 // keep_vgpr(a, b): the values must have been computed at this point (profiling marks: pins work in front of a time stamp)
 __device__ __forceinline__ void keep_vgpr(int a, int b) { asm volatile("" ::"v"(a), "v"(b)); }
+// keep_sgpr_ptr(p, q, ...): the same for (wave-uniform) pointers
+template <typename T>
+__device__ __forceinline__ void keep_sgpr_ptr1(const T *p) { asm volatile("" ::"s"(p)); }
+template <typename... Ts>
+__device__ __forceinline__ void keep_sgpr_ptr(Ts... p) {
+    (keep_sgpr_ptr1(p), ...);
+}
 // opaque(x): the value, with everything the optimiser knew about its bits forgotten
 __device__ __forceinline__ uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
 // uniform(x): tells the compiler a value is wave-uniform (v_readfirstlane), so tests on it become scalar branches

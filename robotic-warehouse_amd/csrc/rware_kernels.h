@@ -60,6 +60,11 @@
 
 #include "rware_pcg64.h"
 
+// RW_RARE(c): c, marked unlikely — the compiler lays the guarded block out of line, so the common path stays one
+// sequential run of code (every launch starts with a cold instruction cache: a taken branch over a big rare block is a
+// fetch miss for the first wavefront that gets there)
+#define RW_RARE(c) __builtin_expect(!!(c), 0)
+
 namespace rw {
 
 enum : int { OP_STEP = 0, OP_RESET = 1, OP_OBS = 2 };
@@ -286,6 +291,20 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // agent phases with cross-lane exchange in registers (see AG); kDirect: own record fetched straight into registers
     constexpr bool kRegAG = Cfg::kN >= 1 && Cfg::kN <= 6;  // (N + 2 link codes must fit 3 bits)
     constexpr bool kDirect = kRegAG && Cfg::kE != 0 && !kMsg;
+    // ONE scalar batch, first thing in the kernel, for every field of the parameter block that the stage-in and the agent
+    // phases read: left to itself hipcc fetches each field where it is first used — three dependent scalar-cache round
+    // trips in the prologue (every launch starts with cold caches) and more inside the agent phases, which run on one
+    // wavefront and cannot hide them.  keep_sgpr*() pins the values in scalar registers right here.
+    CellT *const g_shadow = reinterpret_cast<CellT *>(p.shelf_shadow);
+    int32_t *const q_ax = p.ax, *const q_ay = p.ay, *const q_dir = p.adir, *const q_carry = p.acarry, *const q_deliv = p.adeliv;
+    int32_t *const q_queue = p.queue, *const q_steps = p.steps, *const q_inact = p.inactive;
+    const uint32_t *const q_hw = p.highway_bits;
+    const uint8_t *const q_need = p.need_reset;
+    const int k_reward_type = p.reward_type, k_max_inactivity = p.max_inactivity, k_max_steps = p.max_steps;
+    const int k_autoreset = p.autoreset, k_n_goals = p.n_goals;
+    const int k_goal0 = p.goal_cells[0], k_goal1 = p.goal_cells[1];
+    keep_sgpr_ptr(g_shadow, q_ax, q_ay, q_dir, q_carry, q_deliv, q_queue, q_steps, q_inact, q_hw, q_need);
+    keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1);
     // wavefront 3 = service wave after the agent phases (see WB); pays off while the observation of a workgroup is
     // small enough that three wavefronts expand it as fast as the stores drain (measured: small-4ag 8.91 -> 8.79 us,
     // fused 4.93 -> 4.56; medium-6ag-hard 8.56 -> 8.40; large-16ag r=2 with 23 K floats per workgroup 43.6 -> 46.1, so not there)
@@ -293,7 +312,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int TW = split ? T - 64 : T;        // threads that gather window rows and expand the observation
     const uint32_t mN = Cfg::kN ? rw_magic18(Cfg::kN) : p.magic_n;
     // optional per-workgroup phase stamps (100 MHz wall clock); one scalar branch per mark when off
-#define RW_MARK(k) do { if (tl_on && tid == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + (k)] = wall_clock64(); } while (0)
+#define RW_MARK(k) do { if (RW_RARE(tl_on) && tid == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + (k)] = wall_clock64(); } while (0)
     RW_MARK(TL_START);
 
     const LdsLayout lo = make_lds_layout(E, N, Q, HW, SW, OW, (int)sizeof(CellT), AM);
@@ -311,7 +330,6 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     uint32_t *s_obits = reinterpret_cast<uint32_t *>(smem + lo.obits);
     int32_t *s_envi = smem + lo.envi;
     int32_t *s_misc = smem + lo.misc;
-    CellT *g_shadow = reinterpret_cast<CellT *>(p.shelf_shadow);
     auto on_highway = [&](int c) -> bool { return (s_hw[c >> 5] >> (c & 31)) & 1u; };
     auto coordf = [&](int k, int v) -> float {
         if (p.normalised) return (float)((double)v / (double)((k == 0 ? W : H) - 1));  // :636-638
@@ -332,7 +350,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // first thing in the kernel: the loads fly beside the clear and the stage-in DMA, are complete at the barrier that
     // drains the DMA, and the agent phases start without an LDS read.  The LDS copies the later phases read (window
     // gather, write-back) are written by the agent lanes together with their results.
-    const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : p.need_reset;  // OP_RESET: all-ones when no mask was given
+    const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : q_need;  // OP_RESET: all-ones when no mask was given
     int r_x = 0, r_y = 0, r_d = 0, r_carry = 0, r_deliv = 0, r_act = ACT_NOOP, r_flag = 0, r_steps = 0, r_inact = 0;
     if constexpr (kDirect) {
         constexpr int KN = Cfg::kN, KG = 64 / KN;
@@ -341,21 +359,15 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         if (g < KG && le < Cfg::kE) {
             const int ge = e0 + le;
             const size_t gi = (size_t)ge * KN + a_idx;
-            r_x = p.ax[gi]; r_y = p.ay[gi]; r_d = p.adir[gi]; r_carry = p.acarry[gi]; r_deliv = p.adeliv[gi];
+            r_x = q_ax[gi]; r_y = q_ay[gi]; r_d = q_dir[gi]; r_carry = q_carry[gi]; r_deliv = q_deliv[gi];
             if (op == OP_STEP) r_act = la.actions[gi];
             r_flag = (op == OP_OBS) ? 0 : (int)flag_src[ge];
-            r_steps = p.steps[ge];
-            r_inact = p.inactive[ge];
+            r_steps = q_steps[ge];
+            r_inact = q_inact[ge];
         }
     }
     clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
     RW_MARK(TL_ZEROED);
-    // The per-config scalars the agent phases need (P3, P5) are fetched HERE, so their latency hides under the
-    // stage-in; hipcc would otherwise issue each s_load where it is first used — in the middle of the agent
-    // phases, which run on one wavefront and cannot hide it.  keep_sgpr() pins the values before the barrier.
-    const int k_reward_type = p.reward_type, k_max_inactivity = p.max_inactivity, k_max_steps = p.max_steps;
-    const int k_autoreset = p.autoreset, k_n_goals = p.n_goals;
-    const int k_goal0 = p.goal_cells[0], k_goal1 = p.goal_cells[1];
     if constexpr (Cfg::kE != 0) {
         // Static build: every DMA destination is contiguous in LDS and every source chunk is a whole
         // number of 16-byte pieces, so the chunk is ONE linear stream — thread t moves LDS piece t;
@@ -365,12 +377,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         static_assert((Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0, "shelf chunk not 16-byte granular");
         const char *src[12] = {
             reinterpret_cast<const char *>(g_shadow + (size_t)e0 * HW),
-            reinterpret_cast<const char *>(p.ax + (size_t)e0 * N), reinterpret_cast<const char *>(p.ay + (size_t)e0 * N),
-            reinterpret_cast<const char *>(p.adir + (size_t)e0 * N), reinterpret_cast<const char *>(p.acarry + (size_t)e0 * N),
-            reinterpret_cast<const char *>(p.adeliv + (size_t)e0 * N),
-            reinterpret_cast<const char *>(op == OP_STEP ? la.actions + (size_t)e0 * N * AM : p.ax + (size_t)e0 * N),
-            reinterpret_cast<const char *>(p.queue + (size_t)e0 * Q), reinterpret_cast<const char *>(p.highway_bits),
-            reinterpret_cast<const char *>(p.steps + e0), reinterpret_cast<const char *>(p.inactive + e0),
+            reinterpret_cast<const char *>(q_ax + (size_t)e0 * N), reinterpret_cast<const char *>(q_ay + (size_t)e0 * N),
+            reinterpret_cast<const char *>(q_dir + (size_t)e0 * N), reinterpret_cast<const char *>(q_carry + (size_t)e0 * N),
+            reinterpret_cast<const char *>(q_deliv + (size_t)e0 * N),
+            reinterpret_cast<const char *>(op == OP_STEP ? la.actions + (size_t)e0 * N * AM : q_ax + (size_t)e0 * N),
+            reinterpret_cast<const char *>(q_queue + (size_t)e0 * Q), reinterpret_cast<const char *>(q_hw),
+            reinterpret_cast<const char *>(q_steps + e0), reinterpret_cast<const char *>(q_inact + e0),
             reinterpret_cast<const char *>(flag_src + e0)};
         const int seg[13] = {lo.gs, lo.ax, lo.ay, lo.dir, lo.carry, lo.deliv, lo.act, lo.queue, lo.hw,
                              lo.dsteps, lo.dinact, lo.dflag, lo.dma_end};  // dword offsets, all multiples of 4
@@ -426,22 +438,22 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     } else {
         dma_in(smem + lo.gs, reinterpret_cast<const int32_t *>(g_shadow + (size_t)e0 * HW),
                (ne * HW * (int)sizeof(CellT) + 3) >> 2, tid, T);
-        dma_in(s_ax, p.ax + (size_t)e0 * N, nea, tid, T);
-        dma_in(s_ay, p.ay + (size_t)e0 * N, nea, tid, T);
-        dma_in(s_dir, p.adir + (size_t)e0 * N, nea, tid, T);
-        dma_in(s_carry, p.acarry + (size_t)e0 * N, nea, tid, T);
-        dma_in(s_deliv, p.adeliv + (size_t)e0 * N, nea, tid, T);
-        dma_in(s_queue, p.queue + (size_t)e0 * Q, ne * Q, tid, T);
+        dma_in(s_ax, q_ax + (size_t)e0 * N, nea, tid, T);
+        dma_in(s_ay, q_ay + (size_t)e0 * N, nea, tid, T);
+        dma_in(s_dir, q_dir + (size_t)e0 * N, nea, tid, T);
+        dma_in(s_carry, q_carry + (size_t)e0 * N, nea, tid, T);
+        dma_in(s_deliv, q_deliv + (size_t)e0 * N, nea, tid, T);
+        dma_in(s_queue, q_queue + (size_t)e0 * Q, ne * Q, tid, T);
         if (op == OP_STEP) dma_in(s_act, la.actions + (size_t)e0 * N * AM, nea * AM, tid, T);
         if (kMsg) dma_in(s_msg, p.amsg + (size_t)e0 * N, nea, tid, T);
-        dma_in(smem + lo.hw, reinterpret_cast<const int32_t *>(p.highway_bits), (HW + 31) / 32, tid, T);
+        dma_in(smem + lo.hw, reinterpret_cast<const int32_t *>(q_hw), (HW + 31) / 32, tid, T);
         RW_MARK(TL_DMA_ISSUED);
         lds_barrier();  // orders the s_misc clear above before the flag writes below
         for (int e = tid; e < ne; e += T) {
             int32_t *ev = s_envi + e * ENVI_W;
             const int rs = (op == OP_OBS) ? 0 : (int)flag_src[e0 + e];
-            ev[ENVI_STEPS] = p.steps[e0 + e];
-            ev[ENVI_INACTIVE] = p.inactive[e0 + e];
+            ev[ENVI_STEPS] = q_steps[e0 + e];
+            ev[ENVI_INACTIVE] = q_inact[e0 + e];
             ev[ENVI_RESET] = rs;
             ev[ENVI_SKIP] = rs;  // an env that resets in this call does not step
             ev[ENVI_DONE] = 0;
@@ -539,11 +551,11 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             }
             if (act_prefetch && t + 1 < n_steps) a_pref = (act_t + la.act_stride)[(size_t)ge * KN + a_idx];
         }
-        if (stepping && (unsigned)a > 4u) atomicOr(p.status, STATUS_INVALID_ACTION);  // Action(a) raises (:814); runs as NOOP
+        if (RW_RARE(stepping && (unsigned)a > 4u)) atomicOr(p.status, STATUS_INVALID_ACTION);  // Action(a) raises (:814); runs as NOOP
         a = (stepping && (unsigned)a <= 4u) ? a : (int)ACT_NOOP;
         // ------------------------------------------------------------ P1: intent (:825-846), branch-free
         const int st = y * W + x;
-        if (tl_on) { keep_vgpr(st, a); RW_MARK(TL_AG_RECORD); }
+        if (RW_RARE(tl_on)) { keep_vgpr(st, a); RW_MARK(TL_AG_RECORD); }
         const int fwd = (a == ACT_FORWARD) ? 1 : 0;
         const int dx = fwd & ((d == DIR_RIGHT) ? 1 : 0), dxn = fwd & ((d == DIR_LEFT) ? 1 : 0);
         const int dy = fwd & ((d == DIR_DOWN) ? 1 : 0), dyn = fwd & ((d == DIR_UP) ? 1 : 0);
@@ -567,7 +579,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         const int occ_loaded = (occ_w >> 16) & 1 & ~(occ_w >> 31);
         // a standing shelf blocks a loaded agent (:836-846)
         const bool blocked = (carry != 0) & (tg0 != st) & (sh_tg != 0) & (occ_loaded == 0);
-        if (tl_on) { keep_vgpr((int)blocked, sh_g0 + sh_g1); RW_MARK(TL_AG_CELLS); }
+        if (RW_RARE(tl_on)) { keep_vgpr((int)blocked, sh_g0 + sh_g1); RW_MARK(TL_AG_CELLS); }
         a = blocked ? (int)ACT_NOOP : a;
         const int tg = blocked ? st : tg0, tx = blocked ? x : tx0, ty = blocked ? y : ty0;
         // successor on the chain: agent index on the target cell, -1 empty, -2 == this agent is stationary
@@ -630,7 +642,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             commit = (nxt >= 0) ? cm : commit;
         }
         // ------------------------------------------------------------ P3: apply (:878-899)
-        if (tl_on) { keep_vgpr(commit, lose); RW_MARK(TL_AG_WINNERS); }
+        if (RW_RARE(tl_on)) { keep_vgpr(commit, lose); RW_MARK(TL_AG_WINNERS); }
         a = commit ? a : (int)ACT_NOOP;  // a failed mover does nothing (:875)
         const bool moved = (a == ACT_FORWARD) & (tg != st);
         x = moved ? tx : x;
@@ -665,8 +677,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         const bool stay0 = (sh_g0 != 0) & !(gflags & 4), stay1 = (sh_g1 != 0) & !(gflags & 8);
         const bool goal_hit = (k_n_goals > 2) | in0 | stay0 | ((k_n_goals > 1) & (in1 | stay1));
         const bool leader = stepping && a_idx == 0;
-        if (tl_on) { keep_vgpr((int)goal_hit, (int)moved); RW_MARK(TL_AG_APPLIED); }
-        if (wave_any(leader && goal_hit)) {  // wave-uniform; a delivery may be due: the LDS path
+        if (RW_RARE(tl_on)) { keep_vgpr((int)goal_hit, (int)moved); RW_MARK(TL_AG_APPLIED); }
+        if (RW_RARE(wave_any(leader && goal_hit))) {  // wave-uniform; a delivery may be due: the LDS path
             wave_sync();
             if (leader) {
                 int32_t *q = s_queue + e * Q;
@@ -944,7 +956,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     RW_MARK(TL_AGENTS);
 
     // ---------------------------------------------------------------- RS: reset flagged envs (:757-802)
-    if (s_misc[0] != 0) {  // workgroup-uniform; rare
+    if (RW_RARE(s_misc[0] != 0)) {  // workgroup-uniform; rare
         for (int c = tid; c < ne * HW; c += T) {
             const int e = c / HW;
             if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;
@@ -1416,7 +1428,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     if (!split && kRollout) write_back(wave, nw);
     }  // fused-rollout step loop
     RW_MARK(TL_END);
-    if (tl_on && lane == 0) {  // where each wavefront ran: slot 10 = 4 x 16 bits of HW_ID, slot 11 = XCC id
+    if (RW_RARE(tl_on) && lane == 0) {  // where each wavefront ran: slot 10 = 4 x 16 bits of HW_ID, slot 11 = XCC id
         atomicOr(reinterpret_cast<unsigned long long *>(la.timeline + (size_t)blockIdx.x * TL_MARKS + 10),
                  (unsigned long long)(hw_id() & 0xFFFFu) << (16 * (wave & 3)));
         if (wave == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + 11] = xcc_id();

@@ -24,6 +24,7 @@ inline bool wave_any(bool v) {  // every thread of the wave calls this (wave-uni
     return r;
 }
 template <typename... Ts> inline void keep_sgpr(const Ts &...) {}
+template <typename... Ts> inline void keep_sgpr_ptr(const Ts &...) {}
 inline void keep_vgpr(int, int) {}
 inline uint32_t opaque(uint32_t x) { return x; }
 inline int uniform(int x) { return x; }
