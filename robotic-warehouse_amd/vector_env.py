@@ -37,6 +37,21 @@ except Exception:  # pragma: no cover - exercised only where gymnasium is missin
         closed = False
 
 
+def _autoreset_metadata(mode):
+    """`metadata["autoreset_mode"]`: a `gymnasium.vector.AutoresetMode` member when the real package is present (what
+    Gymnasium >= 1.0 wrappers compare against), the plain string otherwise.  Untested against real gymnasium: the build
+    image does not have it."""
+    if _gym is not None:
+        try:
+            from gymnasium.vector import AutoresetMode
+
+            return {"next_step": AutoresetMode.NEXT_STEP, "same_step": AutoresetMode.SAME_STEP,
+                    "disabled": AutoresetMode.DISABLED, None: AutoresetMode.DISABLED}[mode]
+        except Exception:  # an older gymnasium without AutoresetMode
+            pass
+    return mode
+
+
 STATE_FIELDS = ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry", "agent_delivered",
                 "queue", "steps", "inactive", "rng")
 
@@ -93,7 +108,7 @@ class WarehouseVecEnv(_VectorEnvBase):
         self.highways = self.layout.highways
         self.goals = list(self.layout.goals)
         self.autoreset_mode = autoreset_mode
-        self.metadata = dict(self.metadata, autoreset_mode=autoreset_mode)
+        self.metadata = dict(self.metadata, autoreset_mode=_autoreset_metadata(autoreset_mode))
         self.output = output
         self.obs_length = obs_length(self.sensor_range, self.msg_bits)
         self._seeded = False
