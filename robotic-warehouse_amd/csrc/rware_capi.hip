@@ -103,12 +103,15 @@ struct StaticEntry {
     {H, W, N, Q, S, R, E, T, MAXB, 0, M, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, false, rw::OBS_FLATTENED_MSG>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, true, rw::OBS_FLATTENED_MSG>}
 const StaticEntry kStatic[] = {
-    // half-size workgroups for batches that leave the CUs short of workgroups at E = 16 (measured:
-    // medium-6ag-hard B=8192 9.44 -> 8.62 us, small-4ag B=4096 6.57 -> 6.48 us; slower above these sizes)
-    RW_STATIC(20, 10, 4, 4, 80, 1, 8, 256, 4096),
+    // half-size workgroups for batches that leave the CUs short of workgroups at E = 16 (measured, round 2:
+    // medium-6ag-hard B=8192 9.16 -> 7.98 us, B=4096 7.86 -> 6.71; B=16384 11.2 vs 13.1 the other way round)
     RW_STATIC(20, 16, 6, 3, 144, 1, 8, 256, 8192),
     RW_STATIC(11, 10, 2, 2, 32, 1, 16, 256, 0),    // rware-tiny-2ag
     RW_STATIC(20, 10, 4, 4, 80, 1, 16, 256, 0),    // rware-small-4ag (headline)
+    // (small-4ag with 8 envs per workgroup: since the agent phases run in registers the 16-env build wins at every batch
+    //  size — B=1024 4.77 vs 4.81 us, 4096 5.35 vs 5.63, 16384 7.87 vs 10.3 — so this one only serves batches that are
+    //  a multiple of 8 but not of 16, or an explicit geometry)
+    RW_STATIC(20, 10, 4, 4, 80, 1, 8, 256, 0),
     RW_STATIC(20, 16, 6, 3, 144, 1, 16, 256, 0),   // rware-medium-6ag-hard
     RW_STATIC(29, 16, 16, 16, 224, 2, 8, 256, 0),  // rware-large-16ag, sensor_range = 2
     // the other tasks of the RWARE benchmark suite (Papoudakis et al. 2021: tiny/small, 2-4 agents, normal/hard)

@@ -51,7 +51,7 @@ def test_emulated_engine_matches_reference_golden(name, geom):
     ("rware-large-16ag-v1", {"sensor_range": 2, "max_steps": 15}, 3, (4, 64)),
     # exact-shape builds (default geometry): agent phases in registers — DPP pairs (N = 2), quads (N = 4), ds_bpermute (N = 6)
     ("rware-tiny-2ag-v1", {"max_steps": 25}, 32, (0, 0)),
-    ("rware-small-4ag-v1", {"max_steps": 25, "reward_type": 2}, 16, (0, 0)),            # the 8-env build
+    ("rware-small-4ag-v1", {"max_steps": 25, "reward_type": 2}, 8, (0, 0)),             # the 8-env build
     ("rware-small-4ag-v1", {"max_steps": 25, "max_inactivity_steps": 11}, 32, (16, 256)),
     ("rware-medium-6ag-hard-v1", {"max_steps": 20, "reward_type": 0}, 16, (0, 0)),      # the 8-env build
     ("rware-medium-6ag-hard-v1", {"max_steps": 20}, 16, (16, 256)),
@@ -96,7 +96,7 @@ def test_emulated_exact_shape_builds_match_reference_golden(name, geom, tile):
     be = EngineBackend(meta["E"], library=LIB, envs_per_workgroup=geom[0], threads_per_workgroup=geom[1], tile=tile,
                        **gu.ctor_kwargs(meta))
     assert be.env.engines[0].info.specialised == 1
-    assert gu.replay(be, meta, z, steps=300) > 0
+    assert gu.replay(be, meta, z, steps=300 if tile <= 4 else 120) > 0   # (the GPU suite replays every trace in full)
     be.env.close()
 
 

@@ -32,7 +32,7 @@ def test_engine_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("name,geom,tile", [
-    ("small-4ag", (0, 0), 4), ("small-4ag", (16, 256), 4), ("tiny-2ag", (0, 0), 4), ("medium-6ag-hard", (0, 0), 8),
+    ("small-4ag", (0, 0), 4), ("small-4ag", (0, 0), 2), ("small-4ag", (8, 256), 4), ("tiny-2ag", (0, 0), 4), ("medium-6ag-hard", (0, 0), 8),
     ("medium-6ag-hard", (16, 256), 16), ("large-16ag-sr2", (0, 0), 4),
     ("img-small-4ag-directional", (0, 0), 16), ("msg2-small-4ag", (0, 0), 16),
 ])
