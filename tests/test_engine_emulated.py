@@ -56,6 +56,11 @@ def test_emulated_engine_matches_reference_golden(name, geom):
     ("rware-medium-6ag-hard-v1", {"max_steps": 20, "reward_type": 0}, 16, (0, 0)),      # the 8-env build
     ("rware-medium-6ag-hard-v1", {"max_steps": 20}, 16, (16, 256)),
     ("rware-tiny-4ag-hard-v1", {"max_steps": 20}, 16, (0, 0)),
+    # exact-shape builds, the two-pass observation expansion (normalised coordinates are fractions, not byte-sized integers)
+    ("rware-small-4ag-v1", {"max_steps": 25, "normalised_coordinates": True}, 16, (16, 256)),
+    # exact-shape builds of the other observation kinds, stepwise + (below) fused
+    ("rware-small-4ag-v1", {"max_steps": 25, "observation_type": 2}, 16, (0, 0)),
+    ("rware-small-4ag-v1", {"max_steps": 25, "msg_bits": 2}, 16, (0, 0)),
 ])
 def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
     kw = rware_amd.env_kwargs(env_id)
@@ -68,8 +73,11 @@ def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
     obs, _ = env.reset(seed=99)
     assert np.array_equal(obs, orc.reset(seed=99))
     rng = np.random.default_rng(3)
+    M = kw.get("msg_bits", 0)
     for t in range(70):
         a = rng.choice(5, size=(B, kw["n_agents"]), p=[0.1, 0.55, 0.1, 0.1, 0.15]).astype(np.int32)
+        if M:
+            a = np.concatenate([a[..., None], rng.integers(0, 2, size=(B, kw["n_agents"], M), dtype=np.int32)], axis=-1)
         obs, rew, term, trunc, _ = env.step(a)
         o2, r2, d2 = orc.step_autoreset(a, mode)
         assert np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t

@@ -51,6 +51,8 @@ CASES = [
     ("rware-tiny-2ag-v1", {}, 4096, 560, (0, 0)),
     ("rware-small-4ag-v1", {}, 2048, 560, (0, 0)),
     ("rware-small-4ag-v1", {}, 1023, 120, (8, 64)),      # ragged batch: last workgroup is partial
+    # exact-shape build with normalised (fractional) coordinates: the two-pass observation expansion
+    ("rware-small-4ag-v1", {"normalised_coordinates": True}, 2048, 260, (0, 0)),
     ("rware-medium-6ag-hard-v1", {}, 1024, 300, (0, 0)),
     # the default geometry picks the half-size-workgroup builds at these batch sizes; pin the E = 16 builds too
     ("rware-small-4ag-v1", {}, 2048, 260, (16, 256)),
