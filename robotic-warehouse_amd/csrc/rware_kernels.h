@@ -639,6 +639,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 cm = (!done & !to_empty & back) ? ((hops >= 3) ? 1 : 0) : cm;
                 done = done | to_empty | back | stuck | (hops >= KN);  // hops == N: feeds a cycle it is not part of
                 j = (nj >= 0) ? nj : j;
+                if (h + 1 < KN && !wave_any(!done)) break;  // wave-uniform: the usual chain is one or two links long
             }
             commit = (nxt >= 0) ? cm : commit;
         }
