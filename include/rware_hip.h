@@ -90,7 +90,11 @@ enum rw_buffer_kind {
     RW_BUF_REWARDS = 1,      /* float32 [B][N]                                                    */
     RW_BUF_TERMINATED = 2,   /* uint8   [B]        `done` (:935-941)                              */
     RW_BUF_TRUNCATED = 3,    /* uint8   [B]        always 0 (:942)                                */
-    RW_BUF_GRID = 4,         /* int32   [B][2][H][W] layer 0 agent ids, layer 1 shelf ids (:11-14)*/
+    RW_BUF_GRID = 4,         /* int32   [B][2][H][W] layer 0 agent ids, layer 1 shelf ids (:11-14).
+                                                   A DERIVED VIEW: rebuilt from the state the kernels keep (shelf
+                                                   layer, agent coordinates) by rw_read / rw_get_buffer of this kind
+                                                   and by rw_refresh_grid — steps enqueued after that do not touch
+                                                   it (every other buffer is current after every step)           */
     RW_BUF_AGENT_X = 5,      /* int32   [B][N]                                                    */
     RW_BUF_AGENT_Y = 6,      /* int32   [B][N]                                                    */
     RW_BUF_AGENT_DIR = 7,    /* int32   [B][N]     rw_direction                                   */
@@ -187,6 +191,10 @@ int rw_device_malloc(rw_engine *eng, size_t bytes, void **dev_ptr);
 int rw_device_free(rw_engine *eng, void *dev_ptr);
 int rw_copy_to_device(rw_engine *eng, void *dev_dst, const void *host_src, size_t bytes);
 int rw_copy_to_host(rw_engine *eng, void *host_dst, const void *dev_src, size_t bytes);
+
+/* bring RW_BUF_GRID up to date with the steps enqueued so far (two small kernels on the engine's stream; a no-op when
+ * nothing ran since the last refresh).  For callers that hold a borrowed pointer / a zero-copy tensor of the grid. */
+int rw_refresh_grid(rw_engine *eng);
 
 /* recompute RW_BUF_OBS from the current state (after rw_write of state buffers) */
 int rw_refresh_obs(rw_engine *eng);

@@ -52,7 +52,7 @@ class RwInfo(C.Structure):
 
 EXPORTS = (
     "rw_create", "rw_destroy", "rw_last_error", "rw_reset", "rw_step", "rw_step_device",
-    "rw_step_many_device", "rw_step_tape_device", "rw_refresh_obs", "rw_sync", "rw_get_buffer", "rw_read", "rw_write",
+    "rw_step_many_device", "rw_step_tape_device", "rw_refresh_obs", "rw_refresh_grid", "rw_sync", "rw_get_buffer", "rw_read", "rw_write",
     "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
     "rw_abi_version", "rw_debug_timeline", "rw_device_malloc", "rw_device_free", "rw_copy_to_device",
     "rw_copy_to_host", "rw_snapshot_create", "rw_snapshot_save", "rw_snapshot_restore", "rw_snapshot_destroy",
@@ -105,6 +105,7 @@ def load(path: str | None = None):
     lib.rw_step_many_device.argtypes = [vp, vp, i32, vp, vp, vp]
     lib.rw_step_tape_device.argtypes = [vp, vp, i32, i32, i32]
     lib.rw_refresh_obs.argtypes = [vp]
+    lib.rw_refresh_grid.argtypes = [vp]
     lib.rw_sync.argtypes = [vp]
     lib.rw_get_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.rw_read.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -283,6 +284,10 @@ class Engine:
 
     def refresh_obs(self):
         self._check(self.lib.rw_refresh_obs(self._h))
+
+    def refresh_grid(self):
+        """Brings the exported int32 grid (a derived view) up to date with the steps enqueued so far."""
+        self._check(self.lib.rw_refresh_grid(self._h))
 
     def sync(self):
         self._check(self.lib.rw_sync(self._h))

@@ -48,6 +48,7 @@ struct rw_engine {
     rw::Params *d_prm = nullptr;  // device copy of `prm` (constant for the engine's lifetime)
     rw::LaunchArgs la{};          // per-launch defaults: the engine's own output buffers
     bool specialised = false;
+    bool grid_stale = false;   // steps / resets have run since RW_BUF_GRID was last rebuilt (refresh_grid)
     void *slab = nullptr;      // the single device allocation behind every buffer below
     size_t shadow_off = 0;
     void *d_shadow = nullptr;  // compact shelf layer (uint8 when S <= 255, else uint16), the kernel's read path
@@ -138,6 +139,7 @@ const StaticEntry kStatic[] = {
 
 int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false) {
     la.op = op | (la.timeline ? rw::OP_FLAG_TIMELINE : 0);
+    if (op != rw::OP_OBS) eng->grid_stale = true;  // the kernels keep the shadow and the coordinates current, not the int32 view
     hipLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
                        eng->stream, (const rw::Params *)eng->d_prm, RW_LAUNCH_ARGS(la));
     RW_HIP(eng, hipGetLastError());
@@ -156,6 +158,30 @@ int rebuild_shadow(rw_engine *eng) {
         hipLaunchKernelGGL((rw::rware_shadow_kernel<uint8_t>), dim3(blocks), dim3(256), 0, eng->stream,
                            (const int32_t *)eng->buf[RW_BUF_GRID].ptr, (uint8_t *)eng->d_shadow, B, HW);
     RW_HIP(eng, hipGetLastError());
+    return RW_OK;
+}
+
+// RW_BUF_GRID is a derived view: brought up to date from the shelf shadow and the agent coordinates when it is asked for
+int refresh_grid(rw_engine *eng) {
+    if (!eng->grid_stale) return RW_OK;
+    const int B = eng->prm.B, HW = eng->prm.HW, W = eng->prm.W, N = eng->prm.N;
+    const size_t n = (size_t)B * HW, na = (size_t)B * N;
+    // (grid-stride loops, one wavefront per workgroup, 64 cells / agents per thread: a few thousand workgroups at the big batches)
+    const unsigned blocks = (unsigned)((n + 4095) / 4096 < 4096 ? (n + 4095) / 4096 : 4096);
+    const unsigned ablocks = (unsigned)((na + 4095) / 4096 < 1024 ? (na + 4095) / 4096 : 1024);
+    int32_t *grid = (int32_t *)eng->buf[RW_BUF_GRID].ptr;
+    const int32_t *ax = (const int32_t *)eng->buf[RW_BUF_AGENT_X].ptr, *ay = (const int32_t *)eng->buf[RW_BUF_AGENT_Y].ptr;
+    if (eng->wide) {
+        hipLaunchKernelGGL((rw::rware_grid_cells_kernel<uint16_t>), dim3(blocks), dim3(64), 0, eng->stream,
+                           (const uint16_t *)eng->d_shadow, grid, B, HW);
+        hipLaunchKernelGGL((rw::rware_grid_agents_kernel<uint16_t>), dim3(ablocks), dim3(64), 0, eng->stream, ax, ay, grid, B, HW, W, N);
+    } else {
+        hipLaunchKernelGGL((rw::rware_grid_cells_kernel<uint8_t>), dim3(blocks), dim3(64), 0, eng->stream,
+                           (const uint8_t *)eng->d_shadow, grid, B, HW);
+        hipLaunchKernelGGL((rw::rware_grid_agents_kernel<uint8_t>), dim3(ablocks), dim3(64), 0, eng->stream, ax, ay, grid, B, HW, W, N);
+    }
+    RW_HIP(eng, hipGetLastError());
+    eng->grid_stale = false;
     return RW_OK;
 }
 
@@ -671,7 +697,7 @@ struct rw_snapshot {
 namespace {
 // the state that reset()/step() evolve: (device pointer, size) pieces in a fixed order
 std::vector<std::pair<void *, size_t>> state_pieces(rw_engine *eng) {
-    static const int kinds[] = {RW_BUF_GRID, RW_BUF_AGENT_X, RW_BUF_AGENT_Y, RW_BUF_AGENT_DIR, RW_BUF_AGENT_CARRY,
+    static const int kinds[] = {RW_BUF_AGENT_X, RW_BUF_AGENT_Y, RW_BUF_AGENT_DIR, RW_BUF_AGENT_CARRY,
                                 RW_BUF_AGENT_DELIVERED, RW_BUF_QUEUE, RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_RNG,
                                 RW_BUF_NEED_RESET, RW_BUF_AGENT_MSG};
     std::vector<std::pair<void *, size_t>> v;
@@ -716,6 +742,7 @@ int rw_snapshot_restore(rw_engine *eng, const rw_snapshot *snap) {
         if (pc.second) RW_HIP(eng, hipMemcpyAsync(pc.first, (const char *)snap->mem + off, pc.second, hipMemcpyDeviceToDevice, eng->stream));
         off += (pc.second + 255) & ~(size_t)255;
     }
+    eng->grid_stale = true;  // (the int32 grid is not part of a snapshot: it is derived from what is)
     return launch(eng, eng->la, rw::OP_OBS);
 }
 
@@ -753,8 +780,19 @@ int rw_sync(rw_engine *eng) {
     return RW_OK;
 }
 
+int rw_refresh_grid(rw_engine *eng) {
+    if (!eng) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    return refresh_grid(eng);
+}
+
 int rw_get_buffer(rw_engine *eng, int kind, void **dev_ptr, size_t *bytes) {
     if (!eng || kind < 0 || kind >= RW_BUF_KIND_COUNT) return RW_ERR_INVALID_ARG;
+    if (kind == RW_BUF_GRID) {
+        RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+        const int rc = refresh_grid(eng);
+        if (rc != RW_OK) return rc;
+    }
     if (dev_ptr) *dev_ptr = eng->buf[kind].ptr;
     if (bytes) *bytes = eng->buf[kind].bytes;
     return RW_OK;
@@ -765,6 +803,10 @@ int rw_read(rw_engine *eng, int kind, void *host_dst, size_t bytes) {
     if (bytes != eng->buf[kind].bytes)
         return fail(eng, RW_ERR_INVALID_ARG, "rw_read kind %d: %zu bytes given, buffer holds %zu", kind, bytes, eng->buf[kind].bytes);
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    if (kind == RW_BUF_GRID) {
+        const int rc = refresh_grid(eng);
+        if (rc != RW_OK) return rc;
+    }
     if (bytes) RW_HIP(eng, hipMemcpyAsync(host_dst, eng->buf[kind].ptr, bytes, hipMemcpyDeviceToHost, eng->stream));
     RW_HIP(eng, hipStreamSynchronize(eng->stream));
     return RW_OK;
@@ -779,6 +821,7 @@ int rw_write(rw_engine *eng, int kind, const void *host_src, size_t bytes) {
     if (kind == RW_BUF_GRID) {
         const int rc = rebuild_shadow(eng);
         if (rc != RW_OK) return rc;
+        eng->grid_stale = false;  // the caller's grid is the state now
     }
     RW_HIP(eng, hipStreamSynchronize(eng->stream));
     return RW_OK;

@@ -248,6 +248,26 @@ __device__ __forceinline__ void rng_store(const Pcg64 &g, uint64_t *rng, int B, 
     rng[5 * (size_t)B + e] = (uint64_t)g.uinteger;
 }
 
+// Rebuilds the exported int32 grid [B][2][H][W] (rware/warehouse.py:749-755, _recalc_grid) from the state the kernels keep:
+// layer 1 = the shelf shadow, layer 0 = agent ids at the agent coordinates.  Two launches: cells, then agents.
+template <typename CellT>
+__global__ void rware_grid_cells_kernel(const CellT *shadow, int32_t *grid, int B, int HW) {
+    const size_t n = (size_t)B * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / HW, c = i - e * HW;
+        grid[e * 2 * HW + c] = 0;
+        grid[e * 2 * HW + HW + c] = (int32_t)shadow[i];
+    }
+}
+template <typename CellT>
+__global__ void rware_grid_agents_kernel(const int32_t *ax, const int32_t *ay, int32_t *grid, int B, int HW, int W, int N) {
+    const size_t n = (size_t)B * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / N;
+        grid[e * 2 * HW + (size_t)ay[i] * W + ax[i]] = (int32_t)(i - e * N) + 1;
+    }
+}
+
 // Rebuilds the shelf shadow from the int32 grid (after a host write of RW_BUF_GRID).
 template <typename CellT>
 __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, int HW) {
@@ -996,15 +1016,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             ev[ENVI_INACTIVE] = 0;
         }
         __syncthreads();
-        // write the reset envs back: whole grid (both layers) + shadow, agent SoA, queue, counters, self bits
+        // write the reset envs back: shelf shadow (the exported int32 grid is derived from it on demand), agent SoA, queue,
+        // counters, self bits
         for (int c = tid; c < ne * HW; c += T) {
             const int e = c / HW;
             if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;
-            const int cc = c - e * HW;
-            int32_t *hA = p.grid + (size_t)(e0 + e) * 2 * HW;
-            hA[cc] = s_ga[c] & 0x7f;
-            hA[HW + cc] = s_gs[c];
-            g_shadow[(size_t)(e0 + e) * HW + cc] = s_gs[c];
+            g_shadow[(size_t)(e0 + e) * HW + (c - e * HW)] = s_gs[c];
         }
         for (int i = tid; i < nea; i += T) {
             const int e = rw_div18(i, mN);
@@ -1084,28 +1101,23 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     rew_t[gi] = s_rew[i];
                     if (kMsg) p.amsg[gi] = s_msg[i];
                 }
-        } else if (role == 2) {  // patch the exported int32 grid and the shadow at the two cells a mover changed
+        } else if (role == 2) {  // patch the shelf shadow at the two cells a LOADED mover changed
+            // (The exported int32 grid, RW_BUF_GRID, is NOT patched here any more: it is rebuilt from the shadow and the agent
+            //  coordinates when somebody asks for it — rw_refresh_grid.  Its scattered 4-byte patches were partial-line
+            //  writes; once a batch outgrows the Infinity Cache each of them is a read-modify-write in HBM: 15 % of the
+            //  step at B = 262144, measured by ablation.)
             if (op == OP_STEP)
                 for (int i = lane; i < nea; i += 64) {
-                    const int mv = s_mv[i];
-                    if (mv < 0) continue;
+                    const int mv = s_mv[i], carry = s_carry[i];
+                    if (mv < 0 || !carry) continue;
                     const int e = rw_div18(i, mN);
                     if (s_envi[e * ENVI_W + ENVI_RESET]) continue;
-                    const int st = mv & 0xffff, tg = mv >> 16, carry = s_carry[i];
+                    const int st = mv & 0xffff, tg = mv >> 16;
                     const size_t ge = (size_t)(e0 + e);
-                    int32_t *hA = p.grid + ge * 2 * HW, *hS = hA + HW;
-                    // the cell it left: cleared unless a follower stepped onto it — the follower then writes that cell
-                    // itself (as its `tg`), so every grid cell has exactly one writer
-                    if ((s_ga[e * HW + st] & 0x7f) == 0) hA[st] = 0;
-                    hA[tg] = (i - e * N) + 1;
-                    if (carry) {
-                        if (s_gs[e * HW + st] == 0) {
-                            hS[st] = 0;
-                            g_shadow[ge * HW + st] = 0;
-                        }
-                        hS[tg] = carry;
-                        g_shadow[ge * HW + tg] = (CellT)carry;
-                    }
+                    // the cell it left: cleared unless a loaded follower stepped onto it — the follower then writes that
+                    // cell itself (as its `tg`), so every shadow cell has exactly one writer
+                    if (s_gs[e * HW + st] == 0) g_shadow[ge * HW + st] = 0;
+                    g_shadow[ge * HW + tg] = (CellT)carry;
                 }
         }
     }

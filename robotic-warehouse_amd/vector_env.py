@@ -394,6 +394,12 @@ class WarehouseVecEnv(_VectorEnvBase):
             if refresh_obs:
                 eng.refresh_obs()
 
+    def refresh_grid(self):
+        """`grid` is a derived view (rebuilt from the shelf layer and the agent coordinates the kernels keep): get_state()
+        and a fresh device_tensor("grid") are always current; call this to update a grid tensor obtained earlier."""
+        for eng in self.engines:
+            eng.refresh_grid()
+
     def observations(self):
         return self._observations()
 

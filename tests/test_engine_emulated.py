@@ -476,3 +476,35 @@ def test_step_tape_device_equals_stepwise_calls():
         assert np.array_equal(sa[k], sb[k]), k
     eng.lib.rw_device_free(eng._h, d)
     a.close(); b.close()
+
+
+def test_grid_is_a_derived_view_refreshed_on_demand():
+    """RW_BUF_GRID is rebuilt from the shelf layer and the agent coordinates when asked for: get_state() / a fresh
+    rw_get_buffer are current; a pointer borrowed earlier lags behind later steps until rw_refresh_grid."""
+    import ctypes as C
+    kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
+    kw["reward_type"] = 1
+    B = 4
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **kw)
+    orc = OracleVecEnv(B, **kw)
+    env.reset(seed=3)
+    orc.reset(seed=3)
+    da = env.engines[0].device_array("grid")                      # borrowed pointer (host memory in the emulation)
+    view = np.ctypeslib.as_array((C.c_int32 * int(np.prod(da.shape))).from_address(da.ptr)).reshape(da.shape)
+    assert np.array_equal(view, orc.get_state()["grid"])          # current when handed out
+    rng = np.random.default_rng(0)
+    before = view.copy()
+    for t in range(12):
+        a = rng.choice(5, size=(B, 2), p=[0.1, 0.6, 0.1, 0.1, 0.1]).astype(np.int32)
+        env.step(a)
+        orc.step_autoreset(a, "next_step")
+    want = orc.get_state()["grid"]
+    assert not np.array_equal(want, before), "nothing moved: the test needs a different seed"
+    assert np.array_equal(view, before)                            # the steps did not touch the exported grid
+    env.refresh_grid()
+    assert np.array_equal(view, want)                              # ... rw_refresh_grid brings it up to date
+    a = rng.integers(0, 5, size=(B, 2), dtype=np.int32)
+    env.step(a)
+    orc.step_autoreset(a, "next_step")
+    assert np.array_equal(env.get_state()["grid"], orc.get_state()["grid"])   # get_state() is always current
+    env.close()

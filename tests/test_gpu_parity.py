@@ -182,6 +182,32 @@ def test_torch_stream_ordering_without_sync():
     tenv.close(); nenv.close(); senv.close()
 
 
+def test_grid_view_is_refreshed_on_demand():
+    """The exported int32 grid is a derived view (rw_refresh_grid): a zero-copy tensor obtained earlier lags behind later
+    steps until env.refresh_grid(); get_state() and a fresh device_tensor("grid") are current."""
+    import torch
+    B = 1024
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    env = rware_amd.WarehouseVecEnv(B, output="torch", **kw)
+    orc = OracleVecEnv(B, **dict(kw, reward_type=kw["reward_type"].value))
+    env.reset(seed=11)
+    orc.reset(seed=11)
+    g = env.device_tensor("grid")
+    assert np.array_equal(g.cpu().numpy(), orc.get_state()["grid"])
+    rng = np.random.default_rng(4)
+    for t in range(20):
+        a = rng.choice(5, size=(B, 4), p=[.1, .6, .1, .1, .1]).astype(np.int32)
+        env.step(torch.from_numpy(a).cuda())
+        orc.step_autoreset(a, "next_step")
+    env.sync()
+    want = orc.get_state()["grid"]
+    assert not np.array_equal(g.cpu().numpy(), want)               # stale: the steps do not patch the view
+    env.refresh_grid()
+    assert np.array_equal(g.cpu().numpy(), want)
+    assert np.array_equal(env.get_state()["grid"], want)
+    env.close()
+
+
 def test_full_size_headline_batch_properties():
     """BASELINE config 3 at full size (small-4ag, B=16384): size-independent invariants + an
     oracle spot-check of a strided subset of envs."""
