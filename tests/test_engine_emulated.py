@@ -39,7 +39,7 @@ def test_emulated_engine_matches_reference_golden(name, geom):
     meta, z = gu.load_fixture(name)
     be = EngineBackend(meta["E"], library=LIB, envs_per_workgroup=geom[0], threads_per_workgroup=geom[1],
                        **gu.ctor_kwargs(meta))
-    assert gu.replay(be, meta, z, steps=350) > 0
+    assert gu.replay(be, meta, z, steps=200) > 0   # (the GPU suite replays every trace in full)
     be.env.close()
 
 
@@ -104,7 +104,7 @@ def test_emulated_exact_shape_builds_match_reference_golden(name, geom, tile):
     be = EngineBackend(meta["E"], library=LIB, envs_per_workgroup=geom[0], threads_per_workgroup=geom[1], tile=tile,
                        **gu.ctor_kwargs(meta))
     assert be.env.engines[0].info.specialised == 1
-    assert gu.replay(be, meta, z, steps=300 if tile <= 4 else 120) > 0   # (the GPU suite replays every trace in full)
+    assert gu.replay(be, meta, z, steps=160 if tile <= 4 else 90) > 0   # (the GPU suite replays every trace in full)
     be.env.close()
 
 
