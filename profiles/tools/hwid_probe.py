@@ -9,7 +9,7 @@ env.reset(seed=0)
 acts = torch.randint(0, 5, (32, B, 4), dtype=torch.int32).cuda()
 for t in range(20): eng.step_device(acts[t].data_ptr())
 tl = eng.debug_timeline(acts[21].data_ptr())
-tl = np.asarray(tl).reshape(-1, 12)
+tl = np.asarray(tl); tl = tl.reshape(tl.shape[0], -1)
 hw = tl[:, 10]; xcc = tl[:, 11] & 0xF
 w = [(hw >> (16 * k)) & 0xFFFF for k in range(4)]
 simd = [(x >> 4) & 3 for x in w]; cu = (w[0] >> 8) & 0xF; se = (w[0] >> 13) & 7; sh = (w[0] >> 12) & 1
