@@ -208,9 +208,14 @@ class WarehouseVecEnv(_VectorEnvBase):
     def step_async(self, actions):
         t = self._torch
         if t is not None and isinstance(actions, t.Tensor) and actions.is_cuda:
-            if (actions.dtype != t.int32 or not actions.is_contiguous()
-                    or actions.numel() != self.num_envs * self.n_agents * (1 + self.msg_bits)):
-                raise ValueError("device actions must be a contiguous int32 tensor of B*N*(1+msg_bits) elements")
+            if actions.numel() != self.num_envs * self.n_agents * (1 + self.msg_bits):
+                raise ValueError("device actions must hold B*N*(1+msg_bits) elements")
+            if actions.dtype in (t.int64, t.int16, t.int8, t.uint8) or not actions.is_contiguous():
+                # what a policy usually hands over (argmax / Categorical.sample() are int64): one small cast on the same
+                # stream, ordered before the step like any other torch op
+                actions = actions.to(t.int32).contiguous()
+            if actions.dtype != t.int32:
+                raise ValueError("device actions must be an integer tensor")
             self._live_actions = actions  # keep alive until the step has run
             self.engines[0].step_device(actions.data_ptr())
             return

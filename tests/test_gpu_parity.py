@@ -130,7 +130,7 @@ def test_torch_zero_copy_views_and_device_actions():
     g = torch.Generator(device="cpu").manual_seed(1)
     for _ in range(30):
         a = torch.randint(0, 5, (B, 4), generator=g, dtype=torch.int32)
-        ot, rt, tt, _, _ = tenv.step(a.cuda())
+        ot, rt, tt, _, _ = tenv.step(a.cuda() if _ % 2 else a.cuda().long())   # (int64, as a policy's argmax hands it over)
         on, rn, tn, _, _ = nenv.step(a.numpy())
         tenv.sync()
         assert np.array_equal(ot.cpu().numpy(), on) and np.array_equal(rt.cpu().numpy(), rn)
