@@ -102,6 +102,11 @@ def main():
 
     children = []
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import torch  # (before spawning: a rank without a device would leave the others waiting at the rendezvous)
+
+        n_vis = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_vis < args.gpus and os.environ.get("RWARE_BENCH_SHARE_GPU") != "1":
+            raise SystemExit(f"--gpus {args.gpus} but only {n_vis} HIP device(s) visible")
         children = spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
