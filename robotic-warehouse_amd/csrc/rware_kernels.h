@@ -159,7 +159,9 @@ struct LdsLayout {
     int ga, zero_end;  // cleared every launch
     int tgt, nxt, depth, win, rew, mv, msg, fx, fy, req, obits, envi, misc, total;
 };
-enum : int { ENVI_STEPS = 0, ENVI_INACTIVE = 1, ENVI_RESET = 2, ENVI_DONE = 3, ENVI_SKIP = 4, ENVI_W = 8 };
+enum : int { ENVI_STEPS = 0, ENVI_INACTIVE = 1, ENVI_RESET = 2, ENVI_DONE = 3, ENVI_SKIP = 4,
+             ENVI_QDIRTY = 5,  // a request was replaced since the chunk was staged: the queue has to be written back
+             ENVI_W = 8 };
 
 RW_HD int rw_up4(int x) { return (x + 3) & ~3; }
 RW_HD uint32_t rw_magic18(int d) { return d > 0 ? (uint32_t)(((1u << 18) + (uint32_t)d - 1u) / (uint32_t)d) : 0u; }
@@ -451,7 +453,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 ev[ENVI_INACTIVE] = smem[lo.dinact + e];
                 ev[ENVI_RESET] = rs;
                 ev[ENVI_SKIP] = rs;
-                ev[ENVI_DONE] = 0;
+                ev[ENVI_DONE] = 0; ev[ENVI_QDIRTY] = 0;
                 if (rs) atomicOr(&s_misc[0], 1);
             }
             lds_barrier();
@@ -477,7 +479,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             ev[ENVI_INACTIVE] = q_inact[e0 + e];
             ev[ENVI_RESET] = rs;
             ev[ENVI_SKIP] = rs;  // an env that resets in this call does not step
-            ev[ENVI_DONE] = 0;
+            ev[ENVI_DONE] = 0; ev[ENVI_QDIRTY] = 0;
             if (rs) atomicOr(&s_misc[0], 1);
         }
         RW_MARK(TL_ENV_LOADED);
@@ -549,7 +551,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             x = r_x; y = r_y; d = r_d; carry = r_carry; deliv = r_deliv; a_lds = r_act;
             if (mine && a_idx == 0) {  // the env's leader lane publishes the flags and counters the other phases read
                 ev[ENVI_STEPS] = r_steps; ev[ENVI_INACTIVE] = r_inact; ev[ENVI_RESET] = r_flag; ev[ENVI_SKIP] = r_flag;
-                ev[ENVI_DONE] = 0;
+                ev[ENVI_DONE] = 0; ev[ENVI_QDIRTY] = 0;
                 if (r_flag) atomicOr(&s_misc[0], 1);
             }
         } else {
@@ -713,6 +715,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     for (int k = Q - 1; k >= 0; --k) slot = (q[k] == sid) ? k : slot;
                     if (slot < 0) continue;
                     delivered = true;
+                    ev[ENVI_QDIRTY] = 1;
                     // candidates = shelves not in the queue, id order; one bounded draw (:915-916)
                     Pcg64 rg;
                     rng_load(rg, p.rng, B, ge);
@@ -927,6 +930,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 for (int k = Q - 1; k >= 0; --k) slot = (q[k] == sid) ? k : slot;
                 if (slot < 0) continue;
                 delivered = true;
+                ev[ENVI_QDIRTY] = 1;
                 // candidates = shelves not in the queue, id order; one bounded draw (:915-916)
                 Pcg64 rg;
                 rng_load(rg, p.rng, B, ge);
@@ -1084,9 +1088,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     p.steps[ge] = ev[ENVI_STEPS];
                     p.inactive[ge] = ev[ENVI_INACTIVE];
                     term_t[ge] = (uint8_t)ev[ENVI_DONE];
-                    p.truncated[ge] = 0;  // the reference never truncates (:942)
-                    p.need_reset[ge] = (uint8_t)((p.autoreset == AR_NEXT_STEP) ? ev[ENVI_DONE] : 0);
-                    for (int k = 0; k < Q; ++k) p.queue[(size_t)ge * Q + k] = s_queue[e * Q + k];
+                    // Only what changed: RW_BUF_TRUNCATED is zero for the engine's lifetime (the reference never truncates,
+                    // :942); need_reset was 0 (the env stepped) and becomes 1 only on termination; the queue changes only
+                    // on a delivery.  Every store stream a step does not issue is ~0.1 us of it (DESIGN.md ablations).
+                    if (ev[ENVI_DONE] && k_autoreset == AR_NEXT_STEP) p.need_reset[ge] = 1;
+                    if (ev[ENVI_QDIRTY])
+                        for (int k = 0; k < Q; ++k) p.queue[(size_t)ge * Q + k] = s_queue[e * Q + k];
                 }
         } else if (role == 1) {  // agent SoA and rewards: the chunk is contiguous in every [B][N] array
             if (op == OP_STEP)
