@@ -176,6 +176,13 @@ int rw_step_device(rw_engine *eng, const int32_t *actions_dev);
  * (first + k) % tape_steps.  Exactly the launches n_steps calls of rw_step_device would make, issued from one native loop:
  * replaying recorded actions, open-loop evaluation, benchmarking without per-call host overhead. */
 int rw_step_tape_device(rw_engine *eng, const int32_t *tape_dev, int32_t tape_steps, int32_t first, int32_t n_steps);
+/* The same launches, with two of the engine's timing events (rw_event_record slots) riding on the dispatches themselves:
+ * `start_slot` takes the START timestamp of the first launch, `stop_slot` the END timestamp of the last one
+ * (hipExtLaunchKernel's start / stop events) — rw_event_elapsed_ms(start_slot, stop_slot) is then the device time of the
+ * n_steps launches without the two marker packets that rw_event_record would put around them (≈9 µs on a 150 µs region).
+ * n_steps >= 1, start_slot != stop_slot. */
+int rw_step_tape_device_timed(rw_engine *eng, const int32_t *tape_dev, int32_t tape_steps, int32_t first, int32_t n_steps,
+                              int32_t start_slot, int32_t stop_slot);
 
 /* T consecutive steps from a device-resident action tape int32 [T][B][N] in ONE kernel launch: each
  * workgroup keeps its env chunk in LDS across the T steps, so per step only the actions are read and

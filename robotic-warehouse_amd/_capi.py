@@ -52,7 +52,7 @@ class RwInfo(C.Structure):
 
 EXPORTS = (
     "rw_create", "rw_destroy", "rw_last_error", "rw_reset", "rw_step", "rw_step_device",
-    "rw_step_many_device", "rw_step_tape_device", "rw_refresh_obs", "rw_refresh_grid", "rw_sync", "rw_get_buffer", "rw_read", "rw_write",
+    "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_sync", "rw_get_buffer", "rw_read", "rw_write",
     "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
     "rw_abi_version", "rw_debug_timeline", "rw_device_malloc", "rw_device_free", "rw_copy_to_device",
     "rw_copy_to_host", "rw_snapshot_create", "rw_snapshot_save", "rw_snapshot_restore", "rw_snapshot_destroy",
@@ -104,6 +104,7 @@ def load(path: str | None = None):
     lib.rw_step_device.argtypes = [vp, vp]
     lib.rw_step_many_device.argtypes = [vp, vp, i32, vp, vp, vp]
     lib.rw_step_tape_device.argtypes = [vp, vp, i32, i32, i32]
+    lib.rw_step_tape_device_timed.argtypes = [vp, vp, i32, i32, i32, i32, i32]
     lib.rw_refresh_obs.argtypes = [vp]
     lib.rw_refresh_grid.argtypes = [vp]
     lib.rw_sync.argtypes = [vp]
@@ -230,6 +231,11 @@ class Engine:
     def step_tape_device(self, tape_ptr, tape_steps, first, n_steps):
         """n_steps per-step launches (rw_step_device each) from a device action tape, issued by one native loop."""
         self._check(self.lib.rw_step_tape_device(self._h, C.c_void_p(int(tape_ptr)), int(tape_steps), int(first), int(n_steps)))
+
+    def step_tape_device_timed(self, tape_ptr, tape_steps, first, n_steps, start_slot, stop_slot):
+        """step_tape_device with the timing events attached to the first / last launch (no marker packets)."""
+        self._check(self.lib.rw_step_tape_device_timed(self._h, C.c_void_p(int(tape_ptr)), int(tape_steps), int(first),
+                                                       int(n_steps), int(start_slot), int(stop_slot)))
 
     def step_many_device(self, dev_ptr, n_steps, obs_tape=0, reward_tape=0, terminated_tape=0):
         self._check(self.lib.rw_step_many_device(self._h, C.c_void_p(int(dev_ptr)), int(n_steps),

@@ -4,6 +4,7 @@
 // enqueues the fused step kernel (rware_kernels.h) on one stream.  No CPU fallback exists:
 // without a usable HIP device rw_create fails with RW_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -137,11 +138,15 @@ const StaticEntry kStatic[] = {
 #undef RW_STATIC_IMAGE
 #undef RW_STATIC_MSG
 
-int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false) {
+int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     la.op = op | (la.timeline ? rw::OP_FLAG_TIMELINE : 0);
     if (op != rw::OP_OBS) eng->grid_stale = true;  // the kernels keep the shadow and the coordinates current, not the int32 view
-    hipLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
-                       eng->stream, (const rw::Params *)eng->d_prm, RW_LAUNCH_ARGS(la));
+    if (start || stop)  // the events ride on this dispatch (its own start / end timestamps): no marker packets in the stream
+        hipExtLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
+                              eng->stream, start, stop, 0, (const rw::Params *)eng->d_prm, RW_LAUNCH_ARGS(la));
+    else
+        hipLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
+                           eng->stream, (const rw::Params *)eng->d_prm, RW_LAUNCH_ARGS(la));
     RW_HIP(eng, hipGetLastError());
     return RW_OK;
 }
@@ -586,7 +591,9 @@ int rw_step_device(rw_engine *eng, const int32_t *actions_dev) {
     return launch(eng, la, rw::OP_STEP);
 }
 
-int rw_step_tape_device(rw_engine *eng, const int32_t *tape_dev, int32_t tape_steps, int32_t first, int32_t n_steps) {
+namespace {
+int step_tape(rw_engine *eng, const int32_t *tape_dev, int32_t tape_steps, int32_t first, int32_t n_steps,
+              hipEvent_t start, hipEvent_t stop) {
     // n_steps consecutive rw_step_device launches from a device-resident action tape int32 [tape_steps][B][N][1+M]: step k
     // reads row (first + k) % tape_steps.  Same launches as n_steps calls of rw_step_device — one per step, each ordered
     // behind the previous one on the engine's stream — issued from one native loop instead of one host call each.
@@ -596,10 +603,22 @@ int rw_step_tape_device(rw_engine *eng, const int32_t *tape_dev, int32_t tape_st
     rw::LaunchArgs la = eng->la;
     for (int32_t k = 0; k < n_steps; ++k) {
         la.actions = tape_dev + (size_t)((first + k) % tape_steps) * row;
-        const int rc = launch(eng, la, rw::OP_STEP);
+        const int rc = launch(eng, la, rw::OP_STEP, false, k == 0 ? start : nullptr, k == n_steps - 1 ? stop : nullptr);
         if (rc != RW_OK) return rc;
     }
     return RW_OK;
+}
+}  // namespace
+
+int rw_step_tape_device(rw_engine *eng, const int32_t *tape_dev, int32_t tape_steps, int32_t first, int32_t n_steps) {
+    return step_tape(eng, tape_dev, tape_steps, first, n_steps, nullptr, nullptr);
+}
+
+int rw_step_tape_device_timed(rw_engine *eng, const int32_t *tape_dev, int32_t tape_steps, int32_t first, int32_t n_steps,
+                              int32_t start_slot, int32_t stop_slot) {
+    if (!eng || start_slot < 0 || start_slot >= 8 || stop_slot < 0 || stop_slot >= 8 || start_slot == stop_slot || n_steps < 1)
+        return RW_ERR_INVALID_ARG;
+    return step_tape(eng, tape_dev, tape_steps, first, n_steps, eng->events[start_slot], eng->events[stop_slot]);
 }
 
 int rw_step(rw_engine *eng, const int32_t *actions_host) {

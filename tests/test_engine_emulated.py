@@ -465,8 +465,14 @@ def test_step_tape_device_equals_stepwise_calls():
     d = C.c_void_p()
     eng._check(eng.lib.rw_device_malloc(eng._h, tape.nbytes, C.byref(d)))
     eng._check(eng.lib.rw_copy_to_device(eng._h, d, tape.ctypes.data, tape.nbytes))
-    eng.step_tape_device(d.value, TS, 3, 12)          # rows 3, 4, 0, 1, 2, 3, ...
+    eng.step_tape_device(d.value, TS, 3, 7)           # rows 3, 4, 0, 1, 2, 3, ...
+    eng.step_tape_device_timed(d.value, TS, (3 + 7) % TS, 5, 0, 1)   # same launches, timing events on the first / last one
     eng.sync()
+    assert eng.event_elapsed_ms(0, 1) >= 0.0
+    with pytest.raises(Exception):
+        eng.step_tape_device_timed(d.value, TS, 0, 0, 0, 1)   # nothing to attach the events to
+    with pytest.raises(Exception):
+        eng.step_tape_device_timed(d.value, TS, 0, 1, 2, 2)   # one slot for both ends
     for k in range(12):
         obs, rew, term, _, _ = b.step(tape[(3 + k) % TS])
     assert np.array_equal(a.observations(), obs)

@@ -489,6 +489,35 @@ def test_hip_graph_capture_of_per_step_launches():
     genv.close(); penv.close()
 
 
+def test_timed_tape_launches_carry_their_own_events():
+    """rw_step_tape_device_timed: the same launches as rw_step_tape_device; the start / stop events ride on the first /
+    last dispatch, so their elapsed time is the device time of the n launches (a few us each) with no marker packets."""
+    import torch
+    B, K = 4096, 40
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    a = rware_amd.WarehouseVecEnv(B, **kw)
+    b = rware_amd.WarehouseVecEnv(B, **kw)
+    a.reset(seed=5)
+    b.reset(seed=5)
+    tape = torch.randint(0, 5, (K, B, 4), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ea, eb = a.engines[0], b.engines[0]
+    ea.step_tape_device_timed(tape.data_ptr(), K, 0, K, 0, 1)
+    eb.step_tape_device(tape.data_ptr(), K, 0, K)
+    ea.sync(); eb.sync()
+    ms = ea.event_elapsed_ms(0, 1)
+    assert 0.0 < ms < 50.0 and ms / K > 0.001       # 40 launches of >= 1 us each, well under 50 ms
+    ea.step_tape_device_timed(tape.data_ptr(), K, 0, 1, 2, 3)    # one launch carries both events
+    eb.step_tape_device(tape.data_ptr(), K, 0, 1)
+    ea.sync(); eb.sync()
+    assert 0.0 < ea.event_elapsed_ms(2, 3) < 5.0
+    assert np.array_equal(a.observations(), b.observations())
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    a.close(); b.close()
+
+
 def _check_bench_line(out, n_gpus, steps, warmup, batch):
     import json
     assert out.returncode == 0, out.stderr[-2000:]
