@@ -389,6 +389,35 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             r_inact = q_inact[ge];
         }
     }
+    // P1 of the agent phases as two pieces, so that the exact-shape per-step kernels can run them BEFORE the stage-in barrier
+    // (kEarly, below): intent (:825-834, everything that needs only the agent's own record and action) and the occupant
+    // of the target cell (a cross-lane exchange of the agents' positions).
+    struct Intent { int a, st, tg0, tx0, ty0, occ_w; };
+    constexpr int KNX = kRegAG ? Cfg::kN : 1;
+    auto intent_of = [&](bool stepping, int a, int x, int y, int d) -> Intent {
+        if (RW_RARE(stepping && (unsigned)a > 4u)) atomicOr(p.status, STATUS_INVALID_ACTION);  // Action(a) raises (:814); runs as NOOP
+        a = (stepping && (unsigned)a <= 4u) ? a : (int)ACT_NOOP;
+        const int fwd = (a == ACT_FORWARD) ? 1 : 0;
+        const int dx = fwd & ((d == DIR_RIGHT) ? 1 : 0), dxn = fwd & ((d == DIR_LEFT) ? 1 : 0);
+        const int dy = fwd & ((d == DIR_DOWN) ? 1 : 0), dyn = fwd & ((d == DIR_UP) ? 1 : 0);
+        const int tx0 = min(max(x + dx - dxn, 0), W - 1);  // clamped at the walls (:105-112)
+        const int ty0 = min(max(y + dy - dyn, 0), H - 1);
+        return Intent{a, y * W + x, ty0 * W + tx0, tx0, ty0, -1};
+    };
+    // who stands on my target cell, and is it loaded: every agent announces (cell | loaded << 16 | index << 20)
+    auto occupant_of = [&](const Intent &in, int carry, int a_idx, int lane_base) -> int {
+        int pkv[KNX];
+        env_gather<KNX>(in.st | (carry ? 0x10000 : 0) | (a_idx << 20), lane_base, pkv);
+        int occ_w = -1;
+#pragma unroll
+        for (int k = 0; k < KNX; ++k) occ_w = ((pkv[k] & 0xffff) == in.tg0) ? pkv[k] : occ_w;
+        return occ_w;
+    };
+    // kEarly (exact-shape per-step kernels): the agent wavefront does not take part in the stage-in DMA; its record loads
+    // were the first thing it issued, so they are back while the other wavefronts' DMA is still in flight — it computes
+    // intent and occupant in that window, before the barrier that everything else of the agent phases has to wait for.
+    constexpr bool kEarly = kDirect && !kRollout && Cfg::kT >= 128;
+    Intent early{ACT_NOOP, 0, 0, 0, 0, -1};
     clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
     RW_MARK(TL_ZEROED);
     if constexpr (Cfg::kE != 0) {
@@ -413,20 +442,31 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             // One DMA instruction moves up to 64 pieces of ONE segment (LDS base + lane * 16), so the source
             // pick is scalar; the (compile-time) list of such instructions is dealt round-robin to the waves.
             // Per wave that is 3-4 instructions of ~3 VALU ops each — the phase is VALU-issue bound otherwise.
-            const int wave_s = uniform(wave);
+            // (kEarly: dealt to wavefronts 1.. only — wavefront 0 must not have a DMA of its own to wait for)
+            const int wave_s = uniform(wave) - (kEarly ? 1 : 0), dma_w = nw - (kEarly ? 1 : 0);
             int job = 0;
             for (int k = 0; k < 12; ++k) {  // (fully unrolled when the shapes are compile-time constants)
                 if (kDirect && ((k >= 1 && k <= 6) || k >= 9)) continue;  // agent SoA, actions, counters, flags: in registers
                 const int pieces = (seg[k + 1] - seg[k]) >> 2;
                 for (int c = 0; c < pieces; c += 64, ++job)
-                    if (job % nw == wave_s && c + lane < pieces)
+                    if (job % dma_w == wave_s && c + lane < pieces)
                         lds_dma_b128(src[k] + (size_t)(c + lane) * 16, smem + seg[k] + 4 * c);
             }
             if constexpr (kMsg) {  // the agents' stored messages: a 13th array, outside the contiguous block
                 const int pieces = (Cfg::kE * Cfg::kN) >> 2;
                 for (int c = 0; c < pieces; c += 64, ++job)
-                    if (job % nw == wave_s && c + lane < pieces)
+                    if (job % dma_w == wave_s && c + lane < pieces)
                         lds_dma_b128(reinterpret_cast<const char *>(p.amsg + (size_t)e0 * N) + (size_t)(c + lane) * 16, smem + lo.msg + 4 * c);
+            }
+            if constexpr (kEarly) {
+                constexpr int KN = Cfg::kN, KG = 64 / KN;
+                if (uniform(wave) * KG < Cfg::kE) {  // wave-uniform: a wavefront that runs agent phases
+                    const int g = lane / KN, a_idx = lane - g * KN;
+                    const bool mine = (g < KG) && (wave * KG + g < Cfg::kE);
+                    early = intent_of((op == OP_STEP) && mine && !r_flag, r_act, r_x, r_y, r_d);
+                    early.occ_w = occupant_of(early, r_carry, a_idx, (g < KG ? g : KG - 1) * KN);
+                    keep_vgpr(early.tg0, early.occ_w);  // (materialised here, not sunk below the barrier)
+                }
             }
         } else {  // N, Q are run-time values: thread t moves LDS piece t, its source picked per lane
             const int pieces = (lo.dma_end - lo.gs) >> 2;
@@ -561,7 +601,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         }
         const bool stepping = (op == OP_STEP) && mine && !ev_skip;
         int a = ACT_NOOP;
-        if (mine) {
+        if (!kEarly && mine) {
             if (stepping) a = (t == 0) ? a_lds : (act_prefetch ? a_pref : act_t[((size_t)ge * KN + a_idx) * AM]);
             if (kMsg && stepping) {  // agent.message[:] = action[1:] — for every agent, whatever its move does (:812)
                 int msg = 0;
@@ -574,17 +614,11 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             }
             if (act_prefetch && t + 1 < n_steps) a_pref = (act_t + la.act_stride)[(size_t)ge * KN + a_idx];
         }
-        if (RW_RARE(stepping && (unsigned)a > 4u)) atomicOr(p.status, STATUS_INVALID_ACTION);  // Action(a) raises (:814); runs as NOOP
-        a = (stepping && (unsigned)a <= 4u) ? a : (int)ACT_NOOP;
         // ------------------------------------------------------------ P1: intent (:825-846), branch-free
-        const int st = y * W + x;
+        Intent in = kEarly ? early : intent_of(stepping, a, x, y, d);
+        a = in.a;
+        const int st = in.st, tg0 = in.tg0, tx0 = in.tx0, ty0 = in.ty0;
         if (RW_RARE(tl_on)) { keep_vgpr(st, a); RW_MARK(TL_AG_RECORD); }
-        const int fwd = (a == ACT_FORWARD) ? 1 : 0;
-        const int dx = fwd & ((d == DIR_RIGHT) ? 1 : 0), dxn = fwd & ((d == DIR_LEFT) ? 1 : 0);
-        const int dy = fwd & ((d == DIR_DOWN) ? 1 : 0), dyn = fwd & ((d == DIR_UP) ? 1 : 0);
-        const int tx0 = min(max(x + dx - dxn, 0), W - 1);  // clamped at the walls (:105-112)
-        const int ty0 = min(max(y + dy - dyn, 0), H - 1);
-        const int tg0 = ty0 * W + tx0;
         // ---- LDS read batch 2 (the only one of the common kDirect step): the shelf layer at the target, under the agent and
         // on the first two goal cells (start-of-step values), the highway word of the agent's cell
         const int sh_tg = gS[tg0], shelf_here = gS[st], sh_g0 = gS[k_goal0], sh_g1 = gS[k_goal1];
@@ -592,12 +626,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         int qv[QS > 0 ? QS : 1];  // the queue slots this lane publishes in the requested-shelf bitmap
 #pragma unroll
         for (int q = 0; q < QS; ++q) qv[q] = s_queue[e * KQ + min(a_idx + q * KN, KQ - 1)];
-        // who stands on my target cell, and is it loaded: every agent announces (cell | loaded << 16 | index << 20)
-        int pkv[KN];
-        env_gather<KN>(st | (carry ? 0x10000 : 0) | (a_idx << 20), lane_base, pkv);
-        int occ_w = -1;
-#pragma unroll
-        for (int k = 0; k < KN; ++k) occ_w = ((pkv[k] & 0xffff) == tg0) ? pkv[k] : occ_w;
+        const int occ_w = kEarly ? in.occ_w : occupant_of(in, carry, a_idx, lane_base);  // (issued beside the LDS reads above)
         const int occ = occ_w >> 20;  // -1: nobody there
         const int occ_loaded = (occ_w >> 16) & 1 & ~(occ_w >> 31);
         // a standing shelf blocks a loaded agent (:836-846)
@@ -635,10 +664,14 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                                          : 0x7fff0000u | ((uint32_t)a_idx << 8);
         int kv[KN];
         env_gather<KN>((int)vme, lane_base, kv);
-        int lose = 0;
+        // The priority byte is < 128 (depth <= 5), so for two words with the same cell field 1 <= kv - vme <= 127 iff k beats
+        // me, while different cell fields put the difference outside that range: one subtract and a running minimum per
+        // agent, ONE compare at the end (compare results live in scalar registers: every compare in a chain like this
+        // costs a vector -> scalar -> vector round trip on the one wavefront that runs the agent phases).
+        uint32_t beat = 0xffffffffu;
 #pragma unroll
-        for (int k = 0; k < KN; ++k)  // (bitwise on purpose: no short-circuit branches)
-            lose |= ((((uint32_t)kv[k] ^ vme) < 256u) & ((uint32_t)kv[k] > vme)) ? 1 : 0;
+        for (int k = 0; k < KN; ++k) beat = min(beat, (uint32_t)kv[k] - vme - 1u);
+        const int lose = beat < 127u ? 1 : 0;
         // ------------------------------------------------------------ P2c: commit (:871-876)
         int commit = (nxt == -1) ? (lose ^ 1) : ((nxt == -2) ? 1 : 0);
         if (chains) {  // walk the chain ahead: i -> nxt(i) -> ... on the gathered links
@@ -697,9 +730,11 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // start-of-step shelf unless a loaded mover took it away.  (More than two goal cells: always take the LDS path.)
         const int gflags = env_or<KN>(mcar ? ((tg == k_goal0 ? 1 : 0) | (tg == k_goal1 ? 2 : 0) | (st == k_goal0 ? 4 : 0) |
                                                (st == k_goal1 ? 8 : 0)) : 0, lane_base);
-        const bool in0 = gflags & 1, in1 = gflags & 2;
-        const bool stay0 = (sh_g0 != 0) & !(gflags & 4), stay1 = (sh_g1 != 0) & !(gflags & 8);
-        const bool goal_hit = (k_n_goals > 2) | in0 | stay0 | ((k_n_goals > 1) & (in1 | stay1));
+        // bit g of `on_goal`: a shelf stands on goal g after the moves — a loaded mover arrived (gflags bits 0, 1), or the
+        // start-of-step shelf is still there (bits 2, 3 say a loaded mover took it away).  Integer arithmetic on purpose.
+        const int had = min(sh_g0, 1) | (min(sh_g1, 1) << 1);
+        const int on_goal = (gflags | (had & ~(gflags >> 2))) & (k_n_goals > 1 ? 3 : 1);
+        const bool goal_hit = (on_goal != 0) | (k_n_goals > 2);
         const bool leader = stepping && a_idx == 0;
         if (RW_RARE(tl_on)) { keep_vgpr((int)goal_hit, (int)moved); RW_MARK(TL_AG_APPLIED); }
         if (RW_RARE(wave_any(leader && goal_hit))) {  // wave-uniform; a delivery may be due: the LDS path
