@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Per-workgroup phase timeline of one step (rw_debug_timeline): where does the time go?
 Prints, per phase mark, the median/p10/p90 offset (us) from the earliest workgroup start, and
-the distribution of workgroup start and end times across the grid."""
+the distribution of workgroup start and end times across the grid.
+The marks INSIDE the agent phases exist only in a library built with -DRW_TL_AG_MARKS
+(`make -C robotic-warehouse_amd/csrc clean all CXXFLAGS="<the Makefile's flags> -DRW_TL_AG_MARKS"`): the product build
+leaves them out, because even a switched-off mark is a scalar test + branch on the wavefront everybody waits for."""
 import os
 import sys
 

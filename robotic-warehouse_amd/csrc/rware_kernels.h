@@ -335,6 +335,13 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const uint32_t mN = Cfg::kN ? rw_magic18(Cfg::kN) : p.magic_n;
     // optional per-workgroup phase stamps (100 MHz wall clock); one scalar branch per mark when off
 #define RW_MARK(k) do { if (RW_RARE(tl_on) && tid == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + (k)] = wall_clock64(); } while (0)
+    // marks INSIDE the agent phases: only in a -DRW_TL_AG_MARKS build (profiles/tools/timeline_probe.py says how) — even
+    // switched off each one is a scalar test and a branch on the one wavefront every other wavefront is waiting for
+#ifdef RW_TL_AG_MARKS
+#define RW_AG_MARK(k, v0, v1) do { if (RW_RARE(tl_on)) { keep_vgpr((v0), (v1)); RW_MARK(k); } } while (0)
+#else
+#define RW_AG_MARK(k, v0, v1) do { } while (0)
+#endif
     RW_MARK(TL_START);
 
     const LdsLayout lo = make_lds_layout(E, N, Q, HW, SW, OW, (int)sizeof(CellT), AM);
@@ -589,11 +596,6 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         if (kDirect && t == 0) {
             ev_skip = ev_reset = r_flag; ev_steps = r_steps; ev_inact = r_inact;
             x = r_x; y = r_y; d = r_d; carry = r_carry; deliv = r_deliv; a_lds = r_act;
-            if (mine && a_idx == 0) {  // the env's leader lane publishes the flags and counters the other phases read
-                ev[ENVI_STEPS] = r_steps; ev[ENVI_INACTIVE] = r_inact; ev[ENVI_RESET] = r_flag; ev[ENVI_SKIP] = r_flag;
-                ev[ENVI_DONE] = 0; ev[ENVI_QDIRTY] = 0;
-                if (r_flag) atomicOr(&s_misc[0], 1);
-            }
         } else {
             ev_skip = ev[ENVI_SKIP]; ev_reset = ev[ENVI_RESET]; ev_steps = ev[ENVI_STEPS]; ev_inact = ev[ENVI_INACTIVE];
             x = s_ax[i]; y = s_ay[i]; d = s_dir[i]; carry = s_carry[i]; deliv = s_deliv[i];
@@ -618,7 +620,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         Intent in = kEarly ? early : intent_of(stepping, a, x, y, d);
         a = in.a;
         const int st = in.st, tg0 = in.tg0, tx0 = in.tx0, ty0 = in.ty0;
-        if (RW_RARE(tl_on)) { keep_vgpr(st, a); RW_MARK(TL_AG_RECORD); }
+        RW_AG_MARK(TL_AG_RECORD, st, a);
         // ---- LDS read batch 2 (the only one of the common kDirect step): the shelf layer at the target, under the agent and
         // on the first two goal cells (start-of-step values), the highway word of the agent's cell
         const int sh_tg = gS[tg0], shelf_here = gS[st], sh_g0 = gS[k_goal0], sh_g1 = gS[k_goal1];
@@ -627,11 +629,17 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
 #pragma unroll
         for (int q = 0; q < QS; ++q) qv[q] = s_queue[e * KQ + min(a_idx + q * KN, KQ - 1)];
         const int occ_w = kEarly ? in.occ_w : occupant_of(in, carry, a_idx, lane_base);  // (issued beside the LDS reads above)
+        if (kDirect && t == 0 && mine && a_idx == 0) {  // the env's leader lane publishes the flags and counters the other
+            // phases read (from its registers; LDS stores issued while the reads above are in flight)
+            ev[ENVI_STEPS] = r_steps; ev[ENVI_INACTIVE] = r_inact; ev[ENVI_RESET] = r_flag; ev[ENVI_SKIP] = r_flag;
+            ev[ENVI_DONE] = 0; ev[ENVI_QDIRTY] = 0;
+            if (r_flag) atomicOr(&s_misc[0], 1);
+        }
         const int occ = occ_w >> 20;  // -1: nobody there
         const int occ_loaded = (occ_w >> 16) & 1 & ~(occ_w >> 31);
         // a standing shelf blocks a loaded agent (:836-846)
         const bool blocked = (carry != 0) & (tg0 != st) & (sh_tg != 0) & (occ_loaded == 0);
-        if (RW_RARE(tl_on)) { keep_vgpr((int)blocked, sh_g0 + sh_g1); RW_MARK(TL_AG_CELLS); }
+        RW_AG_MARK(TL_AG_CELLS, (int)blocked, sh_g0 + sh_g1);
         a = blocked ? (int)ACT_NOOP : a;
         const int tg = blocked ? st : tg0, tx = blocked ? x : tx0, ty = blocked ? y : ty0;
         // successor on the chain: agent index on the target cell, -1 empty, -2 == this agent is stationary
@@ -699,7 +707,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             commit = (nxt >= 0) ? cm : commit;
         }
         // ------------------------------------------------------------ P3: apply (:878-899)
-        if (RW_RARE(tl_on)) { keep_vgpr(commit, lose); RW_MARK(TL_AG_WINNERS); }
+        RW_AG_MARK(TL_AG_WINNERS, commit, lose);
         a = commit ? a : (int)ACT_NOOP;  // a failed mover does nothing (:875)
         const bool moved = (a == ACT_FORWARD) & (tg != st);
         x = moved ? tx : x;
@@ -736,7 +744,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         const int on_goal = (gflags | (had & ~(gflags >> 2))) & (k_n_goals > 1 ? 3 : 1);
         const bool goal_hit = (on_goal != 0) | (k_n_goals > 2);
         const bool leader = stepping && a_idx == 0;
-        if (RW_RARE(tl_on)) { keep_vgpr((int)goal_hit, (int)moved); RW_MARK(TL_AG_APPLIED); }
+        RW_AG_MARK(TL_AG_APPLIED, (int)goal_hit, (int)moved);
         if (RW_RARE(wave_any(leader && goal_hit))) {  // wave-uniform; a delivery may be due: the LDS path
             wave_sync();
             if (leader) {
@@ -802,7 +810,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 atomicOr(&s_misc[0], 1);
             }
         }
-        RW_MARK(TL_AG_GOALS);
+        RW_AG_MARK(TL_AG_GOALS, 0, 0);
         // requested-shelf bitmap of the (post-step) queue.  Envs that reset in this launch are included: RS clears and
         // rebuilds their bitmap.
         if (mine) {
@@ -1538,6 +1546,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         if (wave == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + 11] = xcc_id();
     }
 #undef RW_MARK
+#undef RW_AG_MARK
 }
 
 }  // namespace rw
