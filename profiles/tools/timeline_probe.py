@@ -25,6 +25,10 @@ def main():
     E = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     T = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     kw = rware_amd.env_kwargs(env_id)
+    if os.environ.get("TL_OBS_TYPE"):  # 2 IMAGE, 3 IMAGE_DICT
+        kw["observation_type"] = int(os.environ["TL_OBS_TYPE"])
+    if os.environ.get("TL_SENSOR_RANGE"):
+        kw["sensor_range"] = int(os.environ["TL_SENSOR_RANGE"])
     env = rware_amd.WarehouseVecEnv(B, envs_per_workgroup=E, threads_per_workgroup=T, **kw)
     eng = env.engines[0]
     env.reset(seed=0)
