@@ -672,14 +672,13 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                                          : 0x7fff0000u | ((uint32_t)a_idx << 8);
         int kv[KN];
         env_gather<KN>((int)vme, lane_base, kv);
-        // The priority byte is < 128 (depth <= 5), so for two words with the same cell field 1 <= kv - vme <= 127 iff k beats
-        // me, while different cell fields put the difference outside that range: one subtract and a running minimum per
-        // agent, ONE compare at the end (compare results live in scalar registers: every compare in a chain like this
-        // costs a vector -> scalar -> vector round trip on the one wavefront that runs the agent phases).
-        uint32_t beat = 0xffffffffu;
+        // (A subtract-and-running-minimum form of this test — one compare at the end — passed the host emulation and failed a
+        //  golden trace on the GPU: hipcc folds the DPP move into `v_subrev_u32_dpp` and the result came out with the
+        //  operands swapped; profiles/tools/dpp_subrev_probe.hip.  Keep the exchange results in registers of their own.)
+        int lose = 0;
 #pragma unroll
-        for (int k = 0; k < KN; ++k) beat = min(beat, (uint32_t)kv[k] - vme - 1u);
-        const int lose = beat < 127u ? 1 : 0;
+        for (int k = 0; k < KN; ++k)  // (bitwise on purpose: no short-circuit branches)
+            lose |= ((((uint32_t)kv[k] ^ vme) < 256u) & ((uint32_t)kv[k] > vme)) ? 1 : 0;
         // ------------------------------------------------------------ P2c: commit (:871-876)
         int commit = (nxt == -1) ? (lose ^ 1) : ((nxt == -2) ? 1 : 0);
         if (chains) {  // walk the chain ahead: i -> nxt(i) -> ... on the gathered links

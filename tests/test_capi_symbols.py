@@ -72,3 +72,26 @@ def test_no_device_means_loud_failure_not_a_cpu_path():
 def test_missing_library_is_a_loud_error(tmp_path):
     with pytest.raises(RuntimeError, match="not found"):
         _capi.load(str(tmp_path / "librware_hip.so"))
+
+
+def test_kernel_isa_has_no_operand_order_sensitive_dpp_folds(tmp_path):
+    """hipcc folds a DPP cross-lane move into the instruction that uses it.  For a NON-commutative use the fold has to
+    pick the reversed opcode, and `v_subrev_u32_dpp` came out with its operands swapped on gfx950 (round 2: a winner test
+    written as `x_k - x_me - 1` passed the host emulation and failed a golden trace on the GPU;
+    profiles/tools/dpp_subrev_probe.hip shows it in isolation).  The exact-shape kernels may only contain DPP forms whose
+    operand order cannot matter."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    csrc = os.path.join(ROOT, "robotic-warehouse_amd", "csrc")
+    out = tmp_path / "capi.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + csrc, "-mllvm", "-amdgpu-kernarg-preload-count=16",
+                    "--cuda-device-only", "-S", "-o", str(out), os.path.join(csrc, "rware_capi.hip")],
+                   check=True, capture_output=True, timeout=600)
+    ops = set(re.findall(r"^\s*(v_[a-z0-9_]+_dpp)\b", out.read_text(), flags=re.M))
+    assert ops, "the exact-shape builds exchange through DPP moves: none found?"
+    allowed = {"v_mov_b32_dpp", "v_or_b32_dpp", "v_and_b32_dpp", "v_xor_b32_dpp", "v_add_u32_dpp", "v_max_i32_dpp", "v_max_u32_dpp",
+               "v_min_i32_dpp", "v_min_u32_dpp"}
+    assert ops <= allowed, f"operand-order-sensitive DPP folds in the kernel ISA: {sorted(ops - allowed)}"
