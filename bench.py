@@ -92,9 +92,11 @@ def main():
     ap.add_argument("--many", type=int, default=0,
                     help="fused rollout: submit steps in chunks of this many through rw_step_many_device (one launch per chunk, "
                          "env chunk resident in LDS across the steps; open-loop)")
-    ap.add_argument("--submit", choices=["native", "python"], default="native",
+    ap.add_argument("--submit", choices=["native", "python", "graph"], default="native",
                     help="who issues the per-step launches: the library's loop over the device action tape (rw_step_tape_device, "
-                         "default) or one Python -> ctypes rw_step_device call per step; the launches are identical")
+                         "default), one Python -> ctypes rw_step_device call per step, or the same launches captured once in a "
+                         "HIP graph (one whole pass over the action tape) and replayed — for rocprofv3 traces of the small "
+                         "kernels, where the profiled host cannot issue single launches fast enough; the launches are identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-rollout measurement (profiling runs)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the fixed 2000-step sustained leg (profiling runs)")
@@ -143,8 +145,15 @@ def main():
     if args.msg_bits:
         kw["msg_bits"] = args.msg_bits
     B, N, AM = args.batch, kw["n_agents"], 1 + args.msg_bits
-    env = rware_amd.WarehouseVecEnv(B, devices=[local_rank], envs_per_workgroup=args.envs_per_wg,
-                                    threads_per_workgroup=args.threads_per_wg, **kw)
+    gstream = None
+    if args.submit == "graph":  # the engine has to sit on a stream torch can capture: its "torch output" mode does that
+        gstream = torch.cuda.Stream(device=local_rank)
+        with torch.cuda.stream(gstream):
+            env = rware_amd.WarehouseVecEnv(B, devices=[local_rank], envs_per_workgroup=args.envs_per_wg,
+                                            threads_per_workgroup=args.threads_per_wg, output="torch", **kw)
+    else:
+        env = rware_amd.WarehouseVecEnv(B, devices=[local_rank], envs_per_workgroup=args.envs_per_wg,
+                                        threads_per_workgroup=args.threads_per_wg, **kw)
     eng = env.engines[0]
     info = eng.info
     # env i of rank r is global env r*B + i -> SeedSequence(r*B + i): results independent of the GPU count
@@ -155,7 +164,27 @@ def main():
     tape = torch.from_numpy(acts).to(f"cuda:{local_rank}")
     base, stride = tape.data_ptr(), B * N * AM * 4
 
+    graph = None
+    if gstream is not None:  # one pass over the whole tape = TAPE_STEPS per-step launches, captured once
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=gstream):
+            eng.step_tape_device(base, TAPE_STEPS, 0, TAPE_STEPS)
+        torch.cuda.synchronize()
+
     def run(n, t_start, many=args.many):
+        if graph is not None and many == 0:
+            t = t_start
+            with torch.cuda.stream(gstream):
+                while t < t_start + n:
+                    if t % TAPE_STEPS == 0 and t + TAPE_STEPS <= t_start + n:
+                        graph.replay()
+                        t += TAPE_STEPS
+                    else:  # up to the next tape boundary / the tail: plain launches on the same stream
+                        c = min(TAPE_STEPS - t % TAPE_STEPS, t_start + n - t)
+                        eng.step_tape_device(base, TAPE_STEPS, t % TAPE_STEPS, c)
+                        t += c
+            return
         if many > 0:
             t = t_start
             while t < t_start + n:
@@ -265,7 +294,8 @@ def main():
                 "submit": f"rw_step_many_device x{args.many} (fused rollout, one launch per chunk)" if args.many
                           else "one rw_step_device launch per step (closed-loop capable kernel), issued by "
                                + ("rw_step_tape_device's native loop over the device action tape" if args.submit == "native"
-                                  else "one Python/ctypes call per step"),
+                                  else "a HIP graph holding one pass over the action tape (captured rw_step_tape_device), replayed"
+                                  if args.submit == "graph" else "one Python/ctypes call per step"),
                 "envs_per_workgroup": int(info.envs_per_workgroup), "threads_per_workgroup": int(info.threads_per_workgroup),
                 "kernel_specialised": bool(info.specialised),
                 "device": info.device_name.decode(), "arch": info.arch_name.decode(),

@@ -42,7 +42,11 @@ for entry in "${CONFIGS[@]}"; do
   D="$OUT/$name"; mkdir -p "$D"
   export RWARE_BENCH_TAPE_STEPS=$tape
   echo "== $name" >&2
-  rocprofv3 --kernel-trace --stats -d "$D/trace" -o bench -- python "$ROOT/bench.py" $COMMON $args --steps $steps --warmup 50 > "$D/trace.out" 2> "$D/trace.err"
+  # small kernels: the profiled host cannot issue single launches as fast as a ~7 us kernel retires them (a third of the
+  # dispatches then start late, on an idle chip) — replay the same per-step launches from a HIP graph for the trace pass
+  SUBMIT=""
+  if [ "$steps" -ge 1000 ] && [[ "$args" != *"--many"* ]] && [ "${SWEEP_TRACE_SUBMIT:-graph}" = "graph" ]; then SUBMIT="--submit graph"; fi
+  rocprofv3 --kernel-trace --stats -d "$D/trace" -o bench -- python "$ROOT/bench.py" $COMMON $args $SUBMIT --steps $steps --warmup 50 > "$D/trace.out" 2> "$D/trace.err"
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c -d "$D/pmc_$c" -o bench -- python "$ROOT/bench.py" $COMMON $args --steps 30 --warmup 10 > "$D/pmc_$c.out" 2> "$D/pmc_$c.err"
   done
