@@ -549,6 +549,27 @@ def test_bench_two_ranks_self_spawned():
     _check_bench_line(out, 2, 200, 20, 4096)
 
 
+def test_bench_graph_submit_mode():
+    """`bench.py --submit graph` (the per-step launches replayed from a HIP graph — what profiles/tools/sweep.sh traces
+    the small kernels with): a valid line, and the same step time as the native loop within a wide margin."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RWARE_BENCH_TAPE_STEPS"] = "64"
+    res = {}
+    for mode in ("graph", "native"):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--submit", mode, "--steps", "700", "--warmup", "30", "--batch", "4096",
+               "--no-cpu-baseline", "--no-fused-extra", "--no-sustained"]
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[mode] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert res[mode]["steps"] == 700 and res[mode]["ms_per_step"] > 0
+    assert "HIP graph" in res["graph"]["config"]["submit"]
+    assert 0.5 < res["graph"]["ms_per_step"] / res["native"]["ms_per_step"] < 2.0
+
+
 def test_bench_two_ranks_through_torchrun():
     """The driver's N > 1 invocation of bench.py (torch.distributed.run, one rank per GPU), exercised on this
     1-GPU box: both ranks share the device (test hook).  Checks the contract of the JSON line and that rank 0
