@@ -1,0 +1,34 @@
+#!/bin/bash
+# End-of-round evidence pass, ONE gpurun call (run on the GPU box from the repo root, ≈6 GPU-minutes):
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/tools/final_pass.sh r03'
+# Order matters: the GPU suite first (a red suite voids everything after it), then the sweep (which writes
+# gpurun_out/pmc_traffic.json), then THAT file into profiles/ BEFORE bench.py runs (bench.py reports `roofline.traffic`
+# only when the file's kernel_sources_sha matches the sources it is running), then the un-profiled lines.
+# Afterwards, in the build container: copy gpurun_out/{pmc_traffic.json, <tag>_*} into profiles/, regenerate the
+# per-config summaries with summarize_rocpd.py (see the loop at the bottom), update DESIGN.md §6, commit.
+set -u
+TAG=${1:-rNN}
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee gpurun_out/${TAG}_gpu_suite.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+bash profiles/tools/sweep.sh $TAG 2>&1 | tail -15
+cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
+python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
+python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_k20.json 2> /dev/null
+python profiles/tools/timeline_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline.txt
+python profiles/tools/timeline_probe.py rware-small-4ag-v1 262144 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_B262144.txt
+TL_OBS_TYPE=2 python profiles/tools/timeline_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_image.txt
+python profiles/tools/timeline_probe.py rware-medium-6ag-hard-v1 8192 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_medium6.txt
+python profiles/tools/k20_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_k20_probe.txt
+bash profiles/tools/unprofiled.sh $TAG > gpurun_out/${TAG}_unprofiled.txt
+cat gpurun_out/${TAG}_unprofiled.txt
+python - <<PY
+import json
+for f in ("gpurun_out/${TAG}_bench_default.json", "gpurun_out/${TAG}_bench_k20.json"):
+    d = json.loads(open(f).read().strip().splitlines()[-1])
+    print(f, "G=%.3f" % (d["value"] / 1e9), "us/step=%.3f" % (d["ms_per_step"] * 1e3), "sustained=%.3f" % (d["sustained"]["ms_per_step"] * 1e3),
+          "traffic=", d["roofline"]["traffic"], "frac=%.3f" % d["roofline"]["frac"], "frac_physical=", d["roofline"]["frac_physical"])
+PY
+# in the build container afterwards:
+#   cp gpurun_out/pmc_traffic.json profiles/; cp gpurun_out/${TAG}_* profiles/
+#   for d in gpurun_out/sweep_${TAG}/*/; do n=$(basename $d); python profiles/tools/summarize_rocpd.py $d > profiles/${TAG}_${n}_kernels.txt; done
