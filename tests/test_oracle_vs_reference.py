@@ -134,3 +134,18 @@ def test_dict_observations_of_the_engine_match_the_reference(env_id, extra):
                 check(g, w)
             assert np.array_equal(np.asarray(rr_, np.float32), rew[b])
     env.close()
+
+
+def test_cpu_baseline_legs_report_cores_and_model():
+    """oracle/cpu_baseline.py — what bench.py prints as `cpu_baseline`: both legs (the unmodified reference step and the
+    C port), one process and several, on a bounded sample; every case states the cores used and the CPU model."""
+    import cpu_baseline as cb
+
+    assert cb.host_cores() >= 1 and isinstance(cb.cpu_model(), str) and cb.cpu_model()
+    one = cb.time_port("rware-small-4ag-v1", 0.3, 1, b=64)
+    two = cb.time_port("rware-small-4ag-v1", 0.3, 2, b=64)
+    assert one > 1e4 and two > 1e4                      # agent-steps/s of the C port: millions per core; far above 1e4 anywhere
+    ref1, standin = cb.time_reference("rware-small-4ag-v1", 0.5, 1)
+    ref2, _ = cb.time_reference("rware-small-4ag-v1", 0.5, 2)
+    assert 1e2 < ref1 < one and 1e2 < ref2              # the pure-Python step: thousands per core
+    assert isinstance(standin, bool)
