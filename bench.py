@@ -74,6 +74,10 @@ def spawn_ranks(n: int):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.DEVNULL))
     os.environ.update(base, RANK="0", LOCAL_RANK="0")
+    import atexit
+
+    # if this rank dies early, the others would sit at the rendezvous until its timeout: take them down with it
+    atexit.register(lambda: [c.kill() for c in children if c.poll() is None])
     return children
 
 
