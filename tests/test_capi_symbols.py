@@ -95,3 +95,7 @@ def test_kernel_isa_has_no_operand_order_sensitive_dpp_folds(tmp_path):
     allowed = {"v_mov_b32_dpp", "v_or_b32_dpp", "v_and_b32_dpp", "v_xor_b32_dpp", "v_add_u32_dpp", "v_max_i32_dpp", "v_max_u32_dpp",
                "v_min_i32_dpp", "v_min_u32_dpp"}
     assert ops <= allowed, f"operand-order-sensitive DPP folds in the kernel ISA: {sorted(ops - allowed)}"
+    # second audit on the same listing: no kernel keeps anything in scratch memory (a register array indexed by a run-time
+    # value ends up there — the chain walk of the first register version of the agent phases did: 2.3 us per step)
+    scratch = [int(v) for v in re.findall(r"^; ScratchSize: (\d+)", out.read_text(), flags=re.M)]
+    assert scratch and all(v == 0 for v in scratch), f"kernels with scratch memory: {scratch}"
