@@ -15,9 +15,11 @@ The printed JSON line carries
   value / ms_per_step   exactly K steps after W warm-up steps, barrier + device sync on both sides
   sustained             the same launches for a fixed 2000 steps after 100 warm-up steps (SURVEY.md §8(d) protocol,
                         spans 4 mass resets) — the steady state, whatever K and W the caller chose
-  roofline              algorithmic bytes per launch / HIP-event time per launch on the engine's stream, vs the 8 TB/s
+  roofline              algorithmic bytes per launch / HIP-event time per launch on the engine's stream (the two events ride
+                        on the first and the last launch of the timed region: rw_step_tape_device_timed), vs the 8 TB/s
                         HBM peak and the 6.29 TB/s measured copy ceiling; `traffic` = physical bytes per launch from
                         the rocprofv3 PMC passes (profiles/pmc_traffic.json, tied to the kernel sources by hash)
+  (--submit graph: the same per-step launches replayed from a HIP graph — for rocprofv3 traces, see profiles/tools/sweep.sh)
   cpu_baseline (N = 1)  the reference's pure-Python step on the host cores when /root/reference exists, else the C port
                         of it, 1 process and one per core, with the core count and CPU model
 """
