@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int M = kMsg ? (Cfg::kM ? Cfg::kM : p.msg_bits) : 0, AM = 1 + M, CW = 7 + M;
     const int L = kMsg ? 8 + CW * CELLS : L0;
     // words of the observation bit string per agent (the image string holds n_layers * CELLS bits per agent)
-    const int OW = kImage ? max(OW0, (p.n_layers * CELLS + 31) / 32) : kMsg ? (L + 31) / 32 : OW0;
+    const int OW = kImage ? max(OW0, (p.n_layers * CELLS + 31) / 32) : kMsg ? (L + 31) / 32 : OW0;  // (LDS carve-up: needed first)
     extern __shared__ __align__(16) int32_t smem[];
 
     int tid = threadIdx.x;
@@ -327,10 +327,25 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int k_goal0 = p.goal_cells[0], k_goal1 = p.goal_cells[1];
     keep_sgpr_ptr(g_shadow, q_ax, q_ay, q_dir, q_carry, q_deliv, q_queue, q_steps, q_inact, q_hw, q_need);
     keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1);
+    // IMAGE kernels: the layer list and its switches belong to the same batch — the image gather used to fetch them where
+    // it uses them (one scalar-cache round trip per layer, per goal cell and per switch, inside the phase that stands between
+    // the agent phases and the first observation store: 2.5 us against 0.7 us for the FLATTENED gather, r02_timeline_image)
+    int k_n_layers = 0, k_directional = 0, k_transposed = 0;
+    int k_layer[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float *q_features = nullptr;
+    if constexpr (kImage) {
+        k_n_layers = p.n_layers; k_directional = p.directional; k_transposed = p.transposed_layers;
+        q_features = p.features;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) k_layer[l] = p.layers[l];
+        keep_sgpr(k_n_layers, k_directional, k_transposed);
+        keep_sgpr(k_layer[0], k_layer[1], k_layer[2], k_layer[3], k_layer[4], k_layer[5], k_layer[6], k_layer[7]);
+        keep_sgpr_ptr(q_features);
+    }
     // wavefront 3 = service wave after the agent phases (see WB); pays off while the observation of a workgroup is
     // small enough that three wavefronts expand it as fast as the stores drain (measured: small-4ag 8.91 -> 8.79 us,
     // fused 4.93 -> 4.56; medium-6ag-hard 8.56 -> 8.40; large-16ag r=2 with 23 K floats per workgroup 43.6 -> 46.1, so not there)
-    const bool split = nw == 4 && nea * (kImage ? p.n_layers * CELLS : L) <= 8192;
+    const bool split = nw == 4 && nea * (kImage ? k_n_layers * CELLS : L) <= 8192;
     const int TW = split ? T - 64 : T;        // threads that gather window rows and expand the observation
     const uint32_t mN = Cfg::kN ? rw_magic18(Cfg::kN) : p.magic_n;
     // optional per-workgroup phase stamps (100 MHz wall clock); one scalar branch per mark when off
@@ -1191,19 +1206,19 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 if (sh > 26) atomicOr(&s_obits[wd + 1], self >> (32 - sh));
             }
         } else {
-            if (p.features)  // IMAGE_DICT feature vector: one-hot direction, on_highway, carrying (:730-738)
+            if (q_features)  // IMAGE_DICT feature vector: one-hot direction, on_highway, carrying (:730-738)
                 for (int i = lane; i < nea; i += 64) {
                     if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
-                    float *f = p.features + ((size_t)e0 * N + i) * 6;
+                    float *f = q_features + ((size_t)e0 * N + i) * 6;
                     const int d = s_dir[i];
                     f[0] = d == 0 ? 1.0f : 0.0f; f[1] = d == 1 ? 1.0f : 0.0f; f[2] = d == 2 ? 1.0f : 0.0f; f[3] = d == 3 ? 1.0f : 0.0f;
                     f[4] = on_highway(s_ay[i] * W + s_ax[i]) ? 1.0f : 0.0f;
                     f[5] = s_carry[i] ? 1.0f : 0.0f;
                 }
-            if (p.transposed_layers)  // layer[ag.x, ag.y] on an (H, W) array (:552, :558): IndexError when out of bounds
+            if (k_transposed)  // layer[ag.x, ag.y] on an (H, W) array (:552, :558): IndexError when out of bounds
                 for (int i = lane; i < nea; i += 64) {  // (envs reset in this launch included: nobody is loaded there)
                     const bool loaded = s_carry[i] && !s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET];
-                    const bool counted = (p.transposed_layers & 1) || loaded;
+                    const bool counted = (k_transposed & 1) || loaded;
                     if (counted && (s_ax[i] >= H || s_ay[i] >= W)) atomicOr(p.status, STATUS_IMAGE_INDEX);
                 }
         }
@@ -1300,12 +1315,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // thread per (agent, layer, image row).
         // thread per (agent, image row): the row's WIN cells are read once and give one WIN-bit mask per
         // property; every requested layer is then one of those masks.
-        const int Limg = p.n_layers * CELLS;
+        const int Limg = k_n_layers * CELLS;
         if (worker)
         for (int w = tid; w < nea * WIN; w += TW) {
             const int i = w / WIN, r = w - i * WIN;
             const int e = rw_div18(i, mN);
-            const int ax = s_ax[i], ay = s_ay[i], d = p.directional ? s_dir[i] : DIR_UP;
+            const int ax = s_ax[i], ay = s_ay[i], d = k_directional ? s_dir[i] : DIR_UP;
             uint32_t m_shelf = 0, m_req = 0, m_agent = 0, m_goal = 0, m_map = 0;
             uint32_t m_tagent = 0, m_tload = 0;  // the transposed layers: an agent / a loaded agent with (x, y) == (row, col)
             // LDS reads in unconditional batches (an off-map cell reads the agent's own cell and is masked): a
@@ -1326,7 +1341,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 gav[cc] = s_ga[c];
                 gsv[cc] = (int)s_gs[c];
                 gtv[cc] = 0;
-                if (p.transposed_layers) {  // layer[ag.x, ag.y]: the agent standing at (x', y') = (y, x)
+                if (k_transposed) {  // layer[ag.x, ag.y]: the agent standing at (x', y') = (y, x)
                     const bool tok = okv[cc] && x < H && y < W;
                     gtv[cc] = tok ? (int)s_ga[tok ? e * HW + x * W + y : own] : 0;
                 }
@@ -1339,13 +1354,16 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 m_agent |= (ida ? 1u : 0u) << cc;
                 m_shelf |= (ids ? 1u : 0u) << cc;
                 m_req |= (ids ? ((rq >> (ids & 31)) & 1u) : 0u) << cc;
-                for (int g = 0; g < p.n_goals; ++g)
+                m_goal |= ((okv[cc] && ((k_n_goals > 0 && k_goal0 == cellv[cc]) || (k_n_goals > 1 && k_goal1 == cellv[cc]))) ? 1u : 0u) << cc;
+                for (int g = 2; g < k_n_goals; ++g)  // (more than two goal cells: custom layouts)
                     if (okv[cc] && p.goal_cells[g] == cellv[cc]) m_goal |= 1u << cc;
                 m_tagent |= ((gtv[cc] & 0x7f) ? 1u : 0u) << cc;
                 m_tload |= ((gtv[cc] & 0x80) ? 1u : 0u) << cc;
             }
-            for (int l = 0; l < p.n_layers; ++l) {
-                const int layer = p.layers[l];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {  // (unrolled over the register copy of the layer list)
+                if (l >= k_n_layers) break;
+                const int layer = k_layer[l];
                 // (AGENT_DIRECTION holds dir + 1 in 1..4: its bit marks the cell, the value is patched in after the
                 //  expansion, see below)
                 const uint32_t bits = layer == LAYER_SHELVES ? m_shelf : layer == LAYER_REQUESTS ? m_req
@@ -1489,7 +1507,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         }
     }
     else {  // IMAGE: every element is a bit of the string; no coordinate slots
-        const int Limg = p.n_layers * CELLS;
+        const int Limg = k_n_layers * CELLS;
         const int nf = nea * Limg, nf4 = nf >> 2;
         float *out = obs_t + (size_t)e0 * N * Limg;  // 16-byte aligned: e0 is a multiple of 4
         if (worker) {
@@ -1510,7 +1528,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         }
         if (worker)
         for (int g = (nf4 << 2) + tid; g < nf; g += TW) out[g] = ((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f;
-        if (p.transposed_layers & 1) {
+        if (k_transposed & 1) {
             // AGENT_DIRECTION (:547-552): the marked cells hold dir + 1, not 1.  Patched after every 0/1 store of
             // the workgroup has completed (full barrier: vmcnt), one thread per (agent, image row) as in P7.
             __syncthreads();
@@ -1518,7 +1536,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             for (int w = tid; w < nea * WIN; w += TW) {
                 const int i = w / WIN, r = w - i * WIN;
                 const int e = rw_div18(i, mN);
-                const int ax = s_ax[i], ay = s_ay[i], d = p.directional ? s_dir[i] : DIR_UP;
+                const int ax = s_ax[i], ay = s_ay[i], d = k_directional ? s_dir[i] : DIR_UP;
                 for (int cc = 0; cc < WIN; ++cc) {
                     int wr = r, wc = cc;
                     if (d == DIR_DOWN) { wr = WIN - 1 - r; wc = WIN - 1 - cc; }
@@ -1529,8 +1547,9 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     const int ida = s_ga[e * HW + x * W + y] & 0x7f;
                     if (!ida) continue;
                     const float v = (float)(s_dir[e * N + ida - 1] + 1);
-                    for (int l = 0; l < p.n_layers; ++l)
-                        if (p.layers[l] == LAYER_AGENT_DIRECTION) out[(size_t)i * Limg + (l * WIN + r) * WIN + cc] = v;
+#pragma unroll
+                    for (int l = 0; l < 8; ++l)
+                        if (l < k_n_layers && k_layer[l] == LAYER_AGENT_DIRECTION) out[(size_t)i * Limg + (l * WIN + r) * WIN + cc] = v;
                 }
             }
         }
