@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int nea = ne * N;
     // agent phases with cross-lane exchange in registers (see AG); kDirect: own record fetched straight into registers
     constexpr bool kRegAG = Cfg::kN >= 1 && Cfg::kN <= 6;  // (N + 2 link codes must fit 3 bits)
-    constexpr bool kDirect = kRegAG && Cfg::kE != 0 && !kMsg;
+    constexpr bool kDirect = kRegAG && Cfg::kE != 0 && (!kMsg || (Cfg::kM >= 1 && Cfg::kM <= 4));  // (message words: one register each)
     // ONE scalar batch, first thing in the kernel, for every field of the parameter block that the stage-in and the agent
     // phases read: left to itself hipcc fetches each field where it is first used — three dependent scalar-cache round
     // trips in the prologue (every launch starts with cold caches) and more inside the agent phases, which run on one
@@ -397,6 +397,9 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // gather, write-back) are written by the agent lanes together with their results.
     const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : q_need;  // OP_RESET: all-ones when no mask was given
     int r_x = 0, r_y = 0, r_d = 0, r_carry = 0, r_deliv = 0, r_act = ACT_NOOP, r_flag = 0, r_steps = 0, r_inact = 0;
+    constexpr int KMW = (kMsg && Cfg::kM) ? Cfg::kM : 1;
+    int r_mw[KMW] = {};   // the action's message words (_MSG builds), r_msg: the agent's stored message
+    int r_msg = 0;
     if constexpr (kDirect) {
         constexpr int KN = Cfg::kN, KG = 64 / KN;
         static_assert(Cfg::kE <= (Cfg::kT / 64) * KG, "every env of the chunk needs its own agent lanes");
@@ -405,7 +408,13 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             const int ge = e0 + le;
             const size_t gi = (size_t)ge * KN + a_idx;
             r_x = q_ax[gi]; r_y = q_ay[gi]; r_d = q_dir[gi]; r_carry = q_carry[gi]; r_deliv = q_deliv[gi];
-            if (op == OP_STEP) r_act = la.actions[gi];
+            if (op == OP_STEP) r_act = la.actions[gi * AM];
+            if constexpr (kMsg) {
+                r_msg = p.amsg[gi];
+                if (op == OP_STEP)
+#pragma unroll
+                    for (int k = 0; k < KMW; ++k) r_mw[k] = la.actions[gi * AM + 1 + k];
+            }
             r_flag = (op == OP_OBS) ? 0 : (int)flag_src[ge];
             r_steps = q_steps[ge];
             r_inact = q_inact[ge];
@@ -474,7 +483,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     if (job % dma_w == wave_s && c + lane < pieces)
                         lds_dma_b128(src[k] + (size_t)(c + lane) * 16, smem + seg[k] + 4 * c);
             }
-            if constexpr (kMsg) {  // the agents' stored messages: a 13th array, outside the contiguous block
+            if constexpr (kMsg && !kDirect) {  // the agents' stored messages: a 13th array, outside the contiguous block
                 const int pieces = (Cfg::kE * Cfg::kN) >> 2;
                 for (int c = 0; c < pieces; c += 64, ++job)
                     if (job % dma_w == wave_s && c + lane < pieces)
@@ -620,16 +629,30 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         int a = ACT_NOOP;
         if (!kEarly && mine) {
             if (stepping) a = (t == 0) ? a_lds : (act_prefetch ? a_pref : act_t[((size_t)ge * KN + a_idx) * AM]);
-            if (kMsg && stepping) {  // agent.message[:] = action[1:] — for every agent, whatever its move does (:812)
-                int msg = 0;
-                for (int k = 0; k < M; ++k) {
-                    const int v = (t == 0) ? s_act[i * AM + 1 + k] : act_t[((size_t)ge * KN + a_idx) * AM + 1 + k];
-                    if ((unsigned)v > 1u) atomicOr(p.status, STATUS_INVALID_ACTION);  // MultiDiscrete([5, 2, 2, ...])
-                    msg |= (v & 1) << k;
-                }
-                s_msg[i] = msg;
-            }
             if (act_prefetch && t + 1 < n_steps) a_pref = (act_t + la.act_stride)[(size_t)ge * KN + a_idx];
+        }
+        if constexpr (kMsg && kDirect) {  // agent.message[:] = action[1:] — for every agent, whatever its move does (:812)
+            if (mine) {
+                int msg = r_msg;  // an env that does not step keeps its stored messages (first step of the launch: registers)
+                if (stepping) {
+                    msg = 0;
+#pragma unroll
+                    for (int k = 0; k < KMW; ++k) {
+                        const int v = (t == 0) ? r_mw[k] : act_t[((size_t)ge * KN + a_idx) * AM + 1 + k];
+                        if (RW_RARE((unsigned)v > 1u)) atomicOr(p.status, STATUS_INVALID_ACTION);  // MultiDiscrete([5, 2, 2, ...])
+                        msg |= (v & 1) << k;
+                    }
+                }
+                if (stepping || t == 0) s_msg[i] = msg;
+            }
+        } else if (kMsg && mine && stepping) {
+            int msg = 0;
+            for (int k = 0; k < M; ++k) {
+                const int v = (t == 0) ? s_act[i * AM + 1 + k] : act_t[((size_t)ge * KN + a_idx) * AM + 1 + k];
+                if ((unsigned)v > 1u) atomicOr(p.status, STATUS_INVALID_ACTION);  // MultiDiscrete([5, 2, 2, ...])
+                msg |= (v & 1) << k;
+            }
+            s_msg[i] = msg;
         }
         // ------------------------------------------------------------ P1: intent (:825-846), branch-free
         Intent in = kEarly ? early : intent_of(stepping, a, x, y, d);
