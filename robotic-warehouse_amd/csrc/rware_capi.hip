@@ -93,16 +93,24 @@ struct StaticEntry {
     int max_B;  // with the default geometry: chosen only for batches up to this size (0 = any); first match wins
     int image;  // 1: IMAGE / IMAGE_DICT observations (any layer list), 0: FLATTENED
     int M;      // communication bits the build was made for
+    int NL;     // IMAGE builds: > 0 = the layer list baked in (`layers`: 4 bits per id, first layer lowest) with `directional`
+    uint32_t layers;
+    int directional;
     step_kernel_t fn, fn_rollout;
 };
 #define RW_STATIC(H, W, N, Q, S, R, E, T, MAXB)                                                                   \
-    {H, W, N, Q, S, R, E, T, MAXB, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
+    {H, W, N, Q, S, R, E, T, MAXB, 0, 0, 0, 0u, -1, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true>}
 #define RW_STATIC_IMAGE(H, W, N, Q, S, R, E, T, MAXB)                                                             \
-    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false, rw::OBS_IMAGE>, \
+    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, 0, 0u, -1, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false, rw::OBS_IMAGE>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true, rw::OBS_IMAGE>}
+// ... with the layer list and the directional switch baked in (the gather's per-layer selects fold away)
+#define RW_STATIC_IMAGE_LAYERS(H, W, N, Q, S, R, E, T, MAXB, NL, LAYERS, DIR)                                      \
+    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, NL, LAYERS, DIR,                                                           \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, false, rw::OBS_IMAGE>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, true, rw::OBS_IMAGE>}
 #define RW_STATIC_MSG(H, W, N, Q, S, R, E, T, MAXB, M)                                                            \
-    {H, W, N, Q, S, R, E, T, MAXB, 0, M, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, false, rw::OBS_FLATTENED_MSG>, \
+    {H, W, N, Q, S, R, E, T, MAXB, 0, M, 0, 0u, -1, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, false, rw::OBS_FLATTENED_MSG>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, true, rw::OBS_FLATTENED_MSG>}
 const StaticEntry kStatic[] = {
     // half-size workgroups for batches that leave the CUs short of workgroups at E = 16 (measured, round 2:
@@ -123,6 +131,10 @@ const StaticEntry kStatic[] = {
     RW_STATIC(20, 10, 4, 2, 80, 1, 16, 256, 0),    // rware-small-4ag-hard
     // the "next" observation kinds callers hit first: IMAGE / IMAGE_DICT (any layer list, directional
     // or not) and FLATTENED with 1 or 2 communication bits, on the two smallest BASELINE tasks
+    // (first the reference's default layer list — SHELVES, REQUESTS, AGENTS, GOALS, ACCESSIBLE, directional — baked in,
+    //  then the any-list builds)
+    RW_STATIC_IMAGE_LAYERS(20, 10, 4, 4, 80, 1, 16, 256, 0, 5, 0x65210u, 1),
+    RW_STATIC_IMAGE_LAYERS(11, 10, 2, 2, 32, 1, 16, 256, 0, 5, 0x65210u, 1),
     RW_STATIC_IMAGE(20, 10, 4, 4, 80, 1, 16, 256, 0),
     RW_STATIC_IMAGE(11, 10, 2, 2, 32, 1, 16, 256, 0),
     RW_STATIC_MSG(20, 10, 4, 4, 80, 1, 16, 256, 0, 1),
@@ -385,6 +397,11 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             for (const StaticEntry &se : kStatic) {
                 if ((se.N != 0) != (exact != 0)) continue;
                 if (se.image != (eng->image ? 1 : 0) || se.M != eng->msg_bits) continue;
+                if (se.NL > 0) {  // a baked-in layer list serves exactly that list
+                    uint32_t packed = 0;
+                    for (int l = 0; l < n_layers && l < 8; ++l) packed |= (uint32_t)layers[l] << (4 * l);
+                    if (se.NL != n_layers || se.layers != packed || se.directional != (cfg->image_directional ? 1 : 0)) continue;
+                }
                 const bool shape = se.H == H && se.W == W && se.S == S && se.R == R && (se.N == 0 || (se.N == N && se.Q == Q));
                 if (!shape || B % se.E != 0) continue;
                 if (geom_default ? (se.max_B == 0 || B <= se.max_B) : (E == se.E && T == se.T)) { best = &se; break; }

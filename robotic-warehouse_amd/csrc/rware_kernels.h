@@ -212,11 +212,25 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
 // at run time — one such build covers every registered id of a warehouse size.
 struct DynamicCfg {
     static constexpr int kH = 0, kW = 0, kN = 0, kQ = 0, kS = 0, kE = 0, kT = 0, kM = 0;
+    static constexpr int kNL = 0, kDirectional = -1;
+    static constexpr uint32_t kLayers = 0;
 };
-template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_, int M_ = 0>  // M_: communication bits (the _MSG kernels)
+// M_: communication bits (the _MSG kernels).  NL_ / LAYERS_ / DIR_ (IMAGE kernels): a layer list baked in — NL_ layer ids,
+// 4 bits each, first layer in the low nibble — and the `image_observation_directional` switch; NL_ == 0: any list, at run time.
+template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_, int M_ = 0, int NL_ = 0, uint32_t LAYERS_ = 0, int DIR_ = -1>
 struct StaticCfg {
     static constexpr int kH = H_, kW = W_, kN = N_, kQ = Q_, kS = S_, kE = E_, kT = T_, kM = M_;
+    static constexpr int kNL = NL_, kDirectional = DIR_;
+    static constexpr uint32_t kLayers = LAYERS_;
 };
+constexpr int packed_transposed_layers(uint32_t packed, int n) {  // Params::transposed_layers of a packed list
+    int t = 0;
+    for (int l = 0; l < n; ++l) {
+        const int id = (int)((packed >> (4 * l)) & 15u);
+        t |= (id == 3 ? 1 : 0) | (id == 4 ? 2 : 0);  // LAYER_AGENT_DIRECTION, LAYER_AGENT_LOAD
+    }
+    return t;
+}
 
 // Asynchronous flat dword copy HBM -> LDS through the LDS-DMA path.  dwordx4 pieces (1 KiB per wave
 // instruction) when the source is 16-byte aligned, dword pieces otherwise; `lds_dst` is 16-byte
@@ -295,7 +309,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int M = kMsg ? (Cfg::kM ? Cfg::kM : p.msg_bits) : 0, AM = 1 + M, CW = 7 + M;
     const int L = kMsg ? 8 + CW * CELLS : L0;
     // words of the observation bit string per agent (the image string holds n_layers * CELLS bits per agent)
-    const int OW = kImage ? max(OW0, (p.n_layers * CELLS + 31) / 32) : kMsg ? (L + 31) / 32 : OW0;  // (LDS carve-up: needed first)
+    const int OW = kImage ? max(OW0, ((Cfg::kNL > 0 ? Cfg::kNL : p.n_layers) * CELLS + 31) / 32) : kMsg ? (L + 31) / 32 : OW0;  // (LDS carve-up: needed first)
     extern __shared__ __align__(16) int32_t smem[];
 
     int tid = threadIdx.x;
@@ -334,13 +348,21 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     int k_layer[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float *q_features = nullptr;
     if constexpr (kImage) {
-        k_n_layers = p.n_layers; k_directional = p.directional; k_transposed = p.transposed_layers;
         q_features = p.features;
-#pragma unroll
-        for (int l = 0; l < 8; ++l) k_layer[l] = p.layers[l];
-        keep_sgpr(k_n_layers, k_directional, k_transposed);
-        keep_sgpr(k_layer[0], k_layer[1], k_layer[2], k_layer[3], k_layer[4], k_layer[5], k_layer[6], k_layer[7]);
         keep_sgpr_ptr(q_features);
+        if constexpr (Cfg::kNL > 0) {  // the layer list is part of the build: every select on a layer id folds
+            k_n_layers = Cfg::kNL;
+            k_directional = Cfg::kDirectional;
+            k_transposed = packed_transposed_layers(Cfg::kLayers, Cfg::kNL);
+#pragma unroll
+            for (int l = 0; l < 8; ++l) k_layer[l] = (int)((Cfg::kLayers >> (4 * l)) & 15u);
+        } else {
+            k_n_layers = p.n_layers; k_directional = p.directional; k_transposed = p.transposed_layers;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) k_layer[l] = p.layers[l];
+            keep_sgpr(k_n_layers, k_directional, k_transposed);
+            keep_sgpr(k_layer[0], k_layer[1], k_layer[2], k_layer[3], k_layer[4], k_layer[5], k_layer[6], k_layer[7]);
+        }
     }
     // wavefront 3 = service wave after the agent phases (see WB); pays off while the observation of a workgroup is
     // small enough that three wavefronts expand it as fast as the stores drain (measured: small-4ag 8.91 -> 8.79 us,
