@@ -337,10 +337,15 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const uint32_t *const q_hw = p.highway_bits;
     const uint8_t *const q_need = p.need_reset;
     const int k_reward_type = p.reward_type, k_max_inactivity = p.max_inactivity, k_max_steps = p.max_steps;
-    const int k_autoreset = p.autoreset, k_n_goals = p.n_goals;
+    const int k_autoreset = p.autoreset, k_n_goals = p.n_goals, k_normalised = p.normalised;
     const int k_goal0 = p.goal_cells[0], k_goal1 = p.goal_cells[1];
-    keep_sgpr_ptr(g_shadow, q_ax, q_ay, q_dir, q_carry, q_deliv, q_queue, q_steps, q_inact, q_hw, q_need);
-    keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1);
+    // (exact-shape builds whose LDS carve-up is a compile-time constant clear their scratch regions while this batch is in
+    //  flight and pin it afterwards — kClearFirst, below; the others pin it here)
+    constexpr bool kClearFirst = Cfg::kN != 0 && Cfg::kE != 0 && (!kImage || Cfg::kNL > 0) && (!kMsg || Cfg::kM != 0);
+    if constexpr (!kClearFirst) {
+        keep_sgpr_ptr(g_shadow, q_ax, q_ay, q_dir, q_carry, q_deliv, q_queue, q_steps, q_inact, q_hw, q_need);
+        keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
+    }
     // IMAGE kernels: the layer list and its switches belong to the same batch — the image gather used to fetch them where
     // it uses them (one scalar-cache round trip per layer, per goal cell and per switch, inside the phase that stands between
     // the agent phases and the first observation store: 2.5 us against 0.7 us for the FLATTENED gather, r02_timeline_image)
@@ -399,7 +404,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     int32_t *s_misc = smem + lo.misc;
     auto on_highway = [&](int c) -> bool { return (s_hw[c >> 5] >> (c & 31)) & 1u; };
     auto coordf = [&](int k, int v) -> float {
-        if (p.normalised) return (float)((double)v / (double)((k == 0 ? W : H) - 1));  // :636-638
+        if (k_normalised) return (float)((double)v / (double)((k == 0 ? W : H) - 1));  // :636-638
         return (float)v;
     };
 
@@ -417,6 +422,11 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // first thing in the kernel: the loads fly beside the clear and the stage-in DMA, are complete at the barrier that
     // drains the DMA, and the agent phases start without an LDS read.  The LDS copies the later phases read (window
     // gather, write-back) are written by the agent lanes together with their results.
+    if constexpr (kClearFirst) {  // the LDS clear needs no parameter: it runs under the scalar batch's (cold) round trip
+        clear_scratch();
+        keep_sgpr_ptr(g_shadow, q_ax, q_ay, q_dir, q_carry, q_deliv, q_queue, q_steps, q_inact, q_hw, q_need);
+        keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
+    }
     const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : q_need;  // OP_RESET: all-ones when no mask was given
     int r_x = 0, r_y = 0, r_d = 0, r_carry = 0, r_deliv = 0, r_act = ACT_NOOP, r_flag = 0, r_steps = 0, r_inact = 0;
     constexpr int KMW = (kMsg && Cfg::kM) ? Cfg::kM : 1;
@@ -471,7 +481,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // intent and occupant in that window, before the barrier that everything else of the agent phases has to wait for.
     constexpr bool kEarly = kDirect && !kRollout && Cfg::kT >= 128;
     Intent early{ACT_NOOP, 0, 0, 0, 0, -1};
-    clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
+    if constexpr (!kClearFirst) clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
     RW_MARK(TL_ZEROED);
     if constexpr (Cfg::kE != 0) {
         // Static build: every DMA destination is contiguous in LDS and every source chunk is a whole
@@ -578,7 +588,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         RW_MARK(TL_ENV_LOADED);
         __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
     }
-    keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1);
+    keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
     RW_MARK(TL_LOADED);
 
     // kRollout == false is the single-step kernel (rw_step / rw_reset / rw_refresh_obs): no loop at all.
@@ -1462,7 +1472,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // headline batch, -7 % at the cache-exceeding batches).
         // (not in the fused rollout: its steps are bound by instruction issue, not by the store stream, and the single pass
         //  costs ~10 more VALU operations per float4: 4.16 -> 4.78 us per step there)
-        const bool xy_bytes = !kRollout && !p.normalised;  // workgroup-uniform
+        const bool xy_bytes = !kRollout && !k_normalised;  // workgroup-uniform
         if (worker && xy_bytes) {
             const int shift = (tid & 7) << 2, words_per_pass = TW >> 3;  // (TW % 8 == 0)
             const uint32_t *wp = s_obits + (tid >> 3);
