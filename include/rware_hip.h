@@ -237,7 +237,7 @@ typedef struct rw_info {
     int32_t envs_per_workgroup, threads_per_workgroup, n_workgroups, lds_bytes;
     int32_t device_id, compute_units;
     int32_t specialised;  /* 1: a kernel build with this task's shapes folded in at compile time is in use */
-    int32_t reserved_;
+    int32_t state_layout; /* 0: the shelf layer is staged from the per-cell shadow; 1: from the per-shelf position array (big batches) */
     int64_t algorithmic_bytes_per_env_step; /* SURVEY.md §8(d) formula                           */
     char device_name[128];
     char arch_name[64];

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -53,6 +54,9 @@ struct rw_engine {
     void *slab = nullptr;      // the single device allocation behind every buffer below
     size_t shadow_off = 0;
     void *d_shadow = nullptr;  // compact shelf layer (uint8 when S <= 255, else uint16), the kernel's read path
+    size_t pos_off = 0;
+    uint8_t *d_pos = nullptr;  // [B][S] cell of every shelf: the shelf layer of the POSITION layout (pos_layout), else unused
+    bool pos_layout = false;   // the step kernels stage the shelf layer from d_pos; d_shadow is then a derived view (sync_shadow)
     bool wide = false;
     bool image = false;        // IMAGE / IMAGE_DICT observation kernels
     int msg_bits = 0;          // communication bits per agent (FLATTENED only)
@@ -93,18 +97,34 @@ struct StaticEntry {
     int max_B;  // with the default geometry: chosen only for batches up to this size (0 = any); first match wins
     int image;  // 1: IMAGE / IMAGE_DICT observations (any layer list), 0: FLATTENED
     int M;      // communication bits the build was made for
+    int NL;     // IMAGE builds: > 0 = the layer list baked in (`layers`: 4 bits per id, first layer lowest) with `directional`
+    uint32_t layers;
+    int directional;
+    int pos;    // 1: POSITION state layout (rw::StaticCfg POS_), picked for batches of at least `min_B` envs
+    int min_B;
     step_kernel_t fn, fn_rollout;
 };
 #define RW_STATIC(H, W, N, Q, S, R, E, T, MAXB)                                                                   \
-    {H, W, N, Q, S, R, E, T, MAXB, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
+    {H, W, N, Q, S, R, E, T, MAXB, 0, 0, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true>}
 #define RW_STATIC_IMAGE(H, W, N, Q, S, R, E, T, MAXB)                                                             \
-    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false, rw::OBS_IMAGE>, \
+    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false, rw::OBS_IMAGE>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true, rw::OBS_IMAGE>}
+// ... with the layer list and the directional switch baked in (the gather's per-layer selects fold away)
+#define RW_STATIC_IMAGE_LAYERS(H, W, N, Q, S, R, E, T, MAXB, NL, LAYERS, DIR)                                      \
+    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, NL, LAYERS, DIR, 0, 0,                                                     \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, false, rw::OBS_IMAGE>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, true, rw::OBS_IMAGE>}
 #define RW_STATIC_MSG(H, W, N, Q, S, R, E, T, MAXB, M)                                                            \
-    {H, W, N, Q, S, R, E, T, MAXB, 0, M, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, false, rw::OBS_FLATTENED_MSG>, \
+    {H, W, N, Q, S, R, E, T, MAXB, 0, M, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, false, rw::OBS_FLATTENED_MSG>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, true, rw::OBS_FLATTENED_MSG>}
+// FLATTENED builds on the POSITION state layout, for batches of at least MINB envs (a step's traffic past the Infinity Cache)
+#define RW_STATIC_POS(H, W, N, Q, S, R, E, T, MINB)                                                                \
+    {H, W, N, Q, S, R, E, T, 0, 0, 0, 0, 0u, -1, 1, MINB,                                                           \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true>, false>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true>, true>}
 const StaticEntry kStatic[] = {
+    RW_STATIC_POS(20, 10, 4, 4, 80, 1, 16, 256, 196608),   // rware-small-4ag past the Infinity Cache (>= 224 MB of observations per step)
     // half-size workgroups for batches that leave the CUs short of workgroups at E = 16 (measured, round 2:
     // medium-6ag-hard B=8192 9.16 -> 7.98 us, B=4096 7.86 -> 6.71; B=16384 11.2 vs 13.1 the other way round)
     RW_STATIC(20, 16, 6, 3, 144, 1, 8, 256, 8192),
@@ -123,6 +143,10 @@ const StaticEntry kStatic[] = {
     RW_STATIC(20, 10, 4, 2, 80, 1, 16, 256, 0),    // rware-small-4ag-hard
     // the "next" observation kinds callers hit first: IMAGE / IMAGE_DICT (any layer list, directional
     // or not) and FLATTENED with 1 or 2 communication bits, on the two smallest BASELINE tasks
+    // (first the reference's default layer list — SHELVES, REQUESTS, AGENTS, GOALS, ACCESSIBLE, directional — baked in,
+    //  then the any-list builds)
+    RW_STATIC_IMAGE_LAYERS(20, 10, 4, 4, 80, 1, 16, 256, 0, 5, 0x65210u, 1),
+    RW_STATIC_IMAGE_LAYERS(11, 10, 2, 2, 32, 1, 16, 256, 0, 5, 0x65210u, 1),
     RW_STATIC_IMAGE(20, 10, 4, 4, 80, 1, 16, 256, 0),
     RW_STATIC_IMAGE(11, 10, 2, 2, 32, 1, 16, 256, 0),
     RW_STATIC_MSG(20, 10, 4, 4, 80, 1, 16, 256, 0, 1),
@@ -137,6 +161,7 @@ const StaticEntry kStatic[] = {
 #undef RW_STATIC
 #undef RW_STATIC_IMAGE
 #undef RW_STATIC_MSG
+#undef RW_STATIC_POS
 
 int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     la.op = op | (la.timeline ? rw::OP_FLAG_TIMELINE : 0);
@@ -162,6 +187,22 @@ int rebuild_shadow(rw_engine *eng) {
     else
         hipLaunchKernelGGL((rw::rware_shadow_kernel<uint8_t>), dim3(blocks), dim3(256), 0, eng->stream,
                            (const int32_t *)eng->buf[RW_BUF_GRID].ptr, (uint8_t *)eng->d_shadow, B, HW);
+    if (eng->pos_layout)  // the kernels read the shelf layer from the position array: bring it along
+        hipLaunchKernelGGL((rw::rware_pos_from_shadow_kernel<>), dim3(blocks), dim3(256), 0, eng->stream,
+                           (const uint8_t *)eng->d_shadow, eng->d_pos, B, HW, eng->prm.S);
+    RW_HIP(eng, hipGetLastError());
+    return RW_OK;
+}
+
+// POSITION layout: the shadow is a derived view of the position array; rebuilt before anything reads it
+int sync_shadow(rw_engine *eng) {
+    if (!eng->pos_layout) return RW_OK;
+    const int B = eng->prm.B, HW = eng->prm.HW, S = eng->prm.S;
+    const size_t n = (size_t)B * S;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    RW_HIP(eng, hipMemsetAsync(eng->d_shadow, 0, (size_t)B * HW, eng->stream));
+    hipLaunchKernelGGL((rw::rware_shadow_from_pos_kernel<>), dim3(blocks), dim3(256), 0, eng->stream,
+                       (const uint8_t *)eng->d_pos, (uint8_t *)eng->d_shadow, B, HW, S);
     RW_HIP(eng, hipGetLastError());
     return RW_OK;
 }
@@ -169,6 +210,7 @@ int rebuild_shadow(rw_engine *eng) {
 // RW_BUF_GRID is a derived view: brought up to date from the shelf shadow and the agent coordinates when it is asked for
 int refresh_grid(rw_engine *eng) {
     if (!eng->grid_stale) return RW_OK;
+    { const int rc = sync_shadow(eng); if (rc != RW_OK) return rc; }
     const int B = eng->prm.B, HW = eng->prm.HW, W = eng->prm.W, N = eng->prm.N;
     const size_t n = (size_t)B * HW, na = (size_t)B * N;
     // (grid-stride loops, one wavefront per workgroup, 64 cells / agents per thread: a few thousand workgroups at the big batches)
@@ -385,6 +427,16 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             for (const StaticEntry &se : kStatic) {
                 if ((se.N != 0) != (exact != 0)) continue;
                 if (se.image != (eng->image ? 1 : 0) || se.M != eng->msg_bits) continue;
+                if (se.pos) {  // RWARE_STATE_LAYOUT=pos|shadow overrides the batch-size rule (test hook)
+                    const char *pref = getenv("RWARE_STATE_LAYOUT");
+                    const bool force = pref && !strcmp(pref, "pos"), never = pref && !strcmp(pref, "shadow");
+                    if (never || (!force && B < se.min_B)) continue;
+                }
+                if (se.NL > 0) {  // a baked-in layer list serves exactly that list
+                    uint32_t packed = 0;
+                    for (int l = 0; l < n_layers && l < 8; ++l) packed |= (uint32_t)layers[l] << (4 * l);
+                    if (se.NL != n_layers || se.layers != packed || se.directional != (cfg->image_directional ? 1 : 0)) continue;
+                }
                 const bool shape = se.H == H && se.W == W && se.S == S && se.R == R && (se.N == 0 || (se.N == N && se.Q == Q));
                 if (!shape || B % se.E != 0) continue;
                 if (geom_default ? (se.max_B == 0 || B <= se.max_B) : (E == se.E && T == se.T)) { best = &se; break; }
@@ -395,12 +447,13 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             eng->kernel = best->fn;
             eng->kernel_rollout = best->fn_rollout;
             eng->specialised = true;
+            eng->pos_layout = best->pos != 0;
         }
     }
     eng->E = E;
     eng->T = T;
     eng->n_wg = (B + E - 1) / E;
-    eng->lds_bytes = sizeof(int32_t) * (size_t)rw::make_lds_layout(E, N, Q, HW, SW, eng->OW, cell_bytes, AM).total;
+    eng->lds_bytes = sizeof(int32_t) * (size_t)rw::make_lds_layout(E, N, Q, HW, SW, eng->OW, cell_bytes, AM, eng->pos_layout ? S : 0).total;
     if (eng->lds_bytes > 160 * 1024) {
         fail(eng, RW_ERR_INVALID_ARG, "LDS footprint %zu B exceeds 160 KiB; lower envs_per_workgroup", eng->lds_bytes);
         return bail(RW_ERR_INVALID_ARG);
@@ -447,12 +500,15 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         if (k == RW_BUF_ACTIONS) {  // the shelf shadow rides with the hot set
             eng->shadow_off = slab_bytes;
             slab_bytes += up(szB * HW * cell_bytes + 16);
+            eng->pos_off = slab_bytes;
+            slab_bytes += up(szB * S + 16);
         }
     }
     RW_HIP_C(hipMalloc(&eng->slab, slab_bytes));
     RW_HIP_C(hipMemsetAsync(eng->slab, 0, slab_bytes, eng->stream));
     for (int k = 0; k < RW_BUF_KIND_COUNT; ++k) eng->buf[k].ptr = (char *)eng->slab + off[k];
     eng->d_shadow = (char *)eng->slab + eng->shadow_off;
+    eng->d_pos = (uint8_t *)eng->slab + eng->pos_off;
     const int HWW = (HW + 31) / 32;
     // the static kernels stage the bitmap in whole 16-byte pieces: allocate (and zero) the rounded-up size
     const size_t hw_bytes = sizeof(uint32_t) * (size_t)rw::rw_up4(HWW);
@@ -501,6 +557,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.steps = (int32_t *)eng->buf[RW_BUF_STEPS].ptr;
     p.inactive = (int32_t *)eng->buf[RW_BUF_INACTIVE].ptr;
     p.shelf_shadow = eng->d_shadow;
+    p.shelf_pos = eng->d_pos;
     p.rng = (uint64_t *)eng->buf[RW_BUF_RNG].ptr;
     p.need_reset = (uint8_t *)eng->buf[RW_BUF_NEED_RESET].ptr;
     p.truncated = (uint8_t *)eng->buf[RW_BUF_TRUNCATED].ptr;
@@ -722,6 +779,7 @@ std::vector<std::pair<void *, size_t>> state_pieces(rw_engine *eng) {
     std::vector<std::pair<void *, size_t>> v;
     for (int k : kinds) v.emplace_back(eng->buf[k].ptr, eng->buf[k].bytes);
     v.emplace_back(eng->d_shadow, (size_t)eng->prm.B * eng->prm.HW * (eng->wide ? 2 : 1));
+    if (eng->pos_layout) v.emplace_back(eng->d_pos, (size_t)eng->prm.B * eng->prm.S);
     return v;
 }
 }  // namespace
@@ -883,6 +941,7 @@ int rw_get_info(const rw_engine *eng, rw_info *out) {
     out->device_id = eng->cfg.device_id;
     out->compute_units = eng->prop.multiProcessorCount;
     out->specialised = eng->specialised ? 1 : 0;
+    out->state_layout = eng->pos_layout ? 1 : 0;
     // A = 8HW + 4N + 40N + 4Q + 16 + 4NL + 4N + 4
     out->algorithmic_bytes_per_env_step =
         8LL * p.HW + 4LL * p.N + 40LL * p.N + 4LL * p.Q + 16 + 4LL * p.N * eng->L + 4LL * p.N + 4;

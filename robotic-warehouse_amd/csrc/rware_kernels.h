@@ -99,6 +99,7 @@ struct Params {
     uint32_t magic_n;                  // ceil(2^18 / N): x / N == (x * magic) >> 18 for x * N < 2^18
     int32_t goal_cells[MAX_GOALS];     // cell index y*W+x per goal, list order
     const int32_t *shelf_init;     // [HW] shelf layer right after reset: ids 1..S row-major on non-highway cells
+    uint8_t *shelf_pos;            // [B][S] cell of shelf id k+1 — the shelf layer of the POSITION state layout (Cfg::kPos), else unused
     // state (device)
     int32_t *grid;
     uint8_t *truncated;   // [B]
@@ -156,6 +157,7 @@ struct LdsLayout {
     // DMA destinations, contiguous in exactly this order (the static builds fill them with ONE linear
     // LDS-DMA stream): shelf layer, agent SoA, actions, queue, highway bitmap, per-env counters/flags
     int gs, ax, ay, dir, carry, deliv, act, queue, hw, dsteps, dinact, dflag, dma_end;
+    int pos;  // POSITION layout: the chunk's shelf positions take the first DMA slot; `gs` then lies in the cleared block
     int ga, zero_end;  // cleared every launch
     int tgt, nxt, depth, win, rew, mv, msg, fx, fy, req, obits, envi, misc, total;
 };
@@ -167,11 +169,14 @@ RW_HD int rw_up4(int x) { return (x + 3) & ~3; }
 RW_HD uint32_t rw_magic18(int d) { return d > 0 ? (uint32_t)(((1u << 18) + (uint32_t)d - 1u) / (uint32_t)d) : 0u; }
 RW_HD int rw_div18(int x, uint32_t magic) { return (int)(((uint32_t)x * magic) >> 18); }
 
-RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int cell_bytes, int act_words = 1) {
+RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int cell_bytes, int act_words = 1, int pos_shelves = 0) {
     LdsLayout l;
     int o = 0;
     const int en = rw_up4(E * N);
-    l.gs = o;     o += rw_up4((E * HW * cell_bytes + 3) / 4);  // shelf layer, CellT per cell
+    l.pos = -1;
+    l.gs = o;
+    if (pos_shelves) { l.pos = o; o += rw_up4((E * pos_shelves + 3) / 4); }   // 1 byte per shelf
+    else o += rw_up4((E * HW * cell_bytes + 3) / 4);  // shelf layer, CellT per cell
     l.ax = o;     o += en;
     l.ay = o;     o += en;
     l.dir = o;    o += en;
@@ -185,6 +190,7 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
     l.dflag = o;  o += rw_up4((E + 3) / 4);                    // bytes
     l.dma_end = o;
     l.ga = o;     o += rw_up4((E * HW + 3) / 4);               // agent layer, 1 byte per cell: id | 0x80 if loaded
+    if (pos_shelves) { l.gs = o; o += rw_up4((E * HW * cell_bytes + 3) / 4); }  // rebuilt from the positions every launch
     l.zero_end = o;
     l.tgt = o;    o += en;
     l.nxt = o;    o += en;
@@ -212,11 +218,30 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
 // at run time — one such build covers every registered id of a warehouse size.
 struct DynamicCfg {
     static constexpr int kH = 0, kW = 0, kN = 0, kQ = 0, kS = 0, kE = 0, kT = 0, kM = 0;
+    static constexpr int kNL = 0, kDirectional = -1;
+    static constexpr uint32_t kLayers = 0;
+    static constexpr bool kPos = false;
 };
-template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_, int M_ = 0>  // M_: communication bits (the _MSG kernels)
+// M_: communication bits (the _MSG kernels).  NL_ / LAYERS_ / DIR_ (IMAGE kernels): a layer list baked in — NL_ layer ids,
+// 4 bits each, first layer in the low nibble — and the `image_observation_directional` switch; NL_ == 0: any list, at run time.
+// POS_: the shelf layer lives in HBM as one cell index per shelf (Params::shelf_pos) instead of one shelf id per cell
+// (the shadow): 80 instead of 200 bytes per small-4ag env to stage in, and a write-back that is one coalesced store of
+// whole lines instead of scattered 1-byte patches — the layout for batches whose traffic no longer fits the Infinity Cache.
+template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_, int M_ = 0, int NL_ = 0, uint32_t LAYERS_ = 0, int DIR_ = -1, bool POS_ = false>
 struct StaticCfg {
     static constexpr int kH = H_, kW = W_, kN = N_, kQ = Q_, kS = S_, kE = E_, kT = T_, kM = M_;
+    static constexpr int kNL = NL_, kDirectional = DIR_;
+    static constexpr uint32_t kLayers = LAYERS_;
+    static constexpr bool kPos = POS_;
 };
+constexpr int packed_transposed_layers(uint32_t packed, int n) {  // Params::transposed_layers of a packed list
+    int t = 0;
+    for (int l = 0; l < n; ++l) {
+        const int id = (int)((packed >> (4 * l)) & 15u);
+        t |= (id == 3 ? 1 : 0) | (id == 4 ? 2 : 0);  // LAYER_AGENT_DIRECTION, LAYER_AGENT_LOAD
+    }
+    return t;
+}
 
 // Asynchronous flat dword copy HBM -> LDS through the LDS-DMA path.  dwordx4 pieces (1 KiB per wave
 // instruction) when the source is 16-byte aligned, dword pieces otherwise; `lds_dst` is 16-byte
@@ -280,6 +305,26 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
     }
 }
 
+// POSITION state layout (Cfg::kPos): the two conversions between the position array and the shelf shadow the host paths use
+// (after a host write of the grid: shadow -> positions; before the grid view / a snapshot is built: positions -> a zeroed shadow)
+template <typename Dummy = void>
+__global__ void rware_pos_from_shadow_kernel(const uint8_t *shadow, uint8_t *pos, int B, int HW, int S) {
+    const size_t n = (size_t)B * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / HW;
+        const int id = shadow[i];
+        if (id) pos[e * S + id - 1] = (uint8_t)(i - e * HW);
+    }
+}
+template <typename Dummy = void>
+__global__ void rware_shadow_from_pos_kernel(const uint8_t *pos, uint8_t *shadow, int B, int HW, int S) {
+    const size_t n = (size_t)B * S;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / S;
+        shadow[e * HW + pos[i]] = (uint8_t)(i - e * S + 1);
+    }
+}
+
 template <int R, typename CellT, typename Cfg, bool kRollout, int kObs = OBS_FLATTENED>
 __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L0 = 8 + 7 * CELLS, OW0 = (L0 + 31) / 32;
@@ -295,7 +340,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int M = kMsg ? (Cfg::kM ? Cfg::kM : p.msg_bits) : 0, AM = 1 + M, CW = 7 + M;
     const int L = kMsg ? 8 + CW * CELLS : L0;
     // words of the observation bit string per agent (the image string holds n_layers * CELLS bits per agent)
-    const int OW = kImage ? max(OW0, (p.n_layers * CELLS + 31) / 32) : kMsg ? (L + 31) / 32 : OW0;
+    const int OW = kImage ? max(OW0, ((Cfg::kNL > 0 ? Cfg::kNL : p.n_layers) * CELLS + 31) / 32) : kMsg ? (L + 31) / 32 : OW0;  // (LDS carve-up: needed first)
     extern __shared__ __align__(16) int32_t smem[];
 
     int tid = threadIdx.x;
@@ -312,7 +357,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int nea = ne * N;
     // agent phases with cross-lane exchange in registers (see AG); kDirect: own record fetched straight into registers
     constexpr bool kRegAG = Cfg::kN >= 1 && Cfg::kN <= 6;  // (N + 2 link codes must fit 3 bits)
-    constexpr bool kDirect = kRegAG && Cfg::kE != 0 && !kMsg;
+    constexpr bool kDirect = kRegAG && Cfg::kE != 0 && (!kMsg || (Cfg::kM >= 1 && Cfg::kM <= 4));  // (message words: one register each)
     // ONE scalar batch, first thing in the kernel, for every field of the parameter block that the stage-in and the agent
     // phases read: left to itself hipcc fetches each field where it is first used — three dependent scalar-cache round
     // trips in the prologue (every launch starts with cold caches) and more inside the agent phases, which run on one
@@ -323,14 +368,42 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const uint32_t *const q_hw = p.highway_bits;
     const uint8_t *const q_need = p.need_reset;
     const int k_reward_type = p.reward_type, k_max_inactivity = p.max_inactivity, k_max_steps = p.max_steps;
-    const int k_autoreset = p.autoreset, k_n_goals = p.n_goals;
+    const int k_autoreset = p.autoreset, k_n_goals = p.n_goals, k_normalised = p.normalised;
     const int k_goal0 = p.goal_cells[0], k_goal1 = p.goal_cells[1];
-    keep_sgpr_ptr(g_shadow, q_ax, q_ay, q_dir, q_carry, q_deliv, q_queue, q_steps, q_inact, q_hw, q_need);
-    keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1);
+    // (exact-shape builds whose LDS carve-up is a compile-time constant clear their scratch regions while this batch is in
+    //  flight and pin it afterwards — kClearFirst, below; the others pin it here)
+    constexpr bool kClearFirst = Cfg::kN != 0 && Cfg::kE != 0 && (!kImage || Cfg::kNL > 0) && (!kMsg || Cfg::kM != 0);
+    if constexpr (!kClearFirst) {
+        keep_sgpr_ptr(g_shadow, q_ax, q_ay, q_dir, q_carry, q_deliv, q_queue, q_steps, q_inact, q_hw, q_need);
+        keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
+    }
+    // IMAGE kernels: the layer list and its switches belong to the same batch — the image gather used to fetch them where
+    // it uses them (one scalar-cache round trip per layer, per goal cell and per switch, inside the phase that stands between
+    // the agent phases and the first observation store: 2.5 us against 0.7 us for the FLATTENED gather, r02_timeline_image)
+    int k_n_layers = 0, k_directional = 0, k_transposed = 0;
+    int k_layer[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float *q_features = nullptr;
+    if constexpr (kImage) {
+        q_features = p.features;
+        keep_sgpr_ptr(q_features);
+        if constexpr (Cfg::kNL > 0) {  // the layer list is part of the build: every select on a layer id folds
+            k_n_layers = Cfg::kNL;
+            k_directional = Cfg::kDirectional;
+            k_transposed = packed_transposed_layers(Cfg::kLayers, Cfg::kNL);
+#pragma unroll
+            for (int l = 0; l < 8; ++l) k_layer[l] = (int)((Cfg::kLayers >> (4 * l)) & 15u);
+        } else {
+            k_n_layers = p.n_layers; k_directional = p.directional; k_transposed = p.transposed_layers;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) k_layer[l] = p.layers[l];
+            keep_sgpr(k_n_layers, k_directional, k_transposed);
+            keep_sgpr(k_layer[0], k_layer[1], k_layer[2], k_layer[3], k_layer[4], k_layer[5], k_layer[6], k_layer[7]);
+        }
+    }
     // wavefront 3 = service wave after the agent phases (see WB); pays off while the observation of a workgroup is
     // small enough that three wavefronts expand it as fast as the stores drain (measured: small-4ag 8.91 -> 8.79 us,
     // fused 4.93 -> 4.56; medium-6ag-hard 8.56 -> 8.40; large-16ag r=2 with 23 K floats per workgroup 43.6 -> 46.1, so not there)
-    const bool split = nw == 4 && nea * (kImage ? p.n_layers * CELLS : L) <= 8192;
+    const bool split = nw == 4 && nea * (kImage ? k_n_layers * CELLS : L) <= 8192;
     const int TW = split ? T - 64 : T;        // threads that gather window rows and expand the observation
     const uint32_t mN = Cfg::kN ? rw_magic18(Cfg::kN) : p.magic_n;
     // optional per-workgroup phase stamps (100 MHz wall clock); one scalar branch per mark when off
@@ -344,7 +417,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
 #endif
     RW_MARK(TL_START);
 
-    const LdsLayout lo = make_lds_layout(E, N, Q, HW, SW, OW, (int)sizeof(CellT), AM);
+    constexpr bool kPos = Cfg::kPos;  // shelf layer staged from / written back to the position array (see StaticCfg)
+    static_assert(!kPos || (kRegAG && Cfg::kE != 0 && sizeof(CellT) == 1 && Cfg::kH * Cfg::kW <= 256 && (Cfg::kE * Cfg::kS) % 16 == 0),
+                  "the position layout: exact-shape register builds, cell index in a byte, chunk 16-byte granular");
+    const LdsLayout lo = make_lds_layout(E, N, Q, HW, SW, OW, (int)sizeof(CellT), AM, kPos ? S : 0);
+    uint8_t *const s_pos = reinterpret_cast<uint8_t *>(smem + (kPos ? lo.pos : lo.gs));  // (kPos only)
+    uint8_t *const g_pos = p.shelf_pos;
     CellT *s_gs = reinterpret_cast<CellT *>(smem + lo.gs);
     uint8_t *s_ga = reinterpret_cast<uint8_t *>(smem + lo.ga);
     int32_t *s_ax = smem + lo.ax, *s_ay = smem + lo.ay, *s_dir = smem + lo.dir;
@@ -362,7 +440,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     int32_t *s_misc = smem + lo.misc;
     auto on_highway = [&](int c) -> bool { return (s_hw[c >> 5] >> (c & 31)) & 1u; };
     auto coordf = [&](int k, int v) -> float {
-        if (p.normalised) return (float)((double)v / (double)((k == 0 ? W : H) - 1));  // :636-638
+        if (k_normalised) return (float)((double)v / (double)((k == 0 ? W : H) - 1));  // :636-638
         return (float)v;
     };
 
@@ -380,8 +458,16 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // first thing in the kernel: the loads fly beside the clear and the stage-in DMA, are complete at the barrier that
     // drains the DMA, and the agent phases start without an LDS read.  The LDS copies the later phases read (window
     // gather, write-back) are written by the agent lanes together with their results.
+    if constexpr (kClearFirst) {  // the LDS clear needs no parameter: it runs under the scalar batch's (cold) round trip
+        clear_scratch();
+        keep_sgpr_ptr(g_shadow, q_ax, q_ay, q_dir, q_carry, q_deliv, q_queue, q_steps, q_inact, q_hw, q_need);
+        keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
+    }
     const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : q_need;  // OP_RESET: all-ones when no mask was given
     int r_x = 0, r_y = 0, r_d = 0, r_carry = 0, r_deliv = 0, r_act = ACT_NOOP, r_flag = 0, r_steps = 0, r_inact = 0;
+    constexpr int KMW = (kMsg && Cfg::kM) ? Cfg::kM : 1;
+    int r_mw[KMW] = {};   // the action's message words (_MSG builds), r_msg: the agent's stored message
+    int r_msg = 0;
     if constexpr (kDirect) {
         constexpr int KN = Cfg::kN, KG = 64 / KN;
         static_assert(Cfg::kE <= (Cfg::kT / 64) * KG, "every env of the chunk needs its own agent lanes");
@@ -390,7 +476,13 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             const int ge = e0 + le;
             const size_t gi = (size_t)ge * KN + a_idx;
             r_x = q_ax[gi]; r_y = q_ay[gi]; r_d = q_dir[gi]; r_carry = q_carry[gi]; r_deliv = q_deliv[gi];
-            if (op == OP_STEP) r_act = la.actions[gi];
+            if (op == OP_STEP) r_act = la.actions[gi * AM];
+            if constexpr (kMsg) {
+                r_msg = p.amsg[gi];
+                if (op == OP_STEP)
+#pragma unroll
+                    for (int k = 0; k < KMW; ++k) r_mw[k] = la.actions[gi * AM + 1 + k];
+            }
             r_flag = (op == OP_OBS) ? 0 : (int)flag_src[ge];
             r_steps = q_steps[ge];
             r_inact = q_inact[ge];
@@ -425,7 +517,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // intent and occupant in that window, before the barrier that everything else of the agent phases has to wait for.
     constexpr bool kEarly = kDirect && !kRollout && Cfg::kT >= 128;
     Intent early{ACT_NOOP, 0, 0, 0, 0, -1};
-    clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
+    if constexpr (!kClearFirst) clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
     RW_MARK(TL_ZEROED);
     if constexpr (Cfg::kE != 0) {
         // Static build: every DMA destination is contiguous in LDS and every source chunk is a whole
@@ -433,9 +525,9 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // its HBM source is picked from the segment table (all pointers fetched in one scalar batch).
         static_assert((Cfg::kE * Cfg::kN) % 4 == 0 && (Cfg::kE * Cfg::kQ) % 4 == 0 && Cfg::kE % 4 == 0, "chunk not 16-byte granular");
         static_assert(!kMsg || Cfg::kN == 0 || Cfg::kM != 0, "an exact-shape _MSG build needs its communication bits at compile time");
-        static_assert((Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0, "shelf chunk not 16-byte granular");
+        static_assert(kPos || (Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0, "shelf chunk not 16-byte granular");
         const char *src[12] = {
-            reinterpret_cast<const char *>(g_shadow + (size_t)e0 * HW),
+            kPos ? reinterpret_cast<const char *>(g_pos + (size_t)e0 * S) : reinterpret_cast<const char *>(g_shadow + (size_t)e0 * HW),
             reinterpret_cast<const char *>(q_ax + (size_t)e0 * N), reinterpret_cast<const char *>(q_ay + (size_t)e0 * N),
             reinterpret_cast<const char *>(q_dir + (size_t)e0 * N), reinterpret_cast<const char *>(q_carry + (size_t)e0 * N),
             reinterpret_cast<const char *>(q_deliv + (size_t)e0 * N),
@@ -443,7 +535,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             reinterpret_cast<const char *>(q_queue + (size_t)e0 * Q), reinterpret_cast<const char *>(q_hw),
             reinterpret_cast<const char *>(q_steps + e0), reinterpret_cast<const char *>(q_inact + e0),
             reinterpret_cast<const char *>(flag_src + e0)};
-        const int seg[13] = {lo.gs, lo.ax, lo.ay, lo.dir, lo.carry, lo.deliv, lo.act, lo.queue, lo.hw,
+        const int seg[13] = {kPos ? lo.pos : lo.gs, lo.ax, lo.ay, lo.dir, lo.carry, lo.deliv, lo.act, lo.queue, lo.hw,
                              lo.dsteps, lo.dinact, lo.dflag, lo.dma_end};  // dword offsets, all multiples of 4
         if constexpr (Cfg::kN != 0) {
             // One DMA instruction moves up to 64 pieces of ONE segment (LDS base + lane * 16), so the source
@@ -459,7 +551,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     if (job % dma_w == wave_s && c + lane < pieces)
                         lds_dma_b128(src[k] + (size_t)(c + lane) * 16, smem + seg[k] + 4 * c);
             }
-            if constexpr (kMsg) {  // the agents' stored messages: a 13th array, outside the contiguous block
+            if constexpr (kMsg && !kDirect) {  // the agents' stored messages: a 13th array, outside the contiguous block
                 const int pieces = (Cfg::kE * Cfg::kN) >> 2;
                 for (int c = 0; c < pieces; c += 64, ++job)
                     if (job % dma_w == wave_s && c + lane < pieces)
@@ -505,6 +597,13 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             }
             lds_barrier();
         }
+        if constexpr (kPos) {  // the shelf layer of the chunk from its positions: one byte store per shelf into the cleared block
+            for (int k = tid; k < Cfg::kE * Cfg::kS; k += T) {
+                const int e = k / Cfg::kS;
+                s_gs[e * HW + s_pos[k]] = (CellT)(k - e * Cfg::kS + 1);
+            }
+            lds_barrier();
+        }
     } else {
         dma_in(smem + lo.gs, reinterpret_cast<const int32_t *>(g_shadow + (size_t)e0 * HW),
                (ne * HW * (int)sizeof(CellT) + 3) >> 2, tid, T);
@@ -532,7 +631,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         RW_MARK(TL_ENV_LOADED);
         __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
     }
-    keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1);
+    keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
     RW_MARK(TL_LOADED);
 
     // kRollout == false is the single-step kernel (rw_step / rw_reset / rw_refresh_obs): no loop at all.
@@ -559,6 +658,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         lds_barrier();  // the previous step's expansion has finished reading the bit string
         clear_scratch();
         lds_barrier();
+        if constexpr (kPos) {  // (the shelf layer lies in the cleared block: put it back from the positions, which are current)
+            for (int k = tid; k < Cfg::kE * Cfg::kS; k += T) {
+                const int e = k / Cfg::kS;
+                s_gs[e * HW + s_pos[k]] = (CellT)(k - e * Cfg::kS + 1);
+            }
+        }
         for (int e = tid; e < ne; e += T) {
             int32_t *ev = s_envi + e * ENVI_W;
             const int rs = (k_autoreset == AR_NEXT_STEP) ? ev[ENVI_DONE] : 0;
@@ -605,16 +710,30 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         int a = ACT_NOOP;
         if (!kEarly && mine) {
             if (stepping) a = (t == 0) ? a_lds : (act_prefetch ? a_pref : act_t[((size_t)ge * KN + a_idx) * AM]);
-            if (kMsg && stepping) {  // agent.message[:] = action[1:] — for every agent, whatever its move does (:812)
-                int msg = 0;
-                for (int k = 0; k < M; ++k) {
-                    const int v = (t == 0) ? s_act[i * AM + 1 + k] : act_t[((size_t)ge * KN + a_idx) * AM + 1 + k];
-                    if ((unsigned)v > 1u) atomicOr(p.status, STATUS_INVALID_ACTION);  // MultiDiscrete([5, 2, 2, ...])
-                    msg |= (v & 1) << k;
-                }
-                s_msg[i] = msg;
-            }
             if (act_prefetch && t + 1 < n_steps) a_pref = (act_t + la.act_stride)[(size_t)ge * KN + a_idx];
+        }
+        if constexpr (kMsg && kDirect) {  // agent.message[:] = action[1:] — for every agent, whatever its move does (:812)
+            if (mine) {
+                int msg = r_msg;  // an env that does not step keeps its stored messages (first step of the launch: registers)
+                if (stepping) {
+                    msg = 0;
+#pragma unroll
+                    for (int k = 0; k < KMW; ++k) {
+                        const int v = (t == 0) ? r_mw[k] : act_t[((size_t)ge * KN + a_idx) * AM + 1 + k];
+                        if (RW_RARE((unsigned)v > 1u)) atomicOr(p.status, STATUS_INVALID_ACTION);  // MultiDiscrete([5, 2, 2, ...])
+                        msg |= (v & 1) << k;
+                    }
+                }
+                if (stepping || t == 0) s_msg[i] = msg;
+            }
+        } else if (kMsg && mine && stepping) {
+            int msg = 0;
+            for (int k = 0; k < M; ++k) {
+                const int v = (t == 0) ? s_act[i * AM + 1 + k] : act_t[((size_t)ge * KN + a_idx) * AM + 1 + k];
+                if ((unsigned)v > 1u) atomicOr(p.status, STATUS_INVALID_ACTION);  // MultiDiscrete([5, 2, 2, ...])
+                msg |= (v & 1) << k;
+            }
+            s_msg[i] = msg;
         }
         // ------------------------------------------------------------ P1: intent (:825-846), branch-free
         Intent in = kEarly ? early : intent_of(stepping, a, x, y, d);
@@ -730,6 +849,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         if (mcar) gS[st] = 0;  // incremental _recalc_grid (:749-755): clear phase ...
         wave_lds_order();
         if (mcar) gS[tg] = (CellT)carry;  // ... then set phase, for the whole wavefront in this order
+        if (kPos && mcar) s_pos[e * S + carry - 1] = (uint8_t)tg;  // position layout: where that shelf stands now
         // the agent layer was zeroed at the start of the step: final position only (id | 0x80 if loaded)
         if (mine && !ev_reset) gA[moved ? tg : st] = (uint8_t)((a_idx + 1) | (carry ? 0x80 : 0));
         // ------------------------------------------------------------ P5: goals, rewards, termination (:903-942)
@@ -1030,6 +1150,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;
             s_ga[c] = 0;
             s_gs[c] = (CellT)p.shelf_init[c - e * HW];
+            if (kPos && s_gs[c]) s_pos[e * S + (int)s_gs[c] - 1] = (uint8_t)(c - e * HW);
         }
         __syncthreads();
         for (int e = tid; e < ne; e += T) {
@@ -1067,7 +1188,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         for (int c = tid; c < ne * HW; c += T) {
             const int e = c / HW;
             if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;
-            g_shadow[(size_t)(e0 + e) * HW + (c - e * HW)] = s_gs[c];
+            if (!kPos) g_shadow[(size_t)(e0 + e) * HW + (c - e * HW)] = s_gs[c];  // (positions: written by the write-back below)
         }
         for (int i = tid; i < nea; i += T) {
             const int e = rw_div18(i, mN);
@@ -1155,6 +1276,16 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             //  coordinates when somebody asks for it — rw_refresh_grid.  Its scattered 4-byte patches were partial-line
             //  writes; once a batch outgrows the Infinity Cache each of them is a read-modify-write in HBM: 15 % of the
             //  step at B = 262144, measured by ablation.)
+            if constexpr (kPos) {
+                // position layout: the chunk's positions go back as ONE coalesced stream of whole 16-byte pieces (the LDS copy
+                // is current: the agent phases and the reset path update it) — no scattered 1-byte patches, which are
+                // read-modify-writes in HBM once a batch has outgrown the Infinity Cache
+                if (op != OP_OBS) {
+                    const int4 *src = reinterpret_cast<const int4 *>(smem + lo.pos);
+                    int4 *dst = reinterpret_cast<int4 *>(g_pos + (size_t)e0 * S);
+                    for (int k = lane; k < (Cfg::kE * Cfg::kS) >> 4; k += 64) dst[k] = src[k];
+                }
+            } else
             if (op == OP_STEP)
                 for (int i = lane; i < nea; i += 64) {
                     const int mv = s_mv[i], carry = s_carry[i];
@@ -1191,19 +1322,19 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 if (sh > 26) atomicOr(&s_obits[wd + 1], self >> (32 - sh));
             }
         } else {
-            if (p.features)  // IMAGE_DICT feature vector: one-hot direction, on_highway, carrying (:730-738)
+            if (q_features)  // IMAGE_DICT feature vector: one-hot direction, on_highway, carrying (:730-738)
                 for (int i = lane; i < nea; i += 64) {
                     if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
-                    float *f = p.features + ((size_t)e0 * N + i) * 6;
+                    float *f = q_features + ((size_t)e0 * N + i) * 6;
                     const int d = s_dir[i];
                     f[0] = d == 0 ? 1.0f : 0.0f; f[1] = d == 1 ? 1.0f : 0.0f; f[2] = d == 2 ? 1.0f : 0.0f; f[3] = d == 3 ? 1.0f : 0.0f;
                     f[4] = on_highway(s_ay[i] * W + s_ax[i]) ? 1.0f : 0.0f;
                     f[5] = s_carry[i] ? 1.0f : 0.0f;
                 }
-            if (p.transposed_layers)  // layer[ag.x, ag.y] on an (H, W) array (:552, :558): IndexError when out of bounds
+            if (k_transposed)  // layer[ag.x, ag.y] on an (H, W) array (:552, :558): IndexError when out of bounds
                 for (int i = lane; i < nea; i += 64) {  // (envs reset in this launch included: nobody is loaded there)
                     const bool loaded = s_carry[i] && !s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET];
-                    const bool counted = (p.transposed_layers & 1) || loaded;
+                    const bool counted = (k_transposed & 1) || loaded;
                     if (counted && (s_ax[i] >= H || s_ay[i] >= W)) atomicOr(p.status, STATUS_IMAGE_INDEX);
                 }
         }
@@ -1300,12 +1431,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // thread per (agent, layer, image row).
         // thread per (agent, image row): the row's WIN cells are read once and give one WIN-bit mask per
         // property; every requested layer is then one of those masks.
-        const int Limg = p.n_layers * CELLS;
+        const int Limg = k_n_layers * CELLS;
         if (worker)
         for (int w = tid; w < nea * WIN; w += TW) {
             const int i = w / WIN, r = w - i * WIN;
             const int e = rw_div18(i, mN);
-            const int ax = s_ax[i], ay = s_ay[i], d = p.directional ? s_dir[i] : DIR_UP;
+            const int ax = s_ax[i], ay = s_ay[i], d = k_directional ? s_dir[i] : DIR_UP;
             uint32_t m_shelf = 0, m_req = 0, m_agent = 0, m_goal = 0, m_map = 0;
             uint32_t m_tagent = 0, m_tload = 0;  // the transposed layers: an agent / a loaded agent with (x, y) == (row, col)
             // LDS reads in unconditional batches (an off-map cell reads the agent's own cell and is masked): a
@@ -1326,7 +1457,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 gav[cc] = s_ga[c];
                 gsv[cc] = (int)s_gs[c];
                 gtv[cc] = 0;
-                if (p.transposed_layers) {  // layer[ag.x, ag.y]: the agent standing at (x', y') = (y, x)
+                if (k_transposed) {  // layer[ag.x, ag.y]: the agent standing at (x', y') = (y, x)
                     const bool tok = okv[cc] && x < H && y < W;
                     gtv[cc] = tok ? (int)s_ga[tok ? e * HW + x * W + y : own] : 0;
                 }
@@ -1339,13 +1470,16 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 m_agent |= (ida ? 1u : 0u) << cc;
                 m_shelf |= (ids ? 1u : 0u) << cc;
                 m_req |= (ids ? ((rq >> (ids & 31)) & 1u) : 0u) << cc;
-                for (int g = 0; g < p.n_goals; ++g)
+                m_goal |= ((okv[cc] && ((k_n_goals > 0 && k_goal0 == cellv[cc]) || (k_n_goals > 1 && k_goal1 == cellv[cc]))) ? 1u : 0u) << cc;
+                for (int g = 2; g < k_n_goals; ++g)  // (more than two goal cells: custom layouts)
                     if (okv[cc] && p.goal_cells[g] == cellv[cc]) m_goal |= 1u << cc;
                 m_tagent |= ((gtv[cc] & 0x7f) ? 1u : 0u) << cc;
                 m_tload |= ((gtv[cc] & 0x80) ? 1u : 0u) << cc;
             }
-            for (int l = 0; l < p.n_layers; ++l) {
-                const int layer = p.layers[l];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {  // (unrolled over the register copy of the layer list)
+                if (l >= k_n_layers) break;
+                const int layer = k_layer[l];
                 // (AGENT_DIRECTION holds dir + 1 in 1..4: its bit marks the cell, the value is patched in after the
                 //  expansion, see below)
                 const uint32_t bits = layer == LAYER_SHELVES ? m_shelf : layer == LAYER_REQUESTS ? m_req
@@ -1399,7 +1533,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // headline batch, -7 % at the cache-exceeding batches).
         // (not in the fused rollout: its steps are bound by instruction issue, not by the store stream, and the single pass
         //  costs ~10 more VALU operations per float4: 4.16 -> 4.78 us per step there)
-        const bool xy_bytes = !kRollout && !p.normalised;  // workgroup-uniform
+        const bool xy_bytes = !kRollout && !k_normalised;  // workgroup-uniform
         if (worker && xy_bytes) {
             const int shift = (tid & 7) << 2, words_per_pass = TW >> 3;  // (TW % 8 == 0)
             const uint32_t *wp = s_obits + (tid >> 3);
@@ -1489,7 +1623,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         }
     }
     else {  // IMAGE: every element is a bit of the string; no coordinate slots
-        const int Limg = p.n_layers * CELLS;
+        const int Limg = k_n_layers * CELLS;
         const int nf = nea * Limg, nf4 = nf >> 2;
         float *out = obs_t + (size_t)e0 * N * Limg;  // 16-byte aligned: e0 is a multiple of 4
         if (worker) {
@@ -1510,7 +1644,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         }
         if (worker)
         for (int g = (nf4 << 2) + tid; g < nf; g += TW) out[g] = ((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f;
-        if (p.transposed_layers & 1) {
+        if (k_transposed & 1) {
             // AGENT_DIRECTION (:547-552): the marked cells hold dir + 1, not 1.  Patched after every 0/1 store of
             // the workgroup has completed (full barrier: vmcnt), one thread per (agent, image row) as in P7.
             __syncthreads();
@@ -1518,7 +1652,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             for (int w = tid; w < nea * WIN; w += TW) {
                 const int i = w / WIN, r = w - i * WIN;
                 const int e = rw_div18(i, mN);
-                const int ax = s_ax[i], ay = s_ay[i], d = p.directional ? s_dir[i] : DIR_UP;
+                const int ax = s_ax[i], ay = s_ay[i], d = k_directional ? s_dir[i] : DIR_UP;
                 for (int cc = 0; cc < WIN; ++cc) {
                     int wr = r, wc = cc;
                     if (d == DIR_DOWN) { wr = WIN - 1 - r; wc = WIN - 1 - cc; }
@@ -1529,8 +1663,9 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     const int ida = s_ga[e * HW + x * W + y] & 0x7f;
                     if (!ida) continue;
                     const float v = (float)(s_dir[e * N + ida - 1] + 1);
-                    for (int l = 0; l < p.n_layers; ++l)
-                        if (p.layers[l] == LAYER_AGENT_DIRECTION) out[(size_t)i * Limg + (l * WIN + r) * WIN + cc] = v;
+#pragma unroll
+                    for (int l = 0; l < 8; ++l)
+                        if (l < k_n_layers && k_layer[l] == LAYER_AGENT_DIRECTION) out[(size_t)i * Limg + (l * WIN + r) * WIN + cc] = v;
                 }
             }
         }
