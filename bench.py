@@ -83,6 +83,111 @@ def spawn_ranks(n: int):
     return children
 
 
+HBM_REGIME_BATCH, HBM_REGIME_STEPS, HBM_REGIME_WARMUP, HBM_REGIME_TAPE = 262144, 300, 30, 8
+API_LOOP_STEPS, API_LOOP_WARMUP = 2000, 200
+
+
+def pmc_traffic(env_id, B, sha, sensor_range=0, observation_type=1, msg_bits=0):
+    """Physical bytes per launch from the rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by profiles/tools/sweep.sh
+    and tied to the kernel sources by hash).  Returns (bytes or None, note or None)."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(pmc):
+        return None, "profiles/pmc_traffic.json not found"
+    try:
+        rec = json.load(open(pmc))
+        key = f"{env_id}:{B}" + (f":r{sensor_range}" if sensor_range else "") \
+              + (f":obs{observation_type}" if observation_type != 1 else "") + (f":m{msg_bits}" if msg_bits else "")
+        ent = rec.get("entries", {}).get(key)
+        if ent is None:
+            return None, f"no PMC traffic recorded for {key}"
+        if rec.get("kernel_sources_sha") != sha:
+            return None, (f"stale: profiles/pmc_traffic.json was measured at kernel sources {rec.get('kernel_sources_sha')}, "
+                          f"this build is {sha}; re-run profiles/tools/sweep.sh")
+        return int(ent["bytes_per_launch"]), None
+    except Exception as exc:  # noqa: BLE001
+        return None, f"unreadable pmc_traffic.json: {exc}"
+
+
+def hbm_regime_leg(torch, rware_amd, local_rank, env_id, sha):
+    """The same kernel at a batch whose per-step traffic no longer fits the 256 MiB Infinity Cache ("also run
+    a cache-exceeding batch for the roofline claim"): small-4ag x 262144 envs = 298 MB of observations per step.  HIP events on
+    the first / last launch of the timed region, like the headline leg."""
+    B, K, W, TS = HBM_REGIME_BATCH, HBM_REGIME_STEPS, HBM_REGIME_WARMUP, HBM_REGIME_TAPE
+    kw = rware_amd.env_kwargs(env_id)
+    N = kw["n_agents"]
+    env = rware_amd.WarehouseVecEnv(B, devices=[local_rank], **kw)
+    try:
+        eng = env.engines[0]
+        eng.reset(seeds=rware_amd.shard_seeds(0, B))
+        acts = np.random.default_rng(777).integers(0, 5, size=(TS, B, N), dtype=np.int32)
+        tape = torch.from_numpy(acts).to(f"cuda:{local_rank}")
+        torch.cuda.synchronize()
+        eng.step_tape_device_timed(tape.data_ptr(), TS, 0, W, 0, 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.step_tape_device_timed(tape.data_ptr(), TS, W % TS, K, 0, 1)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        k_ms = eng.event_elapsed_ms(0, 1) / K
+        eng.sync()
+        info = eng.info
+        a_bytes = int(info.algorithmic_bytes_per_env_step) * B
+        traffic, note = pmc_traffic(env_id, B, sha)
+        out = {
+            "workload": f"{env_id} batch={B} envs on one GPU (observations {B * N * int(info.obs_length) * 4 / 1e6:.0f} MB per step: "
+                        "past the 256 MiB Infinity Cache), same per-step launches as `value`",
+            "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3, "kernel_ms_per_launch": k_ms,
+            "value": B * N * K / wall, "unit": "agent-steps/s",
+            "algorithmic_bytes_per_launch": a_bytes, "achieved": a_bytes / (k_ms * 1e-3) / 1e9, "frac": a_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "achieved_physical": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+            "frac_physical": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+            "frac_physical_of_measured_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_MEASURED_GBPS) if traffic else None,
+            "peak": HBM_PEAK_GBPS, "peak_measured": HBM_MEASURED_GBPS, "unit_bw": "GB/s",
+            "state_layout": "position" if int(getattr(info, "state_layout", 0)) else "shadow",
+            "envs_per_workgroup": int(info.envs_per_workgroup), "kernel_specialised": bool(info.specialised),
+        }
+        if note:
+            out["traffic_note"] = note
+        return out
+    finally:
+        env.close()
+
+
+def api_closed_loop_leg(torch, rware_amd, local_rank, env_id, B):
+    """End-to-end API throughput: what a training loop gets from `WarehouseVecEnv(output="torch").step(
+    cuda_actions)` — Python -> ctypes -> launch per step on torch's current stream, results as zero-copy torch views, NO sync
+    inside the loop (the policy's next op is ordered behind the step by the stream), one sync at the end."""
+    kw = rware_amd.env_kwargs(env_id)
+    N = kw["n_agents"]
+    dev = f"cuda:{local_rank}"
+    env = rware_amd.WarehouseVecEnv(B, devices=[local_rank], output="torch", **kw)
+    try:
+        env.reset(seed=0)
+        acts = torch.from_numpy(np.random.default_rng(4242).integers(0, 5, size=(64, B, N), dtype=np.int32)).to(dev)
+        slices = [acts[t] for t in range(64)]  # what a policy hands over each step: one (B, N) int32 CUDA tensor
+        for t in range(API_LOOP_WARMUP):
+            env.step(slices[t % 64])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(API_LOOP_STEPS):
+            obs, rew, term, trunc, _ = env.step(slices[t % 64])
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        env.sync()
+        assert obs.is_cuda and term.dtype == torch.bool
+        return {
+            "what": "WarehouseVecEnv(output='torch').step(cuda int32 actions) from Python, one call per step, no sync inside the "
+                    "loop, one device sync at the end",
+            "steps": API_LOOP_STEPS, "warmup": API_LOOP_WARMUP, "us_per_step": wall / API_LOOP_STEPS * 1e6,
+            "host_issue_us_per_step": t_issue / API_LOOP_STEPS * 1e6,
+            "value": B * N * API_LOOP_STEPS / wall, "unit": "agent-steps/s", "envs": B,
+        }
+    finally:
+        env.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +211,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-rollout measurement (profiling runs)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the fixed 2000-step sustained leg (profiling runs)")
+    ap.add_argument("--no-hbm-regime", action="store_true", help="skip the cache-exceeding leg (small-4ag x 262144 envs)")
+    ap.add_argument("--no-api-loop", action="store_true", help="skip the Python closed-loop API leg")
     args = ap.parse_args()
 
     children = []
@@ -261,23 +368,7 @@ def main():
         k_ms = kernel_ms  # HIP-event time per step (== per launch unless --many fuses several steps into one launch)
         achieved = per_launch / (k_ms * 1e-3) / 1e9
         sha = kernel_sources_sha()
-        traffic, traffic_note = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from the rocprofv3 --pmc passes (profiles/tools/sweep.sh)
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                key = f"{args.env_id}:{B}" + (f":r{args.sensor_range}" if args.sensor_range else "") \
-                      + (f":obs{args.observation_type}" if args.observation_type != 1 else "") + (f":m{args.msg_bits}" if args.msg_bits else "")
-                ent = rec.get("entries", {}).get(key)
-                if ent is None:
-                    traffic_note = f"no PMC traffic recorded for {key}"
-                elif rec.get("kernel_sources_sha") != sha:
-                    traffic_note = (f"stale: profiles/pmc_traffic.json was measured at kernel sources {rec.get('kernel_sources_sha')}, "
-                                    f"this build is {sha}; re-run profiles/tools/sweep.sh")
-                else:
-                    traffic = int(ent["bytes_per_launch"])
-            except Exception as exc:  # noqa: BLE001
-                traffic_note = f"unreadable pmc_traffic.json: {exc}"
+        traffic, traffic_note = pmc_traffic(args.env_id, B, sha, args.sensor_range, args.observation_type, args.msg_bits)
         out = {
             "metric": "agent-steps/sec (agents*envs*steps/s)",
             "value": world * B * N * args.steps / elapsed,
@@ -333,6 +424,14 @@ def main():
                 "submit": "rw_step_many_device x64: one launch per 64 steps, env chunk resident in LDS across steps "
                           "(open-loop rollout from the same device action tape; identical results)",
             }
+        extra = world == 1 and args.env_id == ENV_ID and args.many == 0 and args.observation_type == 1 and not args.msg_bits and not args.sensor_range
+        if extra and not (args.no_hbm_regime and args.no_api_loop):
+            env.close()  # one engine at a time on the device
+            if not args.no_api_loop:
+                out["api_closed_loop"] = api_closed_loop_leg(torch, rware_amd, local_rank, args.env_id, B)
+                out["api_closed_loop"]["vs_native_loop"] = out["api_closed_loop"]["us_per_step"] / (out["ms_per_step"] * 1e3)
+            if not args.no_hbm_regime:
+                out["hbm_regime"] = hbm_regime_leg(torch, rware_amd, local_rank, args.env_id, sha)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.env_id)
         print(json.dumps(out), flush=True)

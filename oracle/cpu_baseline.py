@@ -5,8 +5,9 @@ actions, step + FLATTENED observation, reset when an episode ends):
 
   reference  the UNMODIFIED `rware.warehouse.Warehouse.step` (`/root/reference/rware/warehouse.py:804-946`), one
              env per process, 1 process and P processes (multiprocessing, one per host core) — what
-             BASELINE.json's `north_star` and SURVEY.md §8(d) name as the baseline.  Only where the reference
-             tree exists (the build container); the GPU box does not have it.
+             BASELINE.json's `north_star` and SURVEY.md §8(d) name as the baseline.  Imported from /root/reference
+             in the build container, and from the byte-for-byte staged copy under the git-ignored oracle/_ref/
+             (oracle/make_ref.sh, run by __graft_entry__.build()) on the GPU box, which has no reference tree.
   port       `oracle/rware_oracle.c` (the C restatement of the same step), 1 process and P processes, each
              single-threaded with its own batch of envs.
 
@@ -157,7 +158,10 @@ def measure(env_id: str, port_seconds: float = 5.0, ref_seconds: float = 6.0) ->
     if reference_available():
         ref_1, standin = time_reference(env_id, ref_seconds, 1)
         ref_p, _ = time_reference(env_id, ref_seconds, P) if P > 1 else (ref_1, standin)
-        out.update(kind="reference", value=ref_p, single=ref_1, aggregate=ref_p,
+        import ref_runner as rr
+
+        out.update(kind="reference", value=ref_p, single=ref_1, aggregate=ref_p, processes=P,
+                   reference_root=("oracle/_ref (staged by oracle/make_ref.sh)" if rr.REFERENCE_ROOT == rr.STAGED_ROOT else rr.REFERENCE_ROOT),
                    sample=f"{env_id}: unmodified rware.warehouse.Warehouse.step (pure Python + networkx), one env per process, "
                           f"uniform random actions, reset on done, ~{ref_seconds:.0f} s with 1 process and ~{ref_seconds:.0f} s with "
                           f"{P} processes on {P} cores of '{model}'"

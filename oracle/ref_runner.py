@@ -1,8 +1,9 @@
 """TEST INFRASTRUCTURE — drives the UNMODIFIED reference (`/root/reference/rware`) in the
 build container to (a) pin the CPU oracle and (b) generate `tests/golden/*.npz`.
 
-Nothing here runs on the GPU box (`/root/reference` does not exist there) and the
-product package never imports this module.
+On the GPU box `/root/reference` does not exist; the only thing that runs there is `bench.py`'s
+`cpu_baseline` leg timing the staged, unmodified copy under the git-ignored `oracle/_ref/`
+(`oracle/make_ref.sh`).  The product package never imports this module.
 
 Pinned tie-break.  The reference resolves a tree-shaped collision component with
 `nx.algorithms.dag_longest_path(comp)` (`rware/warehouse.py:865`).  When two
@@ -26,8 +27,21 @@ from collections import deque
 
 import numpy as np
 
-REFERENCE_ROOT = os.environ.get("RWARE_REFERENCE_ROOT", "/root/reference")
-_STANDIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gymnasium_standin")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_STANDIN = os.path.join(_HERE, "gymnasium_standin")
+STAGED_ROOT = os.path.join(_HERE, "_ref")  # oracle/make_ref.sh: byte-for-byte copy of rware/{__init__,warehouse}.py (git-ignored)
+
+
+def _find_reference_root() -> str:
+    """/root/reference (build container) first; else the staged copy under oracle/_ref (what the GPU box gets)."""
+    cands = [os.environ.get("RWARE_REFERENCE_ROOT"), "/root/reference", STAGED_ROOT]
+    for c in cands:
+        if c and os.path.isfile(os.path.join(c, "rware", "warehouse.py")):
+            return c
+    return cands[0] or "/root/reference"
+
+
+REFERENCE_ROOT = _find_reference_root()
 
 _rware = None
 _CURRENT_ENV = None

@@ -163,6 +163,7 @@ class Engine:
                  image_layers=(), image_directional=True, msg_bits=0, use_given_stream=False):
         self.lib = load(library)
         self._h = C.c_void_p()
+        self._arena, self.arena_allocations = {}, 0  # rollout_host's device tapes (grow-only; freed in close())
         hw = np.ascontiguousarray(layout.highways, dtype=np.uint8)
         goals = np.ascontiguousarray(np.asarray(layout.goals, dtype=np.int32).reshape(-1))
         cfg = RwConfig(
@@ -205,6 +206,9 @@ class Engine:
 
     def close(self):
         if self._h:
+            for p, _ in self._arena.values():
+                self.lib.rw_device_free(self._h, p)
+            self._arena = {}
             self.lib.rw_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -250,28 +254,30 @@ class Engine:
         obs = np.empty((T,) + self.shapes["obs"], np.float32) if want_obs else None
         rew = np.empty((T, self.B, self.N), np.float32)
         term = np.empty((T, self.B), np.uint8)
-        ptrs = []
+        # device tapes from the engine's arena: grow-only buffers kept for the engine's lifetime, so a training loop that
+        # calls rollout() with the same T does no device allocation after the first call
+        d_a = self._arena_buf("actions", a.nbytes)
+        self._check(self.lib.rw_copy_to_device(self._h, d_a, a.ctypes.data, a.nbytes))
+        d_o = self._arena_buf("obs", obs.nbytes) if want_obs else C.c_void_p(0)
+        d_r, d_t = self._arena_buf("rewards", rew.nbytes), self._arena_buf("terminated", term.nbytes)
+        self._check(self.lib.rw_step_many_device(self._h, d_a, T, d_o, d_r, d_t))
+        if want_obs:
+            self._check(self.lib.rw_copy_to_host(self._h, obs.ctypes.data, d_o, obs.nbytes))
+        self._check(self.lib.rw_copy_to_host(self._h, rew.ctypes.data, d_r, rew.nbytes))
+        self._check(self.lib.rw_copy_to_host(self._h, term.ctypes.data, d_t, term.nbytes))
+        return obs, rew, term
 
-        def dev(nbytes):
+    def _arena_buf(self, name, nbytes):
+        ent = self._arena.get(name)
+        if ent is None or ent[1] < nbytes:
+            if ent is not None:
+                self._check(self.lib.rw_device_free(self._h, ent[0]))
+                del self._arena[name]
             p = C.c_void_p()
             self._check(self.lib.rw_device_malloc(self._h, nbytes, C.byref(p)))
-            ptrs.append(p)
-            return p
-
-        try:
-            d_a = dev(a.nbytes)
-            self._check(self.lib.rw_copy_to_device(self._h, d_a, a.ctypes.data, a.nbytes))
-            d_o = dev(obs.nbytes) if want_obs else C.c_void_p(0)
-            d_r, d_t = dev(rew.nbytes), dev(term.nbytes)
-            self._check(self.lib.rw_step_many_device(self._h, d_a, T, d_o, d_r, d_t))
-            if want_obs:
-                self._check(self.lib.rw_copy_to_host(self._h, obs.ctypes.data, d_o, obs.nbytes))
-            self._check(self.lib.rw_copy_to_host(self._h, rew.ctypes.data, d_r, rew.nbytes))
-            self._check(self.lib.rw_copy_to_host(self._h, term.ctypes.data, d_t, term.nbytes))
-        finally:
-            for p in ptrs:
-                self.lib.rw_device_free(self._h, p)
-        return obs, rew, term
+            ent = self._arena[name] = (p, nbytes)
+            self.arena_allocations += 1
+        return ent[0]
 
     def snapshot(self, into=None):
         """Device-resident copy of the whole env state (see rw_snapshot_*); returns an opaque handle."""

@@ -893,12 +893,18 @@ int rw_write(rw_engine *eng, int kind, const void *host_src, size_t bytes) {
     if (!eng || kind < 0 || kind >= RW_BUF_KIND_COUNT || (!host_src && bytes)) return RW_ERR_INVALID_ARG;
     if (bytes != eng->buf[kind].bytes)
         return fail(eng, RW_ERR_INVALID_ARG, "rw_write kind %d: %zu bytes given, buffer holds %zu", kind, bytes, eng->buf[kind].bytes);
+    // engine-owned flags: the step kernel stores them only when they change (truncated never does, :942), so a host write
+    // would stick for the engine's lifetime — refused rather than silently different from the reference
+    if (kind == RW_BUF_TRUNCATED)
+        return fail(eng, RW_ERR_INVALID_ARG, "rw_write: RW_BUF_TRUNCATED is read-only (the reference never truncates, rware/warehouse.py:942)");
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
     if (bytes) RW_HIP(eng, hipMemcpyAsync(eng->buf[kind].ptr, host_src, bytes, hipMemcpyHostToDevice, eng->stream));
     if (kind == RW_BUF_GRID) {
         const int rc = rebuild_shadow(eng);
         if (rc != RW_OK) return rc;
         eng->grid_stale = false;  // the caller's grid is the state now
+    } else if (kind == RW_BUF_AGENT_X || kind == RW_BUF_AGENT_Y) {
+        eng->grid_stale = true;   // layer 0 of the derived int32 grid follows the coordinates: rebuilt on the next read
     }
     RW_HIP(eng, hipStreamSynchronize(eng->stream));
     return RW_OK;

@@ -1224,7 +1224,9 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             p.truncated[e0 + e] = 0;
             p.need_reset[e0 + e] = 0;
         }
-        lds_barrier();
+        // fused rollout: a later step's write-back (another wavefront) may store need_reset = 1 for the same env — this
+        // path's stores are made visible first (vmcnt drained before the barrier; the path is rare, the wait is free)
+        if (kRollout) __syncthreads(); else lds_barrier();
     }
     RW_MARK(TL_RESET);
 
@@ -1254,7 +1256,10 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     // Only what changed: RW_BUF_TRUNCATED is zero for the engine's lifetime (the reference never truncates,
                     // :942); need_reset was 0 (the env stepped) and becomes 1 only on termination; the queue changes only
                     // on a delivery.  Every store stream a step does not issue is ~0.1 us of it (DESIGN.md ablations).
-                    if (ev[ENVI_DONE] && k_autoreset == AR_NEXT_STEP) p.need_reset[ge] = 1;
+                    // (fused rollout: only the launch's last step stores the flag — the reset at the top of the following
+                    //  step consumes it from LDS, and a store of 1 here would race the RS store of 0 there, which comes from
+                    //  another wavefront)
+                    if (ev[ENVI_DONE] && k_autoreset == AR_NEXT_STEP && (!kRollout || t + 1 == n_steps)) p.need_reset[ge] = 1;
                     if (ev[ENVI_QDIRTY])
                         for (int k = 0; k < Q; ++k) p.queue[(size_t)ge * Q + k] = s_queue[e * Q + k];
                 }
@@ -1533,7 +1538,9 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // headline batch, -7 % at the cache-exceeding batches).
         // (not in the fused rollout: its steps are bound by instruction issue, not by the store stream, and the single pass
         //  costs ~10 more VALU operations per float4: 4.16 -> 4.78 us per step there)
-        const bool xy_bytes = !kRollout && !k_normalised;  // workgroup-uniform
+        // (the coordinates travel as bytes: layouts wider or taller than 256 cells take the two-pass form as well — a
+        //  compile-time fact in the exact-shape and size-static builds)
+        const bool xy_bytes = !kRollout && !k_normalised && W <= 256 && H <= 256;  // workgroup-uniform
         if (worker && xy_bytes) {
             const int shift = (tid & 7) << 2, words_per_pass = TW >> 3;  // (TW % 8 == 0)
             const uint32_t *wp = s_obits + (tid >> 3);

@@ -115,8 +115,9 @@ class WarehouseVecEnv(_VectorEnvBase):
         self.closed = False
 
         devices = [0] if devices is None else list(devices)
-        if output == "torch" and len(devices) != 1:
-            raise ValueError("torch output is per-device: use one WarehouseVecEnv (one process) per GPU")
+        # output="torch" with several devices: every result is a tuple with one zero-copy tensor per device (shard order,
+        # env ranges in `shard_bounds`); step() takes one CUDA tensor per device (or one host array) and launches on every
+        # device before anything waits ("8 async launches ... default to device-resident tensors")
         base, rem = divmod(self.num_envs, len(devices))
         self._bounds, lo = [], 0
         for d in range(len(devices)):
@@ -148,10 +149,13 @@ class WarehouseVecEnv(_VectorEnvBase):
                 image_layers=[l.value for l in layers] if image else (),
                 image_directional=image_observation_directional, msg_bits=self.msg_bits))
         self._bounds = [b for b in self._bounds if b[1] > b[0]]
+        self.shard_bounds = list(self._bounds)  # env range [lo, hi) of every engine / device, in order
         self.devices = devices[: len(self.engines)]
         self.n_shelves = self.engines[0].S
         self._make_spaces()
-        self._tviews = None
+        self._tviews = {}
+        self._live_actions = None
+        self._pool = None
 
     # ------------------------------------------------------------------------------- spaces
     def _make_spaces(self):
@@ -207,16 +211,25 @@ class WarehouseVecEnv(_VectorEnvBase):
 
     def step_async(self, actions):
         t = self._torch
+        if t is not None and isinstance(actions, (list, tuple)) and actions and all(isinstance(a, t.Tensor) for a in actions):
+            # one CUDA tensor per device (the shards of a multi-device env): every launch is enqueued before anything waits
+            if len(actions) != len(self.engines):
+                raise ValueError(f"expected {len(self.engines)} per-device action tensors, got {len(actions)}")
+            live = []
+            for d, (eng, a) in enumerate(zip(self.engines, actions)):
+                a = self._device_actions(a, eng.B, d)
+                live.append(a)
+                eng.step_device(a.data_ptr())
+            self._live_actions = live
+            return
         if t is not None and isinstance(actions, t.Tensor) and actions.is_cuda:
-            if actions.numel() != self.num_envs * self.n_agents * (1 + self.msg_bits):
-                raise ValueError("device actions must hold B*N*(1+msg_bits) elements")
-            if actions.dtype in (t.int64, t.int16, t.int8, t.uint8) or not actions.is_contiguous():
-                # what a policy usually hands over (argmax / Categorical.sample() are int64): one small cast on the same
-                # stream, ordered before the step like any other torch op
-                actions = actions.to(t.int32).contiguous()
-            if actions.dtype != t.int32:
-                raise ValueError("device actions must be an integer tensor")
-            self._live_actions = actions  # keep alive until the step has run
+            if len(self.engines) != 1:
+                raise ValueError("a multi-device env takes one CUDA action tensor per device (a list), or a host array")
+            actions = self._device_actions(actions, self.num_envs, 0)
+            # Kept alive until the NEXT step call replaces it.  That is enough for torch's caching allocator, which is
+            # stream-ordered: memory freed on this stream is only handed to work enqueued later on the same stream, i.e.
+            # behind the step kernel that reads it (a tensor allocated on another stream needs record_stream by its owner).
+            self._live_actions = actions
             self.engines[0].step_device(actions.data_ptr())
             return
         a = np.asarray(actions)
@@ -236,10 +249,30 @@ class WarehouseVecEnv(_VectorEnvBase):
         for eng, (lo, hi) in zip(self.engines, self._bounds):
             eng.step_host(a[lo:hi])
 
+    def _device_actions(self, actions, n_envs, d):
+        t = self._torch
+        if not actions.is_cuda or actions.device.index != self.devices[d]:
+            raise ValueError(f"actions for shard {d} must live on cuda:{self.devices[d]}")
+        if actions.numel() != n_envs * self.n_agents * (1 + self.msg_bits):
+            raise ValueError("device actions must hold B*N*(1+msg_bits) elements")
+        if actions.dtype in (t.int64, t.int16, t.int8, t.uint8) or not actions.is_contiguous():
+            # what a policy usually hands over (argmax / Categorical.sample() are int64): one small cast on the same
+            # stream, ordered before the step like any other torch op
+            actions = actions.to(t.int32).contiguous()
+        if actions.dtype != t.int32:
+            raise ValueError("device actions must be an integer tensor")
+        return actions
+
     def step_wait(self):
         if self.output == "torch":
+            if len(self.engines) > 1:  # one tuple entry per device, in shard order; nothing waited for
+                vs = [self._torch_views(d) for d in range(len(self.engines))]
+                return (tuple(self._obs_of(v) for v in vs), tuple(v["rewards"] for v in vs),
+                        tuple(v["terminated_bool"] for v in vs), tuple(v["truncated_bool"] for v in vs), {})
             v = self._torch_views()
-            return self._observations(), v["rewards"], v["terminated"].bool(), v["truncated"].bool(), {}
+            # the flag buffers are uint8 0/1: reinterpreted as bool, not cast (a cast is a torch kernel per flag per step
+            # around a ~7 us step kernel)
+            return self._observations(), v["rewards"], v["terminated_bool"], v["truncated_bool"], {}
         obs = self._observations()
         rew = self._gather("rewards")
         term = self._gather("terminated").astype(bool)
@@ -250,6 +283,9 @@ class WarehouseVecEnv(_VectorEnvBase):
         """Open-loop rollout: `actions` (T, B, N) -> (obs (T,B,N,L), rewards (T,B,N), terminated (T,B)).
         One fused kernel launch per shard (`rw_step_many_device`): the env chunk stays in LDS across
         the T steps.  Bit-identical to T calls of step() with the same actions."""
+        t = self._torch
+        if t is not None and isinstance(actions, t.Tensor) and actions.is_cuda:
+            return self._rollout_device(actions, want_obs)
         a = np.asarray(actions)
         am = 1 + self.msg_bits
         a = a.reshape(a.shape[0], self.num_envs, self.n_agents, am) if a.size and a.size % (self.num_envs * self.n_agents * am) == 0 else a
@@ -261,6 +297,29 @@ class WarehouseVecEnv(_VectorEnvBase):
         parts = [eng.rollout_host(a[:, lo:hi], want_obs) for eng, (lo, hi) in zip(self.engines, self._bounds)]
         cat = lambda k: parts[0][k] if len(parts) == 1 else np.concatenate([p[k] for p in parts], axis=1)
         return (cat(0) if want_obs else None), cat(1), cat(2).astype(bool)
+
+    def _rollout_device(self, actions, want_obs):
+        """rollout() with a CUDA action tape (T, B, N[, 1+M]) of an output="torch" env: the tapes come back as torch tensors
+        on the same device — obs (T, B, N, L) float32, rewards (T, B, N) float32, terminated (T, B) bool — written by the one
+        fused launch on torch's current stream; nothing is copied, nothing is waited for, no device allocation outside torch's
+        caching allocator.  Out-of-range actions run as NOOP and raise at the next sync() (as for step())."""
+        t = self._torch
+        if len(self.engines) != 1:
+            raise ValueError("device rollouts are per device: one env per GPU")
+        eng, am = self.engines[0], 1 + self.msg_bits
+        per_step = self.num_envs * self.n_agents * am
+        if actions.numel() == 0 or actions.numel() % per_step:
+            raise AssertionError(f"expected (T, {self.num_envs}, {self.n_agents}" + (f", {am}" if self.msg_bits else "") + f") actions, got {tuple(actions.shape)}")
+        T = actions.numel() // per_step
+        if actions.dtype != t.int32 or not actions.is_contiguous():
+            actions = actions.to(t.int32).contiguous()
+        dev = actions.device
+        obs = t.empty((T,) + tuple(eng.shapes["obs"]), dtype=t.float32, device=dev) if want_obs else None
+        rew = t.empty((T, self.num_envs, self.n_agents), dtype=t.float32, device=dev)
+        term = t.empty((T, self.num_envs), dtype=t.uint8, device=dev)
+        self._live_actions = actions
+        eng.step_many_device(actions.data_ptr(), T, obs.data_ptr() if want_obs else 0, rew.data_ptr(), term.data_ptr())
+        return obs, rew, term.view(t.bool)
 
     def snapshot(self):
         """Checkpoint the batched state on the device (grid, agents, queue, counters, RNG streams).
@@ -284,7 +343,14 @@ class WarehouseVecEnv(_VectorEnvBase):
 
     # ------------------------------------------------------------------------------- buffers
     def _gather(self, name):
-        parts = [eng.read(name) for eng in self.engines]
+        if len(self.engines) > 1:  # one reader thread per device: ctypes drops the GIL, the PCIe copies overlap
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+
+                self._pool = ThreadPoolExecutor(len(self.engines))
+            parts = list(self._pool.map(lambda eng: eng.read(name), self.engines))
+        else:
+            parts = [eng.read(name) for eng in self.engines]
         return parts[0] if len(parts) == 1 else np.concatenate(parts, axis=1 if name == "rng" else 0)
 
     def _observations(self):
@@ -294,8 +360,9 @@ class WarehouseVecEnv(_VectorEnvBase):
             if self._dict_obs:
                 raise NotImplementedError("DICT observations are host-side views of the FLATTENED batch: use output='numpy' "
                                           "(or FLATTENED with output='torch')")
-            v = self._torch_views()
-            return {"image": v["obs"], "features": v["features"]} if self.observation_type == ObservationType.IMAGE_DICT else v["obs"]
+            if len(self.engines) > 1:
+                return tuple(self._obs_of(self._torch_views(d)) for d in range(len(self.engines)))
+            return self._obs_of(self._torch_views())
         if self._index_layers:
             self.sync()  # IndexError where the reference's _make_img_obs raises it (device tensors: at sync())
         obs = self._gather("obs")
@@ -350,12 +417,19 @@ class WarehouseVecEnv(_VectorEnvBase):
             }
         return tuple(agent(i) for i in range(n))
 
-    def _torch_views(self):
-        if self._tviews is None:
-            t, eng, dev = self._torch, self.engines[0], self.devices[0]
-            self._tviews = {k: t.as_tensor(eng.device_array(k), device=f"cuda:{dev}")
-                            for k in ("obs", "rewards", "terminated", "truncated", "features")}
-        return self._tviews
+    def _obs_of(self, v):
+        return {"image": v["obs"], "features": v["features"]} if self.observation_type == ObservationType.IMAGE_DICT else v["obs"]
+
+    def _torch_views(self, d=0):
+        v = self._tviews.get(d)
+        if v is None:
+            t, eng, dev = self._torch, self.engines[d], self.devices[d]
+            v = {k: t.as_tensor(eng.device_array(k), device=f"cuda:{dev}")
+                 for k in ("obs", "rewards", "terminated", "truncated", "features")}
+            v["terminated_bool"] = v["terminated"].view(t.bool)  # uint8 0/1 reinterpreted: no kernel, no copy
+            v["truncated_bool"] = v["truncated"].view(t.bool)
+            self._tviews[d] = v
+        return v
 
     def device_tensor(self, name):
         """Zero-copy torch view of any engine buffer (single-device envs)."""
@@ -371,7 +445,8 @@ class WarehouseVecEnv(_VectorEnvBase):
         return out
 
     def set_state(self, refresh_obs: bool = True, **fields):
-        for k, v in fields.items():
+        # `grid` first: later coordinate writes then re-mark the derived int32 view stale (layer 0 follows agent_x / agent_y)
+        for k, v in sorted(fields.items(), key=lambda kv: kv[0] != "grid"):
             if k not in STATE_FIELDS and k not in ("need_reset", "agent_msg"):
                 raise KeyError(k)
             v = np.asarray(v)
@@ -412,6 +487,10 @@ class WarehouseVecEnv(_VectorEnvBase):
         for eng in self.engines:
             eng.close()
         self.engines = []
+        self._tviews = {}
+        if self._pool is not None:
+            self._pool.shutdown(wait=False)
+            self._pool = None
         self.closed = True
 
     def close_extras(self, **kwargs):

@@ -561,7 +561,7 @@ def test_bench_graph_submit_mode():
     res = {}
     for mode in ("graph", "native"):
         cmd = [sys.executable, os.path.join(root, "bench.py"), "--submit", mode, "--steps", "700", "--warmup", "30", "--batch", "4096",
-               "--no-cpu-baseline", "--no-fused-extra", "--no-sustained"]
+               "--no-cpu-baseline", "--no-hbm-regime", "--no-api-loop", "--no-fused-extra", "--no-sustained"]
         out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         res[mode] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

@@ -149,3 +149,28 @@ def test_cpu_baseline_legs_report_cores_and_model():
     ref2, _ = cb.time_reference("rware-small-4ag-v1", 0.5, 2)
     assert 1e2 < ref1 < one and 1e2 < ref2              # the pure-Python step: thousands per core
     assert isinstance(standin, bool)
+
+
+def test_staged_reference_is_the_unmodified_tree():
+    """oracle/make_ref.sh stages rware/{__init__,warehouse}.py byte for byte into the git-ignored oracle/_ref/
+    (what bench.py's cpu_baseline leg imports on the GPU box): same sha256 as the files under /root/reference."""
+    import hashlib
+    import os
+    import subprocess
+
+    tree = "/root/reference"
+    if not os.path.isfile(os.path.join(tree, "rware", "warehouse.py")):
+        pytest.skip("no reference tree to compare the staged copy with")
+    here = os.path.dirname(os.path.abspath(rr.__file__))
+    subprocess.check_call(["bash", os.path.join(here, "make_ref.sh")])
+    lines = open(os.path.join(rr.STAGED_ROOT, "MANIFEST.sha256")).read().split("\n")
+    seen = 0
+    for line in filter(None, lines):
+        sha, rel = line.split()
+        for root in (rr.STAGED_ROOT, tree):
+            with open(os.path.join(root, rel), "rb") as f:
+                assert hashlib.sha256(f.read()).hexdigest() == sha, (root, rel)
+        seen += 1
+    assert seen == 2
+    tracked = subprocess.run(["git", "ls-files", "oracle/_ref"], cwd=os.path.dirname(here), capture_output=True, text=True).stdout
+    assert tracked.strip() == "", "the staged reference must stay out of git history"
