@@ -43,6 +43,10 @@ HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_MEASURED_GBPS = 6290.0   # same guide: measured float4 copy ceiling
 TAPE_STEPS = int(os.environ.get("RWARE_BENCH_TAPE_STEPS", "256"))
 SUSTAINED_STEPS, SUSTAINED_WARMUP = 2000, 100
+try:
+    ORIG_AFFINITY = set(os.sched_getaffinity(0))  # before pin_rank() narrows it
+except AttributeError:
+    ORIG_AFFINITY = None
 KERNEL_SOURCES = ("rware_kernels.h", "rware_cdna4.h", "rware_pcg64.h", "rware_capi.hip")
 
 
@@ -58,7 +62,9 @@ def kernel_sources_sha() -> str:
 def cpu_baseline(env_id: str):
     """CPU legs in a fresh interpreter (it forks workers; this process holds an initialised HIP runtime)."""
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), env_id]
-    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    # (this process pinned itself to a few cores next to its GPU: the CPU legs get every core the job was given)
+    unpin = (lambda: os.sched_setaffinity(0, ORIG_AFFINITY)) if ORIG_AFFINITY else None
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, preexec_fn=unpin)
     if out.returncode != 0:
         return {"error": out.stderr[-500:]}
     return json.loads(out.stdout)
@@ -81,6 +87,79 @@ def spawn_ranks(n: int):
     # if this rank dies early, the others would sit at the rendezvous until its timeout: take them down with it
     atexit.register(lambda: [c.kill() for c in children if c.poll() is None])
     return children
+
+
+# ------------------------------------------------------------------------------------------ host placement
+def _parse_cpulist(txt):
+    out = []
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def gpu_numa_node(torch, dev):
+    """NUMA node of HIP device `dev` from its PCI address (/sys/bus/pci/devices/<bdf>/numa_node), or -1."""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        bdf = f"{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}.0"
+        v = _read(f"/sys/bus/pci/devices/{bdf}/numa_node")
+        return int(v) if v is not None else -1
+    except Exception:  # noqa: BLE001
+        return -1
+
+
+def pin_rank(torch, local_rank, local_world, dev_of_rank):
+    """Pins this process to whole physical cores of its GPU's NUMA node, disjoint from the other local ranks' cores.
+    The step kernel is ~7 us and a launch costs the host ~3.6 us: a rank that shares SMT siblings with another rank, or sits
+    on the far socket from its GPU, is how 8 x 9 G agent-steps/s becomes 5 x.  Returns a description for the JSON line."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return {"pinned": False, "why": "no sched_getaffinity"}
+    if os.environ.get("RWARE_BENCH_NO_PIN") == "1":
+        return {"pinned": False, "why": "RWARE_BENCH_NO_PIN=1", "cpus": len(allowed)}
+    nodes = [gpu_numa_node(torch, dev_of_rank(r)) for r in range(local_world)]
+    mine = nodes[local_rank]
+    cpus = allowed
+    if mine >= 0:
+        txt = _read(f"/sys/devices/system/node/node{mine}/cpulist")
+        on_node = [c for c in (_parse_cpulist(txt) if txt else []) if c in set(allowed)]
+        if on_node:
+            cpus = on_node
+        else:
+            mine = -1
+    peers = [r for r in range(local_world) if (nodes[r] if mine >= 0 else -1) == mine or mine < 0]  # ranks sharing this CPU pool
+    # whole physical cores: group the pool's CPUs by their SMT sibling set
+    cores, seen = [], set()
+    for c in cpus:
+        if c in seen:
+            continue
+        sib = _read(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list")
+        grp = [x for x in (_parse_cpulist(sib) if sib else [c]) if x in set(cpus)] or [c]
+        seen.update(grp)
+        cores.append(grp)
+    k = peers.index(local_rank)
+    per = len(cores) // len(peers)
+    if per < 1:  # fewer physical cores than ranks on this node: share, but say so
+        return {"pinned": False, "why": f"{len(cores)} physical cores for {len(peers)} ranks", "numa_node": mine, "cpus": len(cpus)}
+    take = cores[k * per:(k + 1) * per][:8]  # (a rank runs one launch thread: 8 cores are plenty, the rest stay free)
+    mask = sorted(x for grp in take for x in grp)
+    try:
+        os.sched_setaffinity(0, mask)
+    except OSError as exc:
+        return {"pinned": False, "why": str(exc), "numa_node": mine}
+    return {"pinned": True, "numa_node": mine, "physical_cores": len(take), "cpus": mask if len(mask) <= 16 else f"{mask[0]}-{mask[-1]} ({len(mask)})"}
 
 
 HBM_REGIME_BATCH, HBM_REGIME_STEPS, HBM_REGIME_WARMUP, HBM_REGIME_TAPE = 262144, 300, 30, 8
@@ -203,11 +282,13 @@ def main():
     ap.add_argument("--many", type=int, default=0,
                     help="fused rollout: submit steps in chunks of this many through rw_step_many_device (one launch per chunk, "
                          "env chunk resident in LDS across the steps; open-loop)")
-    ap.add_argument("--submit", choices=["native", "python", "graph"], default="native",
+    ap.add_argument("--submit", choices=["auto", "native", "python", "graph"], default="auto",
                     help="who issues the per-step launches: the library's loop over the device action tape (rw_step_tape_device, "
                          "default), one Python -> ctypes rw_step_device call per step, or the same launches captured once in a "
                          "HIP graph (one whole pass over the action tape) and replayed — for rocprofv3 traces of the small "
-                         "kernels, where the profiled host cannot issue single launches fast enough; the launches are identical")
+                         "kernels, where the profiled host cannot issue single launches fast enough; the launches are identical.  "
+                         "auto = native at N = 1, graph at N > 1: with the launches in a graph a rank's host thread issues one call "
+                         "per 256 steps, so 8 ranks cannot slow each other down on the host side (SURVEY.md §8(e))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-rollout measurement (profiling runs)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the fixed 2000-step sustained leg (profiling runs)")
@@ -215,6 +296,8 @@ def main():
     ap.add_argument("--no-api-loop", action="store_true", help="skip the Python closed-loop API leg")
     args = ap.parse_args()
 
+    if args.submit == "auto":
+        args.submit = "graph" if (args.gpus > 1 and args.many == 0) else "native"
     children = []
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         import torch  # (before spawning: a rank without a device would leave the others waiting at the rendezvous)
@@ -241,6 +324,9 @@ def main():
     elif local_rank >= n_dev:
         raise SystemExit(f"rank {rank}: --gpus {args.gpus} but only {n_dev} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
+    share = os.environ.get("RWARE_BENCH_SHARE_GPU") == "1"
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    placement = pin_rank(torch, int(os.environ.get("LOCAL_RANK", "0")), local_world, (lambda r: r % n_dev) if share else (lambda r: min(r, n_dev - 1)))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -360,6 +446,12 @@ def main():
         tt = torch.tensor(vals, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         vals = [float(v) for v in tt]
+    mine = {"rank": rank, "device": local_rank, "ms_per_step": elapsed / args.steps * 1e3, "kernel_ms_per_launch": kernel_ms,
+            "sustained_ms_per_step": (sus[0] / SUSTAINED_STEPS * 1e3) if sus else None, "placement": placement}
+    per_rank = [mine]
+    if dist is not None:  # (objects over gloo: still nothing on the data path)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     elapsed, kernel_ms, sus_s, sus_kernel_ms, fused_s = vals
 
     if rank == 0:
@@ -387,7 +479,8 @@ def main():
                             "step+FLATTENED obs, on-device next_step autoreset every 500 steps",
                 "envs_per_gpu": B, "n_agents": N, "obs_length": int(info.obs_length),
                 "grid": [int(info.grid_h), int(info.grid_w)],
-                "parallelism": f"env-shard x{world} (no collective, no RCCL; gloo barrier + MAX of the timings only)",
+                "parallelism": f"env-shard x{world} (no collective, no RCCL; gloo barrier + MAX of the timings only); each rank pinned to "
+                               f"whole physical cores of its GPU's NUMA node ({sum(1 for r in per_rank if r['placement'].get('pinned'))}/{world} pinned, see `ranks`)",
                 "submit": f"rw_step_many_device x{args.many} (fused rollout, one launch per chunk)" if args.many
                           else "one rw_step_device launch per step (closed-loop capable kernel), issued by "
                                + ("rw_step_tape_device's native loop over the device action tape" if args.submit == "native"
@@ -406,6 +499,7 @@ def main():
                 "algorithmic_bytes_per_launch": per_launch, "kernel_sources_sha": sha,
             },
         }
+        out["ranks"] = per_rank  # a straggler (or a badly placed rank) shows here: `value` uses the MAX over ranks
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
         if sus_s:

@@ -372,7 +372,11 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int k_goal0 = p.goal_cells[0], k_goal1 = p.goal_cells[1];
     // (exact-shape builds whose LDS carve-up is a compile-time constant clear their scratch regions while this batch is in
     //  flight and pin it afterwards — kClearFirst, below; the others pin it here)
-    constexpr bool kClearFirst = Cfg::kN != 0 && Cfg::kE != 0 && (!kImage || Cfg::kNL > 0) && (!kMsg || Cfg::kM != 0);
+#ifndef RW_CLEAR_FIRST_MODE
+#define RW_CLEAR_FIRST_MODE 1
+#endif
+    constexpr bool kClearFirst = RW_CLEAR_FIRST_MODE != 0 && (RW_CLEAR_FIRST_MODE == 1 || kImage || kMsg) &&
+                                 Cfg::kN != 0 && Cfg::kE != 0 && (!kImage || Cfg::kNL > 0) && (!kMsg || Cfg::kM != 0);
     if constexpr (!kClearFirst) {
         keep_sgpr_ptr(g_shadow, q_ax, q_ay, q_dir, q_carry, q_deliv, q_queue, q_steps, q_inact, q_hw, q_need);
         keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);

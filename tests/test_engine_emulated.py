@@ -576,3 +576,66 @@ def test_position_layout_matches_oracle_with_host_writes_and_snapshots(pos_layou
     for k in so:
         assert np.array_equal(st[k], so[k]), k
     env.close()
+
+
+# --------------------------------------------------------------------------- round-3 additions (advisor findings)
+@pytest.mark.parametrize("name,geom,tile", [
+    ("tiny-2ag", (0, 0), 4),           # pair exchange (N = 2)
+    ("small-4ag", (0, 0), 2),          # quad exchange (N = 4)
+    ("medium-6ag-hard", (0, 0), 8),    # ds_bpermute exchange (N = 6)
+])
+def test_emulated_exact_shape_builds_full_length_golden(name, geom, tile):
+    """One FULL-length golden replay per register-exchange flavour on the emulation: the late part of a trace is where the
+    deliveries, the request replacement (queue written back only when dirty), termination and the autoreset are."""
+    meta, z = gu.load_fixture(name)
+    be = EngineBackend(meta["E"], library=LIB, envs_per_workgroup=geom[0], threads_per_workgroup=geom[1], tile=tile,
+                       **gu.ctor_kwargs(meta))
+    assert be.env.engines[0].info.specialised == 1
+    n = gu.replay(be, meta, z)
+    assert n == meta["T"] if "T" in meta else n > 300
+    be.env.close()
+
+
+def test_layouts_wider_than_256_cells_keep_exact_coordinates():
+    """x, y travel as bytes through the single-pass observation expansion only when the grid fits 256 x 256; a 4 x 268 grid
+    (shelf_columns=89, column_height=1) must take the float path: agents at x >= 256 report x, not x mod 256."""
+    kw = dict(shelf_columns=89, column_height=1, shelf_rows=1, n_agents=8, msg_bits=0, sensor_range=1, request_queue_size=4,
+              max_inactivity_steps=None, max_steps=500, reward_type=1)
+    B = 6
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **kw)
+    assert env.grid_size[1] > 256
+    orc = OracleVecEnv(B, **kw)
+    obs, _ = env.reset(seed=21)
+    assert np.array_equal(obs, orc.reset(seed=21))
+    assert (obs[..., 0] >= 256).any(), "no agent beyond x = 255: pick another seed"
+    rng = np.random.default_rng(2)
+    for t in range(8):
+        a = rng.choice(5, size=(B, 8), p=[0.1, 0.6, 0.1, 0.1, 0.1]).astype(np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(obs, o2), t
+    env.close()
+
+
+def test_coordinate_writes_mark_the_derived_grid_stale_and_truncated_is_read_only():
+    kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
+    env = rware_amd.WarehouseVecEnv(4, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **kw)
+    env.reset(seed=1)
+    st = env.get_state()
+    ax, ay = st["agent_x"].copy(), st["agent_y"].copy()
+    free = (st["grid"][:, 0] == 0) & (st["grid"][:, 1] == 0)
+    for e in range(4):                                    # teleport agent 0 of every env to a free cell
+        y, x = np.argwhere(free[e])[0]
+        ax[e, 0], ay[e, 0] = x, y
+    env.set_state(agent_x=ax, agent_y=ay)
+    g = env.get_state()["grid"]
+    for e in range(4):
+        assert g[e, 0, ay[e, 0], ax[e, 0]] == 1            # layer 0 follows the coordinates right away, not after a step
+        assert (g[e, 0] == 1).sum() == 1
+    # grid and coordinates given together, in either keyword order: the caller's coordinates win for layer 0
+    env.set_state(agent_y=st["agent_y"], grid=st["grid"], agent_x=st["agent_x"])
+    assert np.array_equal(env.get_state()["grid"], st["grid"])
+    with pytest.raises(Exception):
+        env.engines[0].write("truncated", np.ones(4, np.uint8))
+    assert not env.engines[0].read("truncated").any()
+    env.close()
