@@ -51,6 +51,9 @@ struct rw_engine {
     rw::LaunchArgs la{};          // per-launch defaults: the engine's own output buffers
     bool specialised = false;
     bool grid_stale = false;   // steps / resets have run since RW_BUF_GRID was last rebuilt (refresh_grid)
+    bool agents_stale = false; // ... since RW_BUF_AGENT_X .. _DELIVERED were last unpacked from the records (refresh_agents)
+    size_t rec_off = 0;
+    uint32_t *d_rec = nullptr; // [B][N] packed agent records (rw::rec_pack): the agents' state as the step kernels keep it
     void *slab = nullptr;      // the single device allocation behind every buffer below
     size_t shadow_off = 0;
     void *d_shadow = nullptr;  // compact shelf layer (uint8 when S <= 255, else uint16), the kernel's read path
@@ -165,7 +168,7 @@ const StaticEntry kStatic[] = {
 
 int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     la.op = op | (la.timeline ? rw::OP_FLAG_TIMELINE : 0);
-    if (op != rw::OP_OBS) eng->grid_stale = true;  // the kernels keep the shadow and the coordinates current, not the int32 view
+    if (op != rw::OP_OBS) eng->grid_stale = eng->agents_stale = true;  // the kernels keep the shadow and the packed agent records current, not the int32 views
     if (start || stop)  // the events ride on this dispatch (its own start / end timestamps): no marker packets in the stream
         hipExtLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
                               eng->stream, start, stop, 0, (const rw::Params *)eng->d_prm, RW_LAUNCH_ARGS(la));
@@ -211,24 +214,49 @@ int sync_shadow(rw_engine *eng) {
 int refresh_grid(rw_engine *eng) {
     if (!eng->grid_stale) return RW_OK;
     { const int rc = sync_shadow(eng); if (rc != RW_OK) return rc; }
-    const int B = eng->prm.B, HW = eng->prm.HW, W = eng->prm.W, N = eng->prm.N;
+    const int B = eng->prm.B, HW = eng->prm.HW, N = eng->prm.N;
     const size_t n = (size_t)B * HW, na = (size_t)B * N;
     // (grid-stride loops, one wavefront per workgroup, 64 cells / agents per thread: a few thousand workgroups at the big batches)
     const unsigned blocks = (unsigned)((n + 4095) / 4096 < 4096 ? (n + 4095) / 4096 : 4096);
     const unsigned ablocks = (unsigned)((na + 4095) / 4096 < 1024 ? (na + 4095) / 4096 : 1024);
     int32_t *grid = (int32_t *)eng->buf[RW_BUF_GRID].ptr;
-    const int32_t *ax = (const int32_t *)eng->buf[RW_BUF_AGENT_X].ptr, *ay = (const int32_t *)eng->buf[RW_BUF_AGENT_Y].ptr;
+    const uint32_t *rec = eng->d_rec;
     if (eng->wide) {
         hipLaunchKernelGGL((rw::rware_grid_cells_kernel<uint16_t>), dim3(blocks), dim3(64), 0, eng->stream,
                            (const uint16_t *)eng->d_shadow, grid, B, HW);
-        hipLaunchKernelGGL((rw::rware_grid_agents_kernel<uint16_t>), dim3(ablocks), dim3(64), 0, eng->stream, ax, ay, grid, B, HW, W, N);
+        hipLaunchKernelGGL((rw::rware_grid_agents_kernel<uint16_t>), dim3(ablocks), dim3(64), 0, eng->stream, rec, grid, B, HW, N);
     } else {
         hipLaunchKernelGGL((rw::rware_grid_cells_kernel<uint8_t>), dim3(blocks), dim3(64), 0, eng->stream,
                            (const uint8_t *)eng->d_shadow, grid, B, HW);
-        hipLaunchKernelGGL((rw::rware_grid_agents_kernel<uint8_t>), dim3(ablocks), dim3(64), 0, eng->stream, ax, ay, grid, B, HW, W, N);
+        hipLaunchKernelGGL((rw::rware_grid_agents_kernel<uint8_t>), dim3(ablocks), dim3(64), 0, eng->stream, rec, grid, B, HW, N);
     }
     RW_HIP(eng, hipGetLastError());
     eng->grid_stale = false;
+    return RW_OK;
+}
+
+// RW_BUF_AGENT_X .. RW_BUF_AGENT_DELIVERED are derived views of the packed agent records: unpacked when somebody asks
+bool is_agent_view(int kind) { return kind >= RW_BUF_AGENT_X && kind <= RW_BUF_AGENT_DELIVERED; }
+unsigned agent_blocks(size_t n) { return (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024); }
+int refresh_agents(rw_engine *eng) {
+    if (!eng->agents_stale) return RW_OK;
+    const size_t n = (size_t)eng->prm.B * eng->prm.N;
+    hipLaunchKernelGGL((rw::rware_unpack_agents_kernel<>), dim3(agent_blocks(n)), dim3(256), 0, eng->stream, (const uint32_t *)eng->d_rec,
+                       (int32_t *)eng->buf[RW_BUF_AGENT_X].ptr, (int32_t *)eng->buf[RW_BUF_AGENT_Y].ptr, (int32_t *)eng->buf[RW_BUF_AGENT_DIR].ptr,
+                       (int32_t *)eng->buf[RW_BUF_AGENT_CARRY].ptr, (int32_t *)eng->buf[RW_BUF_AGENT_DELIVERED].ptr, n, eng->prm.W);
+    RW_HIP(eng, hipGetLastError());
+    eng->agents_stale = false;
+    return RW_OK;
+}
+// after a host write of one of the five views: the views are the state now, the records follow
+int pack_agents(rw_engine *eng) {
+    const size_t n = (size_t)eng->prm.B * eng->prm.N;
+    hipLaunchKernelGGL((rw::rware_pack_agents_kernel<>), dim3(agent_blocks(n)), dim3(256), 0, eng->stream, eng->d_rec,
+                       (const int32_t *)eng->buf[RW_BUF_AGENT_X].ptr, (const int32_t *)eng->buf[RW_BUF_AGENT_Y].ptr,
+                       (const int32_t *)eng->buf[RW_BUF_AGENT_DIR].ptr, (const int32_t *)eng->buf[RW_BUF_AGENT_CARRY].ptr,
+                       (const int32_t *)eng->buf[RW_BUF_AGENT_DELIVERED].ptr, n, eng->prm.W);
+    RW_HIP(eng, hipGetLastError());
+    eng->agents_stale = false;
     return RW_OK;
 }
 
@@ -493,6 +521,8 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         RW_BUF_ACTIONS, RW_BUF_RNG, RW_BUF_FEATURES, RW_BUF_OBS, RW_BUF_GRID};
     auto up = [](size_t x) { return (x + 4095) & ~(size_t)4095; };
     size_t slab_bytes = 0, off[RW_BUF_KIND_COUNT];
+    eng->rec_off = 0;  // the packed agent records lead the hot set
+    slab_bytes += up(szB * N * sizeof(uint32_t));
     for (int k : order) {
         eng->buf[k].bytes = n_elems[k] * elem_size(k);
         off[k] = slab_bytes;
@@ -508,6 +538,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     RW_HIP_C(hipMemsetAsync(eng->slab, 0, slab_bytes, eng->stream));
     for (int k = 0; k < RW_BUF_KIND_COUNT; ++k) eng->buf[k].ptr = (char *)eng->slab + off[k];
     eng->d_shadow = (char *)eng->slab + eng->shadow_off;
+    eng->d_rec = (uint32_t *)((char *)eng->slab + eng->rec_off);
     eng->d_pos = (uint8_t *)eng->slab + eng->pos_off;
     const int HWW = (HW + 31) / 32;
     // the static kernels stage the bitmap in whole 16-byte pieces: allocate (and zero) the rounded-up size
@@ -548,6 +579,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.highway_bits = eng->d_highway_bits;
     p.shelf_init = eng->d_shelf_init;
     p.grid = (int32_t *)eng->buf[RW_BUF_GRID].ptr;
+    p.arec = eng->d_rec;
     p.ax = (int32_t *)eng->buf[RW_BUF_AGENT_X].ptr;
     p.ay = (int32_t *)eng->buf[RW_BUF_AGENT_Y].ptr;
     p.adir = (int32_t *)eng->buf[RW_BUF_AGENT_DIR].ptr;
@@ -773,10 +805,9 @@ struct rw_snapshot {
 namespace {
 // the state that reset()/step() evolve: (device pointer, size) pieces in a fixed order
 std::vector<std::pair<void *, size_t>> state_pieces(rw_engine *eng) {
-    static const int kinds[] = {RW_BUF_AGENT_X, RW_BUF_AGENT_Y, RW_BUF_AGENT_DIR, RW_BUF_AGENT_CARRY,
-                                RW_BUF_AGENT_DELIVERED, RW_BUF_QUEUE, RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_RNG,
-                                RW_BUF_NEED_RESET, RW_BUF_AGENT_MSG};
+    static const int kinds[] = {RW_BUF_QUEUE, RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_RNG, RW_BUF_NEED_RESET, RW_BUF_AGENT_MSG};
     std::vector<std::pair<void *, size_t>> v;
+    v.emplace_back(eng->d_rec, (size_t)eng->prm.B * eng->prm.N * sizeof(uint32_t));  // the agents: their packed records
     for (int k : kinds) v.emplace_back(eng->buf[k].ptr, eng->buf[k].bytes);
     v.emplace_back(eng->d_shadow, (size_t)eng->prm.B * eng->prm.HW * (eng->wide ? 2 : 1));
     if (eng->pos_layout) v.emplace_back(eng->d_pos, (size_t)eng->prm.B * eng->prm.S);
@@ -819,7 +850,7 @@ int rw_snapshot_restore(rw_engine *eng, const rw_snapshot *snap) {
         if (pc.second) RW_HIP(eng, hipMemcpyAsync(pc.first, (const char *)snap->mem + off, pc.second, hipMemcpyDeviceToDevice, eng->stream));
         off += (pc.second + 255) & ~(size_t)255;
     }
-    eng->grid_stale = true;  // (the int32 grid is not part of a snapshot: it is derived from what is)
+    eng->grid_stale = eng->agents_stale = true;  // (the int32 views are not part of a snapshot: they are derived from what is)
     return launch(eng, eng->la, rw::OP_OBS);
 }
 
@@ -865,9 +896,9 @@ int rw_refresh_grid(rw_engine *eng) {
 
 int rw_get_buffer(rw_engine *eng, int kind, void **dev_ptr, size_t *bytes) {
     if (!eng || kind < 0 || kind >= RW_BUF_KIND_COUNT) return RW_ERR_INVALID_ARG;
-    if (kind == RW_BUF_GRID) {
+    if (kind == RW_BUF_GRID || is_agent_view(kind)) {
         RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
-        const int rc = refresh_grid(eng);
+        const int rc = kind == RW_BUF_GRID ? refresh_grid(eng) : refresh_agents(eng);
         if (rc != RW_OK) return rc;
     }
     if (dev_ptr) *dev_ptr = eng->buf[kind].ptr;
@@ -880,8 +911,8 @@ int rw_read(rw_engine *eng, int kind, void *host_dst, size_t bytes) {
     if (bytes != eng->buf[kind].bytes)
         return fail(eng, RW_ERR_INVALID_ARG, "rw_read kind %d: %zu bytes given, buffer holds %zu", kind, bytes, eng->buf[kind].bytes);
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
-    if (kind == RW_BUF_GRID) {
-        const int rc = refresh_grid(eng);
+    if (kind == RW_BUF_GRID || is_agent_view(kind)) {
+        const int rc = kind == RW_BUF_GRID ? refresh_grid(eng) : refresh_agents(eng);
         if (rc != RW_OK) return rc;
     }
     if (bytes) RW_HIP(eng, hipMemcpyAsync(host_dst, eng->buf[kind].ptr, bytes, hipMemcpyDeviceToHost, eng->stream));
@@ -898,7 +929,15 @@ int rw_write(rw_engine *eng, int kind, const void *host_src, size_t bytes) {
     if (kind == RW_BUF_TRUNCATED)
         return fail(eng, RW_ERR_INVALID_ARG, "rw_write: RW_BUF_TRUNCATED is read-only (the reference never truncates, rware/warehouse.py:942)");
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    if (is_agent_view(kind)) {  // the other four views have to be current before the five are packed again
+        const int rc = refresh_agents(eng);
+        if (rc != RW_OK) return rc;
+    }
     if (bytes) RW_HIP(eng, hipMemcpyAsync(eng->buf[kind].ptr, host_src, bytes, hipMemcpyHostToDevice, eng->stream));
+    if (is_agent_view(kind)) {
+        const int rc = pack_agents(eng);
+        if (rc != RW_OK) return rc;
+    }
     if (kind == RW_BUF_GRID) {
         const int rc = rebuild_shadow(eng);
         if (rc != RW_OK) return rc;

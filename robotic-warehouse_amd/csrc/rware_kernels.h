@@ -85,7 +85,8 @@ struct Params {
     // The twelve pointers the P0 stage-in needs come first, contiguous and cache-line aligned: the
     // compiler fetches them with two wide scalar loads.
     void *shelf_shadow;            // CellT [B][HW] (+ padding): compact copy of grid layer 1, the kernel's read path
-    int32_t *ax, *ay, *adir, *acarry, *adeliv, *queue;
+    uint32_t *arec;                // [B][N] packed agent records (rec_pack below): the agents' state as the kernels keep it
+    int32_t *queue;
     const uint32_t *highway_bits;  // [HWW] bit c == highways[c]                  (static per config)
     int32_t *steps, *inactive;
     uint8_t *need_reset;           // [B]
@@ -101,6 +102,9 @@ struct Params {
     const int32_t *shelf_init;     // [HW] shelf layer right after reset: ids 1..S row-major on non-highway cells
     uint8_t *shelf_pos;            // [B][S] cell of shelf id k+1 — the shelf layer of the POSITION state layout (Cfg::kPos), else unused
     // state (device)
+    // exported int32 views RW_BUF_AGENT_X .. _DELIVERED: derived from `arec` on demand (rware_unpack_agents_kernel), never
+    // touched by the step kernels — five store streams and five load streams per step that the step does not issue
+    int32_t *ax, *ay, *adir, *acarry, *adeliv;
     int32_t *grid;
     uint8_t *truncated;   // [B]
     int32_t *status;      // [1] sticky error bits
@@ -275,6 +279,38 @@ __device__ __forceinline__ void rng_store(const Pcg64 &g, uint64_t *rng, int B, 
     rng[5 * (size_t)B + e] = (uint64_t)g.uinteger;
 }
 
+// Packed agent record — the HBM form of one agent (Agent.x/.y/.dir/.carrying_shelf/.has_delivered, rware/warehouse.py:82-93):
+//   bits 0..13  cell = y * W + x      (rw_create limits H*W to 10000 cells)
+//   bits 14..15 dir                    (rw_direction)
+//   bit  16     has_delivered
+//   bits 17..30 carried shelf id, 0 == none   (ids 1..S, S <= H*W)
+// One dword per agent: a step loads ONE stream and stores ONE stream for the agents' state instead of five each (the state
+// write-back is priced per store stream, DESIGN.md ablations).  The five exported int32 arrays are derived views.
+RW_HD uint32_t rec_pack(int cell, int d, int deliv, int carry) {
+    return (uint32_t)cell | ((uint32_t)d << 14) | ((uint32_t)(deliv ? 1 : 0) << 16) | ((uint32_t)carry << 17);
+}
+RW_HD int rec_cell(uint32_t r) { return (int)(r & 0x3fffu); }
+RW_HD int rec_dir(uint32_t r) { return (int)((r >> 14) & 3u); }
+RW_HD int rec_deliv(uint32_t r) { return (int)((r >> 16) & 1u); }
+RW_HD int rec_carry(uint32_t r) { return (int)((r >> 17) & 0x3fffu); }
+
+// exported views <-> records (host paths: rw_read / rw_get_buffer of an agent array; after rw_write of one)
+template <typename Dummy = void>
+__global__ void rware_unpack_agents_kernel(const uint32_t *rec, int32_t *ax, int32_t *ay, int32_t *adir, int32_t *acarry,
+                                           int32_t *adeliv, size_t n, int W) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t r = rec[i];
+        const int c = rec_cell(r), y = c / W;
+        ax[i] = c - y * W; ay[i] = y; adir[i] = rec_dir(r); acarry[i] = rec_carry(r); adeliv[i] = rec_deliv(r);
+    }
+}
+template <typename Dummy = void>
+__global__ void rware_pack_agents_kernel(uint32_t *rec, const int32_t *ax, const int32_t *ay, const int32_t *adir,
+                                         const int32_t *acarry, const int32_t *adeliv, size_t n, int W) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        rec[i] = rec_pack(ay[i] * W + ax[i], adir[i] & 3, adeliv[i], acarry[i] & 0x3fff);
+}
+
 // Rebuilds the exported int32 grid [B][2][H][W] (rware/warehouse.py:749-755, _recalc_grid) from the state the kernels keep:
 // layer 1 = the shelf shadow, layer 0 = agent ids at the agent coordinates.  Two launches: cells, then agents.
 template <typename CellT>
@@ -287,11 +323,11 @@ __global__ void rware_grid_cells_kernel(const CellT *shadow, int32_t *grid, int 
     }
 }
 template <typename CellT>
-__global__ void rware_grid_agents_kernel(const int32_t *ax, const int32_t *ay, int32_t *grid, int B, int HW, int W, int N) {
+__global__ void rware_grid_agents_kernel(const uint32_t *rec, int32_t *grid, int B, int HW, int N) {
     const size_t n = (size_t)B * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i / N;
-        grid[e * 2 * HW + (size_t)ay[i] * W + ax[i]] = (int32_t)(i - e * N) + 1;
+        grid[e * 2 * HW + (size_t)rec_cell(rec[i])] = (int32_t)(i - e * N) + 1;
     }
 }
 
@@ -363,7 +399,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // trips in the prologue (every launch starts with cold caches) and more inside the agent phases, which run on one
     // wavefront and cannot hide them.  keep_sgpr*() pins the values in scalar registers right here.
     CellT *const g_shadow = reinterpret_cast<CellT *>(p.shelf_shadow);
-    int32_t *const q_ax = p.ax, *const q_ay = p.ay, *const q_dir = p.adir, *const q_carry = p.acarry, *const q_deliv = p.adeliv;
+    uint32_t *const q_rec = p.arec;
     int32_t *const q_queue = p.queue, *const q_steps = p.steps, *const q_inact = p.inactive;
     const uint32_t *const q_hw = p.highway_bits;
     const uint8_t *const q_need = p.need_reset;
@@ -378,7 +414,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     constexpr bool kClearFirst = RW_CLEAR_FIRST_MODE != 0 && (RW_CLEAR_FIRST_MODE == 1 || kImage || kMsg) &&
                                  Cfg::kN != 0 && Cfg::kE != 0 && (!kImage || Cfg::kNL > 0) && (!kMsg || Cfg::kM != 0);
     if constexpr (!kClearFirst) {
-        keep_sgpr_ptr(g_shadow, q_ax, q_ay, q_dir, q_carry, q_deliv, q_queue, q_steps, q_inact, q_hw, q_need);
+        keep_sgpr_ptr(g_shadow, q_rec, q_queue, q_steps, q_inact, q_hw, q_need);
         keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
     }
     // IMAGE kernels: the layer list and its switches belong to the same batch — the image gather used to fetch them where
@@ -464,11 +500,16 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // gather, write-back) are written by the agent lanes together with their results.
     if constexpr (kClearFirst) {  // the LDS clear needs no parameter: it runs under the scalar batch's (cold) round trip
         clear_scratch();
-        keep_sgpr_ptr(g_shadow, q_ax, q_ay, q_dir, q_carry, q_deliv, q_queue, q_steps, q_inact, q_hw, q_need);
+        keep_sgpr_ptr(g_shadow, q_rec, q_queue, q_steps, q_inact, q_hw, q_need);
         keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
     }
     const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : q_need;  // OP_RESET: all-ones when no mask was given
     int r_x = 0, r_y = 0, r_d = 0, r_carry = 0, r_deliv = 0, r_act = ACT_NOOP, r_flag = 0, r_steps = 0, r_inact = 0;
+    uint32_t r_rec = 0;
+    auto unpack_own = [&]() {  // (W is a compile-time constant in the builds that use this)
+        r_y = rec_cell(r_rec) / W; r_x = rec_cell(r_rec) - r_y * W;
+        r_d = rec_dir(r_rec); r_carry = rec_carry(r_rec); r_deliv = rec_deliv(r_rec);
+    };
     constexpr int KMW = (kMsg && Cfg::kM) ? Cfg::kM : 1;
     int r_mw[KMW] = {};   // the action's message words (_MSG builds), r_msg: the agent's stored message
     int r_msg = 0;
@@ -479,7 +520,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         if (g < KG && le < Cfg::kE) {
             const int ge = e0 + le;
             const size_t gi = (size_t)ge * KN + a_idx;
-            r_x = q_ax[gi]; r_y = q_ay[gi]; r_d = q_dir[gi]; r_carry = q_carry[gi]; r_deliv = q_deliv[gi];
+            r_rec = q_rec[gi];  // ONE load per agent: the packed record (unpacked where it is first needed — unpack_own —
+                                // so that nothing up here waits for it: the clear and the DMA issue run under its latency)
             if (op == OP_STEP) r_act = la.actions[gi * AM];
             if constexpr (kMsg) {
                 r_msg = p.amsg[gi];
@@ -521,6 +563,15 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     // intent and occupant in that window, before the barrier that everything else of the agent phases has to wait for.
     constexpr bool kEarly = kDirect && !kRollout && Cfg::kT >= 128;
     Intent early{ACT_NOOP, 0, 0, 0, 0, -1};
+    // builds that stage the agents through LDS: the DMA put the chunk's packed records into the `ax` slot; every thread
+    // unpacks its agents in place (reads its own slot before it overwrites it) into the five per-agent LDS arrays
+    auto unpack_records = [&]() {
+        for (int i = tid; i < nea; i += T) {
+            const uint32_t r = (uint32_t)s_ax[i];
+            const int c = rec_cell(r), y = c / W;
+            s_ax[i] = c - y * W; s_ay[i] = y; s_dir[i] = rec_dir(r); s_carry[i] = rec_carry(r); s_deliv[i] = rec_deliv(r);
+        }
+    };
     if constexpr (!kClearFirst) clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
     RW_MARK(TL_ZEROED);
     if constexpr (Cfg::kE != 0) {
@@ -532,10 +583,11 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         static_assert(kPos || (Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0, "shelf chunk not 16-byte granular");
         const char *src[12] = {
             kPos ? reinterpret_cast<const char *>(g_pos + (size_t)e0 * S) : reinterpret_cast<const char *>(g_shadow + (size_t)e0 * HW),
-            reinterpret_cast<const char *>(q_ax + (size_t)e0 * N), reinterpret_cast<const char *>(q_ay + (size_t)e0 * N),
-            reinterpret_cast<const char *>(q_dir + (size_t)e0 * N), reinterpret_cast<const char *>(q_carry + (size_t)e0 * N),
-            reinterpret_cast<const char *>(q_deliv + (size_t)e0 * N),
-            reinterpret_cast<const char *>(op == OP_STEP ? la.actions + (size_t)e0 * N * AM : q_ax + (size_t)e0 * N),
+            // the chunk's packed records go to the `ax` slot and are unpacked in place behind the barrier (unpack_records);
+            // the ay / dir / carry / deliv slots have no DMA source any more (entries 2..5 are skipped below)
+            reinterpret_cast<const char *>(q_rec + (size_t)e0 * N), nullptr, nullptr, nullptr, nullptr,
+            reinterpret_cast<const char *>(op == OP_STEP ? la.actions + (size_t)e0 * N * AM
+                                                         : reinterpret_cast<const int32_t *>(q_rec) + (size_t)e0 * N),
             reinterpret_cast<const char *>(q_queue + (size_t)e0 * Q), reinterpret_cast<const char *>(q_hw),
             reinterpret_cast<const char *>(q_steps + e0), reinterpret_cast<const char *>(q_inact + e0),
             reinterpret_cast<const char *>(flag_src + e0)};
@@ -549,7 +601,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             const int wave_s = uniform(wave) - (kEarly ? 1 : 0), dma_w = nw - (kEarly ? 1 : 0);
             int job = 0;
             for (int k = 0; k < 12; ++k) {  // (fully unrolled when the shapes are compile-time constants)
-                if (kDirect && ((k >= 1 && k <= 6) || k >= 9)) continue;  // agent SoA, actions, counters, flags: in registers
+                if (k >= 2 && k <= 5) continue;  // (filled by unpack_records, not by DMA)
+                if (kDirect && ((k >= 1 && k <= 6) || k >= 9)) continue;  // agent records, actions, counters, flags: in registers
                 const int pieces = (seg[k + 1] - seg[k]) >> 2;
                 for (int c = 0; c < pieces; c += 64, ++job)
                     if (job % dma_w == wave_s && c + lane < pieces)
@@ -566,6 +619,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 if (uniform(wave) * KG < Cfg::kE) {  // wave-uniform: a wavefront that runs agent phases
                     const int g = lane / KN, a_idx = lane - g * KN;
                     const bool mine = (g < KG) && (wave * KG + g < Cfg::kE);
+                    unpack_own();
                     early = intent_of((op == OP_STEP) && mine && !r_flag, r_act, r_x, r_y, r_d);
                     early.occ_w = occupant_of(early, r_carry, a_idx, (g < KG ? g : KG - 1) * KN);
                     keep_vgpr(early.tg0, early.occ_w);  // (materialised here, not sunk below the barrier)
@@ -579,7 +633,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
 #pragma unroll
                 for (int k = 1; k < 12; ++k)
                     if (t >= ((seg[k] - seg[0]) >> 2)) g = src[k] + (size_t)(t - ((seg[k] - seg[0]) >> 2)) * 16;
-                if (t < pieces) lds_dma_b128(g, smem + lo.gs + 4 * b);
+                const bool no_src = t >= ((seg[2] - seg[0]) >> 2) && t < ((seg[6] - seg[0]) >> 2);  // ay .. deliv slots: unpack_records
+                if (t < pieces && !no_src) lds_dma_b128(g, smem + lo.gs + 4 * b);
             }
         }
         // (rounding pieces at the tail of hw / dflag read a few bytes past the logical end of their source:
@@ -599,6 +654,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 ev[ENVI_DONE] = 0; ev[ENVI_QDIRTY] = 0;
                 if (rs) atomicOr(&s_misc[0], 1);
             }
+            unpack_records();
             lds_barrier();
         }
         if constexpr (kPos) {  // the shelf layer of the chunk from its positions: one byte store per shelf into the cleared block
@@ -611,11 +667,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     } else {
         dma_in(smem + lo.gs, reinterpret_cast<const int32_t *>(g_shadow + (size_t)e0 * HW),
                (ne * HW * (int)sizeof(CellT) + 3) >> 2, tid, T);
-        dma_in(s_ax, q_ax + (size_t)e0 * N, nea, tid, T);
-        dma_in(s_ay, q_ay + (size_t)e0 * N, nea, tid, T);
-        dma_in(s_dir, q_dir + (size_t)e0 * N, nea, tid, T);
-        dma_in(s_carry, q_carry + (size_t)e0 * N, nea, tid, T);
-        dma_in(s_deliv, q_deliv + (size_t)e0 * N, nea, tid, T);
+        dma_in(s_ax, reinterpret_cast<const int32_t *>(q_rec) + (size_t)e0 * N, nea, tid, T);  // packed records -> the `ax` slot
         dma_in(s_queue, q_queue + (size_t)e0 * Q, ne * Q, tid, T);
         if (op == OP_STEP) dma_in(s_act, la.actions + (size_t)e0 * N * AM, nea * AM, tid, T);
         if (kMsg) dma_in(s_msg, p.amsg + (size_t)e0 * N, nea, tid, T);
@@ -634,6 +686,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         }
         RW_MARK(TL_ENV_LOADED);
         __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
+        unpack_records();
+        lds_barrier();
     }
     keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
     RW_MARK(TL_LOADED);
@@ -755,6 +809,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // ---- own record, env flags and counters: from registers (kDirect, first step of the launch), else LDS read batch 1
         int ev_skip, ev_reset, ev_steps, ev_inact, x, y, d, carry, deliv, a_lds;
         if (kDirect && t == 0) {
+            if constexpr (!kEarly) unpack_own();  // (kEarly: done in front of the stage-in barrier)
             ev_skip = ev_reset = r_flag; ev_steps = r_steps; ev_inact = r_inact;
             x = r_x; y = r_y; d = r_d; carry = r_carry; deliv = r_deliv; a_lds = r_act;
         } else {
@@ -1158,8 +1213,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             const int e = rw_div18(i, mN);
             if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;
             const size_t gi = (size_t)e0 * N + i;
-            p.ax[gi] = s_ax[i]; p.ay[gi] = s_ay[i]; p.adir[gi] = s_dir[i];
-            p.acarry[gi] = 0; p.adeliv[gi] = 0;
+            q_rec[gi] = rec_pack(s_ay[i] * W + s_ax[i], s_dir[i], 0, 0);
             if (kMsg) { s_msg[i] = 0; p.amsg[gi] = 0; }  // fresh Agent objects: message = zeros (:89)
             rew_t[gi] = s_rew[i];
             if (!kImage) {
@@ -1227,16 +1281,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                     if (ev[ENVI_QDIRTY])
                         for (int k = 0; k < Q; ++k) p.queue[(size_t)ge * Q + k] = s_queue[e * Q + k];
                 }
-        } else if (role == 1) {  // agent SoA and rewards: the chunk is contiguous in every [B][N] array
+        } else if (role == 1) {  // agent records and rewards: the chunk is contiguous in both [B][N] arrays
             if (op == OP_STEP)
                 for (int i = lane; i < nea; i += 64) {
                     if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
                     const size_t gi = (size_t)e0 * N + i;
-                    p.ax[gi] = s_ax[i];
-                    p.ay[gi] = s_ay[i];
-                    p.adir[gi] = s_dir[i];
-                    p.acarry[gi] = s_carry[i];
-                    p.adeliv[gi] = s_deliv[i];
+                    q_rec[gi] = rec_pack(s_ay[i] * W + s_ax[i], s_dir[i], s_deliv[i], s_carry[i]);  // one store stream, not five
                     rew_t[gi] = s_rew[i];
                     if (kMsg) p.amsg[gi] = s_msg[i];
                 }
