@@ -19,6 +19,7 @@
 #include "../../include/rware_hip.h"
 #include "rware_kernel_table.h"
 #include "rware_kernels.h"
+#include "rware_static_table.h"
 
 namespace {
 
@@ -93,78 +94,18 @@ int fail(rw_engine *eng, int code, const char *fmt, ...) {
 
 using rw_tab::step_kernel_t;
 
-// Specialised builds for the BASELINE.json tasks at their default launch geometry:
-//   {H, W, N, Q, S, R}  ->  kernel with those shapes (and E, T) folded in at compile time.
-struct StaticEntry {
-    int H, W, N, Q, S, R, E, T;
-    int max_B;  // with the default geometry: chosen only for batches up to this size (0 = any); first match wins
-    int image;  // 1: IMAGE / IMAGE_DICT observations (any layer list), 0: FLATTENED
-    int M;      // communication bits the build was made for
-    int NL;     // IMAGE builds: > 0 = the layer list baked in (`layers`: 4 bits per id, first layer lowest) with `directional`
-    uint32_t layers;
-    int directional;
-    int pos;    // 1: POSITION state layout (rw::StaticCfg POS_), picked for batches of at least `min_B` envs
-    int min_B;
-    step_kernel_t fn, fn_rollout;
-};
-#define RW_STATIC(H, W, N, Q, S, R, E, T, MAXB)                                                                   \
-    {H, W, N, Q, S, R, E, T, MAXB, 0, 0, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true>}
-#define RW_STATIC_IMAGE(H, W, N, Q, S, R, E, T, MAXB)                                                             \
-    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false, rw::OBS_IMAGE>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true, rw::OBS_IMAGE>}
-// ... with the layer list and the directional switch baked in (the gather's per-layer selects fold away)
-#define RW_STATIC_IMAGE_LAYERS(H, W, N, Q, S, R, E, T, MAXB, NL, LAYERS, DIR)                                      \
-    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, NL, LAYERS, DIR, 0, 0,                                                     \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, false, rw::OBS_IMAGE>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, true, rw::OBS_IMAGE>}
-#define RW_STATIC_MSG(H, W, N, Q, S, R, E, T, MAXB, M)                                                            \
-    {H, W, N, Q, S, R, E, T, MAXB, 0, M, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, false, rw::OBS_FLATTENED_MSG>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, true, rw::OBS_FLATTENED_MSG>}
-// FLATTENED builds on the POSITION state layout, for batches of at least MINB envs (a step's traffic past the Infinity Cache)
-#define RW_STATIC_POS(H, W, N, Q, S, R, E, T, MINB)                                                                \
-    {H, W, N, Q, S, R, E, T, 0, 0, 0, 0, 0u, -1, 1, MINB,                                                           \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true>, false>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true>, true>}
-const StaticEntry kStatic[] = {
-    RW_STATIC_POS(20, 10, 4, 4, 80, 1, 16, 256, 196608),   // rware-small-4ag past the Infinity Cache (>= 224 MB of observations per step)
-    // half-size workgroups for batches that leave the CUs short of workgroups at E = 16 (measured, round 2:
-    // medium-6ag-hard B=8192 9.16 -> 7.98 us, B=4096 7.86 -> 6.71; B=16384 11.2 vs 13.1 the other way round)
-    RW_STATIC(20, 16, 6, 3, 144, 1, 8, 256, 8192),
-    RW_STATIC(11, 10, 2, 2, 32, 1, 16, 256, 0),    // rware-tiny-2ag
-    RW_STATIC(20, 10, 4, 4, 80, 1, 16, 256, 0),    // rware-small-4ag (headline)
-    // (small-4ag with 8 envs per workgroup: since the agent phases run in registers the 16-env build wins at every batch
-    //  size — B=1024 4.77 vs 4.81 us, 4096 5.35 vs 5.63, 16384 7.87 vs 10.3 — so this one only serves batches that are
-    //  a multiple of 8 but not of 16, or an explicit geometry)
-    RW_STATIC(20, 10, 4, 4, 80, 1, 8, 256, 0),
-    RW_STATIC(20, 16, 6, 3, 144, 1, 16, 256, 0),   // rware-medium-6ag-hard
-    RW_STATIC(29, 16, 16, 16, 224, 2, 8, 256, 0),  // rware-large-16ag, sensor_range = 2
-    // the other tasks of the RWARE benchmark suite (Papoudakis et al. 2021: tiny/small, 2-4 agents, normal/hard)
-    RW_STATIC(11, 10, 4, 4, 32, 1, 16, 256, 0),    // rware-tiny-4ag
-    RW_STATIC(11, 10, 2, 1, 32, 1, 16, 256, 0),    // rware-tiny-2ag-hard
-    RW_STATIC(11, 10, 4, 2, 32, 1, 16, 256, 0),    // rware-tiny-4ag-hard
-    RW_STATIC(20, 10, 4, 2, 80, 1, 16, 256, 0),    // rware-small-4ag-hard
-    // the "next" observation kinds callers hit first: IMAGE / IMAGE_DICT (any layer list, directional
-    // or not) and FLATTENED with 1 or 2 communication bits, on the two smallest BASELINE tasks
-    // (first the reference's default layer list — SHELVES, REQUESTS, AGENTS, GOALS, ACCESSIBLE, directional — baked in,
-    //  then the any-list builds)
-    RW_STATIC_IMAGE_LAYERS(20, 10, 4, 4, 80, 1, 16, 256, 0, 5, 0x65210u, 1),
-    RW_STATIC_IMAGE_LAYERS(11, 10, 2, 2, 32, 1, 16, 256, 0, 5, 0x65210u, 1),
-    RW_STATIC_IMAGE(20, 10, 4, 4, 80, 1, 16, 256, 0),
-    RW_STATIC_IMAGE(11, 10, 2, 2, 32, 1, 16, 256, 0),
-    RW_STATIC_MSG(20, 10, 4, 4, 80, 1, 16, 256, 0, 1),
-    RW_STATIC_MSG(20, 10, 4, 4, 80, 1, 16, 256, 0, 2),
-    RW_STATIC_MSG(11, 10, 2, 2, 32, 1, 16, 256, 0, 2),
-    // size-static builds (N == 0: any agent count / queue length): every other registered id, sensor_range 1
-    RW_STATIC(11, 10, 0, 0, 32, 1, 16, 256, 0),    // rware-tiny-*
-    RW_STATIC(20, 10, 0, 0, 80, 1, 16, 256, 0),    // rware-small-*
-    RW_STATIC(20, 16, 0, 0, 144, 1, 16, 256, 0),   // rware-medium-*
-    RW_STATIC(29, 16, 0, 0, 224, 1, 16, 256, 0),   // rware-large-*
-};
-#undef RW_STATIC
-#undef RW_STATIC_IMAGE
-#undef RW_STATIC_MSG
-#undef RW_STATIC_POS
+// The exact-shape and size-static kernel builds live in rware_static.hip, one translation unit per group of the table in
+// rware_static_table.h (they compile in parallel); rw_tab::static_group(g, &n) hands out group g's entries.
+using rw_tab::StaticEntry;
+}  // namespace
+namespace rw_tab {
+const StaticEntry *static_group(int group, int *n) {
+    using fn_t = const StaticEntry *(*)(int *);
+    static const fn_t kGroups[kStaticGroups] = {static_group_0, static_group_1, static_group_2, static_group_3, static_group_4, static_group_5};
+    return kGroups[group](n);
+}
+}  // namespace rw_tab
+namespace {
 
 int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     la.op = op | (la.timeline ? rw::OP_FLAG_TIMELINE : 0);
@@ -452,7 +393,11 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         const bool geom_default = cfg->envs_per_workgroup == 0 && cfg->threads_per_workgroup == 0;
         const StaticEntry *best = nullptr;
         for (int exact = 1; exact >= 0 && !best; --exact)
-            for (const StaticEntry &se : kStatic) {
+            for (int grp = 0; grp < rw_tab::kStaticGroups && !best; ++grp) {
+            int n_se = 0;
+            const StaticEntry *tab = rw_tab::static_group(grp, &n_se);
+            for (int k_se = 0; k_se < n_se; ++k_se) {
+                const StaticEntry &se = tab[k_se];
                 if ((se.N != 0) != (exact != 0)) continue;
                 if (se.image != (eng->image ? 1 : 0) || se.M != eng->msg_bits) continue;
                 if (se.pos) {  // RWARE_STATE_LAYOUT=pos|shadow overrides the batch-size rule (test hook)
@@ -468,6 +413,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
                 const bool shape = se.H == H && se.W == W && se.S == S && se.R == R && (se.N == 0 || (se.N == N && se.Q == Q));
                 if (!shape || B % se.E != 0) continue;
                 if (geom_default ? (se.max_B == 0 || B <= se.max_B) : (E == se.E && T == se.T)) { best = &se; break; }
+            }
             }
         if (best) {
             E = best->E;

@@ -1,0 +1,127 @@
+// rware_static_table.h — the specialised kernel builds (rw::StaticCfg): which shapes get a build of their own.
+//
+//   {H, W, N, Q, S, R}  ->  kernel with those shapes (and the launch geometry E, T) folded in at compile time.
+//
+// The table is cut into groups; rware_static.hip is compiled once per group (-DRW_STATIC_GROUP=g, see the Makefile) so
+// the ~100 kernel instantiations build in parallel.  rware_capi.hip walks the groups in order, exact-shape entries
+// (N != 0) before size-static ones (N == 0), first match wins — so WITHIN the exact-shape entries order matters only
+// between entries of the same shape (geometry / batch-size variants): keep those in one group, most specific first.
+#pragma once
+#include "rware_kernel_table.h"
+
+namespace rw_tab {
+
+struct StaticEntry {
+    int H, W, N, Q, S, R, E, T;
+    int max_B;  // with the default geometry: chosen only for batches up to this size (0 = any); first match wins
+    int image;  // 1: IMAGE / IMAGE_DICT observations (any layer list), 0: FLATTENED
+    int M;      // communication bits the build was made for
+    int NL;     // IMAGE builds: > 0 = the layer list baked in (`layers`: 4 bits per id, first layer lowest) with `directional`
+    uint32_t layers;
+    int directional;
+    int pos;    // 1: POSITION state layout (rw::StaticCfg POS_), picked for batches of at least `min_B` envs
+    int min_B;
+    step_kernel_t fn, fn_rollout;
+};
+
+enum : int { kStaticGroups = 6 };
+const StaticEntry *static_group(int group, int *n);   // rware_capi.hip's view: dispatches to the per-group tables below
+const StaticEntry *static_group_0(int *n);
+const StaticEntry *static_group_1(int *n);
+const StaticEntry *static_group_2(int *n);
+const StaticEntry *static_group_3(int *n);
+const StaticEntry *static_group_4(int *n);
+const StaticEntry *static_group_5(int *n);
+
+}  // namespace rw_tab
+
+#ifdef RW_STATIC_GROUP  // ------------------------------------------------------------ only inside rware_static.hip
+namespace rw_tab {
+namespace {
+#define RW_STATIC(H, W, N, Q, S, R, E, T, MAXB)                                                                   \
+    {H, W, N, Q, S, R, E, T, MAXB, 0, 0, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true>}
+#define RW_STATIC_IMAGE(H, W, N, Q, S, R, E, T, MAXB)                                                             \
+    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false, rw::OBS_IMAGE>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true, rw::OBS_IMAGE>}
+// ... with the layer list and the directional switch baked in (the gather's per-layer selects fold away)
+#define RW_STATIC_IMAGE_LAYERS(H, W, N, Q, S, R, E, T, MAXB, NL, LAYERS, DIR)                                      \
+    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, NL, LAYERS, DIR, 0, 0,                                                     \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, false, rw::OBS_IMAGE>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, true, rw::OBS_IMAGE>}
+#define RW_STATIC_MSG(H, W, N, Q, S, R, E, T, MAXB, M)                                                            \
+    {H, W, N, Q, S, R, E, T, MAXB, 0, M, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, false, rw::OBS_FLATTENED_MSG>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, true, rw::OBS_FLATTENED_MSG>}
+// FLATTENED builds on the POSITION state layout, for batches of at least MINB envs (a step's traffic past the Infinity Cache)
+#define RW_STATIC_POS(H, W, N, Q, S, R, E, T, MINB)                                                                \
+    {H, W, N, Q, S, R, E, T, 0, 0, 0, 0, 0u, -1, 1, MINB,                                                           \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true>, false>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true>, true>}
+// the three registered warehouse sizes of the RWARE papers (rware/__init__.py:7-12): grid, shelves
+#define RW_TINY(N, Q) RW_STATIC(11, 10, N, Q, 32, 1, 16, 256, 0)
+#define RW_SMALL(N, Q) RW_STATIC(20, 10, N, Q, 80, 1, 16, 256, 0)
+#define RW_MEDIUM(N, Q) RW_STATIC(20, 16, N, Q, 144, 1, 16, 256, 0)
+
+const StaticEntry kEntries[] = {
+#if RW_STATIC_GROUP == 0
+    // ---- the BASELINE.json tasks (+ their batch-size / geometry variants)
+    RW_STATIC_POS(20, 10, 4, 4, 80, 1, 16, 256, 196608),   // rware-small-4ag past the Infinity Cache (>= 224 MB of observations per step)
+    // half-size workgroups for batches that leave the CUs short of workgroups at E = 16 (measured, round 2:
+    // medium-6ag-hard B=8192 9.16 -> 7.98 us, B=4096 7.86 -> 6.71; B=16384 11.2 vs 13.1 the other way round)
+    RW_STATIC(20, 16, 6, 3, 144, 1, 8, 256, 8192),
+    RW_STATIC(11, 10, 2, 2, 32, 1, 16, 256, 0),    // rware-tiny-2ag
+    RW_STATIC(20, 10, 4, 4, 80, 1, 16, 256, 0),    // rware-small-4ag (headline)
+    // (small-4ag with 8 envs per workgroup: since the agent phases run in registers the 16-env build wins at every batch
+    //  size — B=1024 4.77 vs 4.81 us, 4096 5.35 vs 5.63, 16384 7.87 vs 10.3 — so this one only serves batches that are
+    //  a multiple of 8 but not of 16, or an explicit geometry)
+    RW_STATIC(20, 10, 4, 4, 80, 1, 8, 256, 0),
+    RW_STATIC(20, 16, 6, 3, 144, 1, 16, 256, 0),   // rware-medium-6ag-hard
+    RW_STATIC(29, 16, 16, 16, 224, 2, 8, 256, 0),  // rware-large-16ag, sensor_range = 2
+#elif RW_STATIC_GROUP == 1
+    // ---- the "next" observation kinds callers hit first: IMAGE / IMAGE_DICT (any layer list, directional
+    // or not) and FLATTENED with 1 or 2 communication bits, on the two smallest BASELINE tasks
+    // (first the reference's default layer list — SHELVES, REQUESTS, AGENTS, GOALS, ACCESSIBLE, directional — baked in,
+    //  then the any-list builds)
+    RW_STATIC_IMAGE_LAYERS(20, 10, 4, 4, 80, 1, 16, 256, 0, 5, 0x65210u, 1),
+    RW_STATIC_IMAGE_LAYERS(11, 10, 2, 2, 32, 1, 16, 256, 0, 5, 0x65210u, 1),
+    RW_STATIC_IMAGE(20, 10, 4, 4, 80, 1, 16, 256, 0),
+    RW_STATIC_IMAGE(11, 10, 2, 2, 32, 1, 16, 256, 0),
+    RW_STATIC_MSG(20, 10, 4, 4, 80, 1, 16, 256, 0, 1),
+    RW_STATIC_MSG(20, 10, 4, 4, 80, 1, 16, 256, 0, 2),
+    RW_STATIC_MSG(11, 10, 2, 2, 32, 1, 16, 256, 0, 2),
+#elif RW_STATIC_GROUP == 2
+    // ---- the task grid of the RWARE benchmark papers (Papoudakis et al. 2021; Christianos et al. 2020): tiny / small /
+    // medium x 2, 4, 6, 8 agents x easy / normal / hard.  request_queue_size = int(n_agents * {2, 1, 0.5})
+    // (rware/__init__.py:14-21).  Shapes already listed in group 0 are not repeated.
+    RW_TINY(2, 4), RW_TINY(4, 8), RW_TINY(6, 12), RW_TINY(8, 16),          // -easy
+    RW_TINY(4, 4), RW_TINY(6, 6), RW_TINY(8, 8),                           // normal (tiny-2ag: group 0)
+    RW_TINY(2, 1), RW_TINY(4, 2), RW_TINY(6, 3), RW_TINY(8, 4),            // -hard
+#elif RW_STATIC_GROUP == 3
+    RW_SMALL(2, 4), RW_SMALL(4, 8), RW_SMALL(6, 12), RW_SMALL(8, 16),      // -easy
+    RW_SMALL(2, 2), RW_SMALL(6, 6), RW_SMALL(8, 8),                        // normal (small-4ag: group 0)
+    RW_SMALL(2, 1), RW_SMALL(4, 2), RW_SMALL(6, 3), RW_SMALL(8, 4),        // -hard
+#elif RW_STATIC_GROUP == 4
+    RW_MEDIUM(2, 4), RW_MEDIUM(4, 8), RW_MEDIUM(6, 12), RW_MEDIUM(8, 16),  // -easy
+    RW_MEDIUM(2, 2), RW_MEDIUM(4, 4), RW_MEDIUM(6, 6), RW_MEDIUM(8, 8),    // normal
+    RW_MEDIUM(2, 1), RW_MEDIUM(4, 2), RW_MEDIUM(8, 4),                     // -hard (medium-6ag-hard: group 0)
+#elif RW_STATIC_GROUP == 5
+    // ---- size-static builds (N == 0: any agent count / queue length): every other registered id, sensor_range 1
+    RW_STATIC(11, 10, 0, 0, 32, 1, 16, 256, 0),    // rware-tiny-*
+    RW_STATIC(20, 10, 0, 0, 80, 1, 16, 256, 0),    // rware-small-*
+    RW_STATIC(20, 16, 0, 0, 144, 1, 16, 256, 0),   // rware-medium-*
+    RW_STATIC(29, 16, 0, 0, 224, 1, 16, 256, 0),   // rware-large-*
+#else
+#error "RW_STATIC_GROUP out of range"
+#endif
+};
+#undef RW_STATIC
+#undef RW_STATIC_IMAGE
+#undef RW_STATIC_IMAGE_LAYERS
+#undef RW_STATIC_MSG
+#undef RW_STATIC_POS
+#undef RW_TINY
+#undef RW_SMALL
+#undef RW_MEDIUM
+}  // namespace
+}  // namespace rw_tab
+#endif  // RW_STATIC_GROUP

@@ -639,3 +639,30 @@ def test_coordinate_writes_mark_the_derived_grid_stale_and_truncated_is_read_onl
         env.engines[0].write("truncated", np.ones(4, np.uint8))
     assert not env.engines[0].read("truncated").any()
     env.close()
+
+
+@pytest.mark.parametrize("env_id", [
+    "rware-tiny-8ag-v1", "rware-tiny-6ag-easy-v1", "rware-small-2ag-hard-v1", "rware-small-8ag-easy-v1",
+    "rware-medium-4ag-v1", "rware-medium-8ag-hard-v1",
+])
+def test_paper_task_grid_runs_exact_shape_builds(env_id):
+    """tiny / small / medium x 2, 4, 6, 8 agents x easy / normal / hard each have an exact-shape build (rware_static_table.h):
+    a sample of them against the oracle across an autoreset (N = 8: exact-shape build with the LDS exchange)."""
+    kw = rware_amd.env_kwargs(env_id)
+    kw["max_steps"] = 18
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    B = 16
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, **kw)
+    assert env.engines[0].info.specialised == 1 and env.engines[0].info.envs_per_workgroup == 16
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=4)[0], orc.reset(seed=4))
+    rng = np.random.default_rng(6)
+    for t in range(30):
+        a = rng.choice(5, size=(B, kw["n_agents"]), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    env.close()

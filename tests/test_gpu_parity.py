@@ -773,3 +773,35 @@ def test_bench_driver_invocation_carries_every_leg():
     assert c["cores"] >= 1 and c["port"]["aggregate"] > 0
     if os.path.isfile(os.path.join(root, "oracle", "_ref", "rware", "warehouse.py")):
         assert c["kind"] == "reference" and c["value"] > 0 and "oracle/_ref" in c["reference_root"], c
+
+
+PAPER_GRID = [f"rware-{size}-{n}ag{diff}-v1" for size in ("tiny", "small", "medium") for n in (2, 4, 6, 8) for diff in ("-easy", "", "-hard")]
+
+
+@pytest.mark.parametrize("env_id", PAPER_GRID)
+def test_paper_task_grid_exact_shape_builds_match_oracle(env_id):
+    """Every task of the RWARE papers' grid (tiny / small / medium x 2, 4, 6, 8 agents x easy / normal / hard) runs an exact-shape
+    kernel build; each against the oracle on every env, per-step launches and a fused rollout, across autoresets."""
+    kw = rware_amd.env_kwargs(env_id)
+    kw["max_steps"] = 50
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    B, N = 512, kw["n_agents"]
+    env = rware_amd.WarehouseVecEnv(B, **kw)
+    assert env.engines[0].info.specialised == 1
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=31)[0], orc.reset(seed=31))
+    rng = np.random.default_rng(8)
+    for t in range(70):
+        a = rng.choice(5, size=(B, N), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+    acts = rng.choice(5, size=(40, B, N), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+    obs, rew, term = env.rollout(acts)
+    for k in range(40):
+        o2, r2, d2 = orc.step_autoreset(acts[k], "next_step")
+        assert np.array_equal(obs[k], o2) and np.array_equal(rew[k], r2) and np.array_equal(term[k], d2.astype(bool)), k
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    env.close()
