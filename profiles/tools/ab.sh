@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of library builds (run on the GPU box from the repo root, through gpurun):
-#   build the variants in the build container first:  mkdir -p ab; (build) ; cp robotic-warehouse_amd/csrc/librware_hip.so ab/<name>.so
-#   (ab/ is git-ignored but travels with the gpurun snapshot), then
+#   build the variants in the build container first:  mkdir -p scratch/ab; (build) ; cp robotic-warehouse_amd/csrc/librware_hip.so scratch/ab/<name>.so
+#   (scratch/ is git-ignored but travels with the gpurun snapshot), then
 #   gpurun -- 'bash profiles/tools/ab.sh "base variant" 16384:0:0:6000 262144:0:0:300'
 # Each spec is <batch>:<envs per workgroup>:<threads per workgroup>:<steps> (0:0 = the engine's own geometry); optional
 # extra bench.py arguments in AB_ARGS (e.g. AB_ARGS="--observation-type 2").  Every variant runs twice, alternating, so a
@@ -9,7 +9,7 @@
 VARS=$1; shift
 for r in 1 2; do
   for v in $VARS; do
-    cp ab/$v.so robotic-warehouse_amd/csrc/librware_hip.so
+    cp ${AB_DIR:-scratch/ab}/$v.so robotic-warehouse_amd/csrc/librware_hip.so
     echo -n "$v: "
     for spec in "$@"; do
       IFS=':' read -r b e t n <<< "$spec"

@@ -1,6 +1,6 @@
-# helper (git-ignored): is a cache-exceeding batch faster as two half-batch engines stepped one after the other?
+# helper: is a cache-exceeding batch faster as two half-batch engines stepped one after the other, or on streams of their own?
 import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, '.')
 import rware_amd
 kw = rware_amd.env_kwargs("rware-small-4ag-v1")
 TAPE = 16
