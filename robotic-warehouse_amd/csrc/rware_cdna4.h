@@ -93,6 +93,10 @@ __device__ __forceinline__ int env_or(int v, int lane_base) {
     } else if constexpr (N == 4) {
         v |= quad_perm<1, 0, 3, 2>(v);
         return v | quad_perm<2, 3, 0, 1>(v);
+    } else if constexpr (N == 8) {  // an env is half a DPP row: the two quads meet through row_half_mirror (lane i <-> 7 - i)
+        v |= quad_perm<1, 0, 3, 2>(v);
+        v |= quad_perm<2, 3, 0, 1>(v);
+        return v | __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);
     } else {
         int g[N], r = 0;
         env_gather<N>(v, lane_base, g);

@@ -56,6 +56,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include <rware_cdna4.h>
 
 #include "rware_pcg64.h"
@@ -392,7 +394,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int S = Cfg::kS ? Cfg::kS : p.S, SW = (S + 32) / 32, B = p.B;
     const int nea = ne * N;
     // agent phases with cross-lane exchange in registers (see AG); kDirect: own record fetched straight into registers
-    constexpr bool kRegAG = Cfg::kN >= 1 && Cfg::kN <= 6;  // (N + 2 link codes must fit 3 bits)
+    constexpr bool kRegAG = Cfg::kN >= 1 && Cfg::kN <= 12;  // (the chain links of an env as one word: 4 bits x 6 agents, or 5 bits x 12 in 64)
     constexpr bool kDirect = kRegAG && Cfg::kE != 0 && (!kMsg || (Cfg::kM >= 1 && Cfg::kM <= 4));  // (message words: one register each)
     // ONE scalar batch, first thing in the kernel, for every field of the parameter block that the stage-in and the agent
     // phases read: left to itself hipcc fetches each field where it is first used — three dependent scalar-cache round
@@ -912,18 +914,32 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // ------------------------------------------------------------ P2c: commit (:871-876)
         int commit = (nxt == -1) ? (lose ^ 1) : ((nxt == -2) ? 1 : 0);
         if (chains) {  // walk the chain ahead: i -> nxt(i) -> ... on the gathered links
-            // every agent's (nxt + 2 | win << 3) as one nibble of a word every lane of the env holds: following a link is
-            // a shift and a mask (a register array indexed by a run-time agent index would live in scratch memory)
-            const uint32_t links = (uint32_t)env_or<KN>(((nxt + 2) | ((lose ^ 1) << 3)) << (4 * a_idx), lane_base);
+            // every agent's (nxt + 2 | win << LB) as one field of a word every lane of the env holds: following a link is
+            // a shift and a mask (a register array indexed by a run-time agent index would live in scratch memory).
+            // N <= 6: 3 + 1 bits per agent in 32 bits; 7 <= N <= 12: 4 + 1 bits per agent in 64 bits (two OR-reductions).
+            constexpr int LB = KN <= 6 ? 3 : 4, FW = LB + 1;
+            constexpr uint32_t LM = (1u << LB) - 1u;
+            using links_t = typename std::conditional<KN <= 6, uint32_t, uint64_t>::type;
+            links_t links;
+            {
+                const links_t own = (links_t)(uint32_t)((nxt + 2) | ((lose ^ 1) << LB)) << (FW * a_idx);
+                if constexpr (KN <= 6) {
+                    links = (links_t)(uint32_t)env_or<KN>((int)(uint32_t)own, lane_base);
+                } else {
+                    const uint32_t lo = (uint32_t)env_or<KN>((int)(uint32_t)own, lane_base);
+                    const uint32_t hi = (uint32_t)env_or<KN>((int)(uint32_t)((uint64_t)own >> 32), lane_base);
+                    links = (links_t)(((uint64_t)hi << 32) | lo);
+                }
+            }
             int j = a_idx, hops = 0, ok = 1, cm = 0;
             bool done = nxt < 0;
 #pragma unroll
             for (int h = 0; h < KN; ++h) {
-                const uint32_t ent = (links >> (4 * j)) & 0xFu;
-                const int nj = (int)(ent & 7u) - 2;
-                ok &= (int)(ent >> 3);
+                const uint32_t ent = (uint32_t)(links >> (FW * j)) & ((1u << FW) - 1u);
+                const int nj = (int)(ent & LM) - 2;
+                ok &= (int)(ent >> LB);
                 ++hops;
-                const int nnj = (int)((links >> (4 * (nj & 7))) & 7u) - 2;  // nxt of the successor (not used when nj < 0)
+                const int nnj = (int)((uint32_t)(links >> (FW * (nj & (KN <= 6 ? 7 : (nj < 0 ? 0 : 15))))) & LM) - 2;  // nxt of the successor (not used when nj < 0)
                 const bool to_empty = nj == -1;                     // drains into an empty cell
                 const bool back = nj == a_idx;                      // a cycle through me; the 2-swap is refused
                 const bool stuck = (nj >= 0) & (nnj == -2);         // blocked by a stationary agent

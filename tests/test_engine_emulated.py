@@ -96,6 +96,8 @@ def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
     ("large-16ag-sr2", (0, 0), 4),     # exact-shape build with the LDS exchange (N = 16)
     ("img-small-4ag-directional", (0, 0), 16),   # exact-shape IMAGE build
     ("msg2-small-4ag", (0, 0), 16),              # exact-shape build with 2 communication bits
+    ("small-8ag-global-inact", (0, 0), 16),      # N = 8 in registers: 64-bit chain links (round 3)
+    ("tiny-4ag-easy-twostage", (0, 0), 16),      # Q > N: two queue slots per agent lane
 ])
 def test_emulated_exact_shape_builds_match_reference_golden(name, geom, tile):
     """The golden traces of the unmodified reference, replayed on the EXACT-SHAPE kernel builds (the ones the BASELINE

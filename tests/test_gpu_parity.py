@@ -35,6 +35,8 @@ def test_engine_matches_reference_golden(name):
     ("small-4ag", (0, 0), 4), ("small-4ag", (0, 0), 2), ("small-4ag", (8, 256), 4), ("tiny-2ag", (0, 0), 4), ("medium-6ag-hard", (0, 0), 8),
     ("medium-6ag-hard", (16, 256), 16), ("large-16ag-sr2", (0, 0), 4),
     ("img-small-4ag-directional", (0, 0), 16), ("msg2-small-4ag", (0, 0), 16),
+    # round 3: N = 8 in registers (ds_bpermute gathers, 64-bit chain links, row_half_mirror OR); Q > N (two queue slots per lane)
+    ("small-8ag-global-inact", (0, 0), 16), ("tiny-4ag-easy-twostage", (0, 0), 16),
 ])
 def test_exact_shape_builds_match_reference_golden(name, geom, tile):
     """The golden traces of the unmodified reference on the EXACT-SHAPE kernel builds (what the BASELINE configs run):
