@@ -26,6 +26,7 @@ CONFIGS=(
   "image_small4_B16384|256|6000|--observation-type 2"
   "image_tiny2_B4096|256|6000|--env-id rware-tiny-2ag-v1 --batch 4096 --observation-type 2"
   "msg2_small4_B16384|256|6000|--msg-bits 2"
+  "small8_B16384|256|6000|--env-id rware-small-8ag-v1"
   "fused64_small4_B16384|256|1024|--many 64"
 )
 cd /tmp
