@@ -89,14 +89,18 @@ enum rw_buffer_kind {
                                                    types, [B][N][C][2r+1][2r+1] (:527-596)        */
     RW_BUF_REWARDS = 1,      /* float32 [B][N]                                                    */
     RW_BUF_TERMINATED = 2,   /* uint8   [B]        `done` (:935-941)                              */
-    RW_BUF_TRUNCATED = 3,    /* uint8   [B]        always 0 (:942)                                */
+    RW_BUF_TRUNCATED = 3,    /* uint8   [B]        always 0 (:942); read-only (rw_write refuses it) */
     RW_BUF_GRID = 4,         /* int32   [B][2][H][W] layer 0 agent ids, layer 1 shelf ids (:11-14).
                                                    A DERIVED VIEW: rebuilt from the state the kernels keep (shelf
                                                    layer, agent coordinates) by rw_read / rw_get_buffer of this kind
                                                    and by rw_refresh_grid — steps enqueued after that do not touch
                                                    it (every other buffer is current after every step)           */
-    RW_BUF_AGENT_X = 5,      /* int32   [B][N]                                                    */
-    RW_BUF_AGENT_Y = 6,      /* int32   [B][N]                                                    */
+    /* The five agent arrays are DERIVED VIEWS as well (round 3): the kernels keep an agent as ONE packed dword
+     * (cell, dir, has_delivered, carried shelf) — one load stream and one store stream per step instead of five each.
+     * rw_read / rw_get_buffer of these kinds unpack the records first (call rw_get_buffer again to bring a pointer
+     * borrowed earlier up to date: it is stable); rw_write of one of them re-packs all five.                       */
+    RW_BUF_AGENT_X = 5,      /* int32   [B][N]     Agent.x (:86)                                  */
+    RW_BUF_AGENT_Y = 6,      /* int32   [B][N]     Agent.y                                        */
     RW_BUF_AGENT_DIR = 7,    /* int32   [B][N]     rw_direction                                   */
     RW_BUF_AGENT_CARRY = 8,  /* int32   [B][N]     carried shelf id, 0 == none                    */
     RW_BUF_AGENT_DELIVERED = 9, /* int32 [B][N]    has_delivered                                  */
@@ -200,7 +204,8 @@ int rw_copy_to_device(rw_engine *eng, void *dev_dst, const void *host_src, size_
 int rw_copy_to_host(rw_engine *eng, void *host_dst, const void *dev_src, size_t bytes);
 
 /* bring RW_BUF_GRID up to date with the steps enqueued so far (two small kernels on the engine's stream; a no-op when
- * nothing ran since the last refresh).  For callers that hold a borrowed pointer / a zero-copy tensor of the grid. */
+ * nothing ran since the last refresh).  For callers that hold a borrowed pointer / a zero-copy tensor of the grid.
+ * (The agent views: rw_get_buffer(kind) again — same pointer, refreshed.) */
 int rw_refresh_grid(rw_engine *eng);
 
 /* recompute RW_BUF_OBS from the current state (after rw_write of state buffers) */
@@ -221,8 +226,8 @@ int rw_write(rw_engine *eng, int kind, const void *host_src, size_t bytes);
 int rw_recalc_grid(rw_engine *eng, const int32_t *shelf_xy, int32_t n_shelves);
 
 /* -- snapshot / restore (checkpointing the batched env state) ------------ */
-/* A snapshot is a device-resident copy of everything reset()/step() evolve: grid, shelf shadow, agent
- * SoA, queue, counters, PCG64 streams, pending-autoreset flags.  Saving and restoring are device-to-
+/* A snapshot is a device-resident copy of everything reset()/step() evolve: shelf layer, packed agent
+ * records, queue, counters, PCG64 streams, pending-autoreset flags (the int32 views are derived from these).  Saving and restoring are device-to-
  * device copies on the engine's stream (tens of microseconds); restore also refreshes RW_BUF_OBS, so
  * the engine continues bit-identically from the saved point. */
 typedef struct rw_snapshot rw_snapshot;

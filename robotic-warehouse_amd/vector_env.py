@@ -475,8 +475,9 @@ class WarehouseVecEnv(_VectorEnvBase):
                 eng.refresh_obs()
 
     def refresh_grid(self):
-        """`grid` is a derived view (rebuilt from the shelf layer and the agent coordinates the kernels keep): get_state()
-        and a fresh device_tensor("grid") are always current; call this to update a grid tensor obtained earlier."""
+        """`grid` and the five `agent_*` arrays are derived views (rebuilt from the shelf layer and the packed agent records
+        the kernels keep): get_state() and a fresh device_tensor(name) are always current; call this to update a grid
+        tensor obtained earlier (an agent_* tensor: device_tensor(name) again — same memory, refreshed)."""
         for eng in self.engines:
             eng.refresh_grid()
 

@@ -668,3 +668,47 @@ def test_paper_task_grid_runs_exact_shape_builds(env_id):
     for k in so:
         assert np.array_equal(st[k], so[k]), k
     env.close()
+
+
+def test_agent_arrays_are_derived_views_of_the_packed_records():
+    """RW_BUF_AGENT_X .. _DELIVERED are unpacked from the packed agent records when asked for: a pointer borrowed earlier lags
+    behind later steps until rw_get_buffer is called again (same pointer, refreshed); a host write of ONE view keeps the
+    other four (the records are re-packed from all five)."""
+    import ctypes as C
+    kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
+    kw["reward_type"] = 1
+    B = 4
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **kw)
+    orc = OracleVecEnv(B, **kw)
+    env.reset(seed=3)
+    orc.reset(seed=3)
+    eng = env.engines[0]
+    da = eng.device_array("agent_x")                               # borrowed pointer (host memory in the emulation)
+    view = np.ctypeslib.as_array((C.c_int32 * int(np.prod(da.shape))).from_address(da.ptr)).reshape(da.shape)
+    assert np.array_equal(view, orc.get_state()["agent_x"])
+    rng = np.random.default_rng(0)
+    before = view.copy()
+    for t in range(12):
+        a = rng.choice(5, size=(B, 2), p=[0.1, 0.6, 0.1, 0.1, 0.1]).astype(np.int32)
+        env.step(a)
+        orc.step_autoreset(a, "next_step")
+    so = orc.get_state()
+    assert not np.array_equal(so["agent_x"], before), "nothing moved: the test needs a different seed"
+    assert np.array_equal(view, before)                            # the steps did not touch the exported array
+    assert eng.device_array("agent_x").ptr == da.ptr               # same buffer ...
+    assert np.array_equal(view, so["agent_x"])                     # ... now current
+    # write one view: the other four survive, and the engine continues from the injected state
+    st = env.get_state()
+    new_dir = (st["agent_dir"] + 1) % 4
+    env.set_state(agent_dir=new_dir)
+    orc.set_state(agent_dir=new_dir)
+    st2 = env.get_state()
+    for k in ("agent_x", "agent_y", "agent_carry", "agent_delivered"):
+        assert np.array_equal(st2[k], st[k]), k
+    assert np.array_equal(st2["agent_dir"], new_dir)
+    for t in range(6):
+        a = rng.integers(0, 5, size=(B, 2), dtype=np.int32)
+        obs, _, _, _, _ = env.step(a)
+        o2, _, _ = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(obs, o2), t
+    env.close()
