@@ -49,6 +49,27 @@ def host_cores() -> int:
         return max(1, os.cpu_count() or 1)
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 `cpu.max` / v1 `cpu.cfs_quota_us`), or None when
+    unlimited / unreadable.  The GPU box reports 256 schedulable CPUs, yet 256 single-threaded processes ran only ~16x as
+    fast as one (round 3: both the C port and the Python reference) — a quota is the usual reason; it is reported so the
+    aggregate is not read as a 256-core figure."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 # ------------------------------------------------------------------------------------------ process fan-out
 def _fan_out(worker, args, procs, seconds):
     """Runs `worker(*args, seed, queue, (ready_semaphore, go_event))` in `procs` forked processes; each reports (agent_steps, seconds)."""
@@ -151,7 +172,7 @@ def measure(env_id: str, port_seconds: float = 5.0, ref_seconds: float = 6.0) ->
     port_1 = time_port(env_id, port_seconds, 1)
     port_p = time_port(env_id, port_seconds, P) if P > 1 else port_1
     out = {
-        "unit": "agent-steps/s", "cores": P, "cpu_model": model,
+        "unit": "agent-steps/s", "cores": P, "cpu_model": model, "cpu_quota_cores": cpu_quota(),
         "port": {"single": port_1, "aggregate": port_p, "processes": P,
                  "what": "oracle/rware_oracle.c (C restatement of Warehouse.step + FLATTENED obs), 512 envs per process"},
     }
@@ -160,7 +181,7 @@ def measure(env_id: str, port_seconds: float = 5.0, ref_seconds: float = 6.0) ->
         ref_p, _ = time_reference(env_id, ref_seconds, P) if P > 1 else (ref_1, standin)
         import ref_runner as rr
 
-        out.update(kind="reference", value=ref_p, single=ref_1, aggregate=ref_p, processes=P,
+        out.update(kind="reference", value=ref_p, single=ref_1, aggregate=ref_p, processes=P, parallel_speedup=ref_p / ref_1,
                    reference_root=("oracle/_ref (staged by oracle/make_ref.sh)" if rr.REFERENCE_ROOT == rr.STAGED_ROOT else rr.REFERENCE_ROOT),
                    sample=f"{env_id}: unmodified rware.warehouse.Warehouse.step (pure Python + networkx), one env per process, "
                           f"uniform random actions, reset on done, ~{ref_seconds:.0f} s with 1 process and ~{ref_seconds:.0f} s with "
