@@ -13,25 +13,74 @@ from .enums import RewardType
 _SIZES = {"tiny": (1, 3), "small": (2, 3), "medium": (2, 5), "large": (3, 5)}  # (shelf_rows, shelf_columns)
 _DIFFICULTY = {"-easy": 2, "": 1, "-hard": 0.5}
 _ID = re.compile(r"^rware-(tiny|small|medium|large)-(\d+)ag(-easy|-hard)?-v([12])$")
+# the opt-in registries of the reference: image_registration() (rware/__init__.py:42-80) and full_registration() (:83-175)
+_OBS = r"(-img|-imgdict)?(-Nd)?"
+_ID_IMAGE = re.compile(rf"^rware{_OBS}-(tiny|small|medium|large)-(\d+)ag(-easy|-hard)?-v([12])$")
+_ID_FULL_SIZE = re.compile(rf"^rware{_OBS}(-[2-5]s)?-(tiny|small|medium|large)-(\d+)h-(\d+)ag(-easy|-hard)?-v([12])$")
+_ID_FULL_GRID = re.compile(rf"^rware{_OBS}(-[2-5]s)?-(\d+)x(\d+)-(\d+)h-(\d+)ag-(\d+)req-(indiv|global|twostage)-v([12])$")
+_REWARDS = {"indiv": RewardType.INDIVIDUAL, "global": RewardType.GLOBAL, "twostage": RewardType.TWO_STAGE}
+
+
+def _base(rows, cols, height, agents, queue, sensor_range=1, reward=RewardType.INDIVIDUAL):
+    return {
+        "column_height": height, "shelf_rows": rows, "shelf_columns": cols, "n_agents": agents, "msg_bits": 0,
+        "sensor_range": sensor_range, "request_queue_size": queue, "max_inactivity_steps": None, "max_steps": 500,
+        "reward_type": reward,
+    }
+
+
+def _obs_kwargs(obs, nd, allow_imgdict, allow_bare_nd=False):
+    """`-img` / `-imgdict` / `-Nd` id parts -> observation kwargs, with the reference's own restrictions."""
+    from .enums import ObservationType
+
+    if nd and not obs:
+        if allow_bare_nd:  # the rows x cols loop of full_registration() has no such filter (:143-175): the id exists, FLATTENED
+            return {"image_observation_directional": False}
+        raise KeyError("-Nd ids exist only with image observations")  # (:59-61, :108-110)
+    if obs == "-imgdict" and not allow_imgdict:
+        raise KeyError("full_registration() has no -imgdict ids")     # (:84)
+    if not obs:
+        return {}
+    return {"observation_type": ObservationType.IMAGE if obs == "-img" else ObservationType.IMAGE_DICT,
+            "image_observation_directional": not nd}
 
 
 def env_kwargs(env_id: str) -> dict:
+    """Constructor kwargs of a reference id: the 228 ids registered at import (rware/__init__.py:22-39) and every id
+    `image_registration()` / `full_registration()` would add — same grammar, same kwargs, `-v1` and `-v2`."""
     m = _ID.match(env_id)
-    if not m or not (1 <= int(m.group(2)) <= 19):
-        raise KeyError(f"unknown rware id {env_id!r}")
-    size, agents, diff = m.group(1), int(m.group(2)), m.group(3) or ""
-    return {
-        "column_height": 8,
-        "shelf_rows": _SIZES[size][0],
-        "shelf_columns": _SIZES[size][1],
-        "n_agents": agents,
-        "msg_bits": 0,
-        "sensor_range": 1,
-        "request_queue_size": int(agents * _DIFFICULTY[diff]),
-        "max_inactivity_steps": None,
-        "max_steps": 500,
-        "reward_type": RewardType.INDIVIDUAL,
-    }
+    if m:
+        if not 1 <= int(m.group(2)) <= 19:
+            raise KeyError(f"unknown rware id {env_id!r}")
+        size, agents, diff = m.group(1), int(m.group(2)), m.group(3) or ""
+        return _base(_SIZES[size][0], _SIZES[size][1], 8, agents, int(agents * _DIFFICULTY[diff]))
+    try:
+        m = _ID_IMAGE.match(env_id)
+        if m:  # rware{-img|-imgdict}{-Nd}-{size}-{agents}ag{diff}
+            obs, nd, size, agents, diff = m.group(1) or "", m.group(2) or "", m.group(3), int(m.group(4)), m.group(5) or ""
+            if not 1 <= agents <= 19:
+                raise KeyError("agents")
+            return dict(_base(_SIZES[size][0], _SIZES[size][1], 8, agents, int(agents * _DIFFICULTY[diff])),
+                        **_obs_kwargs(obs, nd, True))
+        m = _ID_FULL_SIZE.match(env_id)
+        if m:  # rware{-img}{-Nd}{-Ns}-{size}-{h}h-{agents}ag{diff}
+            obs, nd, sr, size = m.group(1) or "", m.group(2) or "", m.group(3), m.group(4)
+            height, agents, diff = int(m.group(5)), int(m.group(6)), m.group(7) or ""
+            if not (1 <= agents <= 19 and 1 <= height <= 15):
+                raise KeyError("range")
+            return dict(_base(_SIZES[size][0], _SIZES[size][1], height, agents, int(agents * _DIFFICULTY[diff]),
+                              int(sr[1]) if sr else 1), **_obs_kwargs(obs, nd, False))
+        m = _ID_FULL_GRID.match(env_id)
+        if m:  # rware{-img}{-Nd}{-Ns}-{rows}x{cols}-{h}h-{agents}ag-{req}req-{reward}
+            obs, nd, sr = m.group(1) or "", m.group(2) or "", m.group(3)
+            rows, cols, height, agents, req = (int(m.group(k)) for k in (4, 5, 6, 7, 8))
+            if not (1 <= rows <= 4 and cols in (3, 5, 7, 9) and 1 <= height <= 15 and 1 <= agents <= 19 and 1 <= req <= 19):
+                raise KeyError("range")
+            return dict(_base(rows, cols, height, agents, req, int(sr[1]) if sr else 1, _REWARDS[m.group(9)]),
+                        **_obs_kwargs(obs, nd, False, allow_bare_nd=True))
+    except KeyError:
+        pass
+    raise KeyError(f"unknown rware id {env_id!r}")
 
 
 def all_ids(versions=("v1", "v2")):
