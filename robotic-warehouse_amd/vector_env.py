@@ -56,6 +56,51 @@ STATE_FIELDS = ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry", "agent
                 "queue", "steps", "inactive", "rng")
 
 
+def global_image_from_state(state, goals, image_layers, pad_to_shape=None):
+    """`Warehouse.get_global_image` (rware/warehouse.py:966-1040) from a batched get_state() dict: (B, C, H, W) float32.
+    Same quirks: GOALS written as the reference does (its loop variables are swapped twice: the right cells, :1013-1015);
+    AGENT_DIRECTION / AGENT_LOAD indexed `[ag.x, ag.y]` on an (H, W) array (:1003-1011) — the mirrored cell, IndexError when
+    x >= H or y >= W; REQUESTS from the positions of the queued shelves; padding split as in :1023-1039."""
+    grid = np.asarray(state["grid"])
+    B, _, H, W = grid.shape
+    ax, ay = np.asarray(state["agent_x"]), np.asarray(state["agent_y"])
+    rows = np.arange(B)[:, None]
+    layers = []
+    for lt in image_layers:
+        lt = ImageLayer(enum_value(lt))
+        layer = np.zeros((B, H, W), np.float32)
+        if lt == ImageLayer.SHELVES:
+            layer[grid[:, 1] > 0] = 1.0
+        elif lt == ImageLayer.REQUESTS:
+            q = np.asarray(state["queue"])
+            for k in range(q.shape[1]):
+                layer[np.asarray(grid[:, 1] == q[:, k, None, None]) & (q[:, k, None, None] > 0)] = 1.0
+        elif lt == ImageLayer.AGENTS:
+            layer[grid[:, 0] > 0] = 1.0
+        elif lt in (ImageLayer.AGENT_DIRECTION, ImageLayer.AGENT_LOAD):
+            carry = np.asarray(state["agent_carry"])
+            use = np.ones_like(ax, bool) if lt == ImageLayer.AGENT_DIRECTION else carry > 0
+            if ((ax >= H) | (ay >= W))[use].any():
+                raise IndexError("index out of bounds: AGENT_DIRECTION / AGENT_LOAD are written at [ag.x, ag.y] (rware/warehouse.py:1006,1011)")
+            val = (np.asarray(state["agent_dir"]) + 1).astype(np.float32) if lt == ImageLayer.AGENT_DIRECTION else np.ones_like(ax, np.float32)
+            for i in range(ax.shape[1]):  # agent order: a later agent overwrites an earlier one on the same (mirrored) cell
+                m = use[:, i]
+                layer[rows[m, 0], ax[m, i], ay[m, i]] = val[m, i]
+        elif lt == ImageLayer.GOALS:
+            for gx, gy in goals:
+                layer[:, gy, gx] = 1.0
+        elif lt == ImageLayer.ACCESSIBLE:
+            layer[:] = 1.0
+            layer[rows, ay, ax] = 0.0
+        layers.append(layer)
+    img = np.stack(layers, axis=1)
+    if pad_to_shape is not None:
+        pad = [p - g for p, g in zip(pad_to_shape, img.shape[1:])]
+        assert all(d >= 0 for d in pad)
+        img = np.pad(img, ((0, 0),) + tuple((d // 2, d // 2 if d % 2 == 0 else d // 2 + 1) for d in pad), mode="constant", constant_values=0)
+    return img
+
+
 class _Space:
     """Shape/dtype descriptor used when gymnasium is not installed."""
 
@@ -483,6 +528,33 @@ class WarehouseVecEnv(_VectorEnvBase):
 
     def observations(self):
         return self._observations()
+
+    # ------------------------------------------------------------------------------- the rest of Warehouse's public surface
+    def seed(self, seed=None):
+        """Warehouse.seed (rware/warehouse.py:962-964): re-seed the RNG streams without resetting — env i gets
+        `np_random(seed + i)` (the vector convention of reset(seed=...)); None leaves them alone."""
+        if seed is None:
+            return
+        if int(seed) < 0:
+            raise ValueError(f"Seed must be a non-negative integer, got {seed!r}")
+        lib = getattr(self.engines[0], "lib", None)
+        states = np.empty((self.num_envs, 6), np.uint64)
+        for i in range(self.num_envs):
+            rc = lib.rw_seed_state(int(seed) + i, states[i].ctypes.data)
+            assert rc == 0
+        self.set_state(refresh_obs=False, rng=states)
+        self._seeded = True
+
+    def get_global_image(self, image_layers=(ImageLayer.SHELVES, ImageLayer.GOALS), recompute=False, pad_to_shape=None):
+        """Warehouse.get_global_image (:966-1040) for every env: float32 (B, C, H, W) (or (B,) + pad_to_shape), layer by layer
+        as the reference builds them — including its cache (`recompute=False` returns the last image, whatever layers it was
+        built with) and the transposed AGENT_DIRECTION / AGENT_LOAD layers (IndexError where the reference raises it).
+        Host-side, from get_state(): a global-state input for centralised critics, not part of the per-step path."""
+        if not recompute and getattr(self, "global_image", None) is not None:
+            return self.global_image
+        st = self.get_state()
+        self.global_image = global_image_from_state(st, self.goals, image_layers, pad_to_shape)
+        return self.global_image
 
     def close(self, **kwargs):
         for eng in self.engines:

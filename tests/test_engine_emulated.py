@@ -712,3 +712,30 @@ def test_agent_arrays_are_derived_views_of_the_packed_records():
         o2, _, _ = orc.step_autoreset(a, "next_step")
         assert np.array_equal(obs, o2), t
     env.close()
+
+
+def test_seed_and_global_image_methods():
+    """The rest of Warehouse's public surface: seed() (:962-964) re-seeds the streams without resetting; get_global_image()
+    (:966-1040) with the reference's cache semantics."""
+    from rware_oracle import seed_state
+    kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
+    env = rware_amd.WarehouseVecEnv(4, library=LIB, envs_per_workgroup=4, threads_per_workgroup=64, **kw)
+    env.reset(seed=1)
+    before = env.get_state()
+    env.seed(77)
+    after = env.get_state()
+    for i in range(4):
+        assert np.array_equal(after["rng"][i], seed_state(77 + i))
+    for k in before:
+        if k != "rng":
+            assert np.array_equal(before[k], after[k]), k       # nothing but the streams changed
+    env.seed(None)
+    assert np.array_equal(env.get_state()["rng"], after["rng"])
+    img = env.get_global_image()
+    assert img.shape == (4, 2, 11, 10) and img.dtype == np.float32
+    assert np.array_equal(img[:, 0] > 0, after["grid"][:, 1] > 0) and img[:, 1].sum() == 2 * 4     # SHELVES, GOALS (2 goal cells)
+    env.step(np.full((4, 2), 1))
+    assert env.get_global_image([2]) is img                      # cached, like the reference (recompute=False)
+    img2 = env.get_global_image([2], recompute=True)
+    assert img2.shape == (4, 1, 11, 10) and np.array_equal(img2[:, 0] > 0, env.get_state()["grid"][:, 0] > 0)
+    env.close()

@@ -216,3 +216,45 @@ def test_opt_in_registries_parse_to_the_reference_kwargs():
                 "rware-6s-tiny-8h-2ag-v2", "rware-tiny-16h-2ag-v2"):
         with pytest.raises(KeyError):
             rware_amd.env_kwargs(bad)
+
+
+@pytest.mark.parametrize("env_id,extra", [
+    ("rware-tiny-2ag-v2", {}),
+    ("rware-small-4ag-v2", {}),
+    (None, dict(shelf_columns=3, column_height=3, shelf_rows=2, n_agents=5, msg_bits=0, sensor_range=1, request_queue_size=3,
+                max_inactivity_steps=None, max_steps=500, reward_type=1)),   # a square 10 x 10 grid: the transposed layers stay inside
+])
+def test_global_image_matches_the_reference(env_id, extra):
+    """`get_global_image` (rware/warehouse.py:966-1040) rebuilt from the batched state: every layer type, the default pair,
+    padding — against the live reference at the same state (the oracle steps beside it and supplies get_state())."""
+    from rware_amd.vector_env import global_image_from_state
+
+    kw = rr.registry_kwargs(env_id) if env_id else {}
+    kw.update(extra)
+    env = rr.make_reference_env(None, **kw)
+    wh = rr.load_reference()
+    orc = OracleVecEnv(1, **kw)
+    env.reset(seed=99)
+    orc.reset(seed=99)
+    pol = np.random.default_rng(3)
+    square = env.grid_size[0] == env.grid_size[1]
+    sets = [[0, 5], [0, 1, 2, 5, 6]] + ([[0, 1, 2, 3, 4, 5, 6], [3], [4]] if square else [])
+    for t in range(80):
+        a = rr.scripted_actions(env, pol) if t % 3 else list(pol.choice(5, size=env.n_agents, p=[.1, .5, .1, .1, .2]))
+        rr.ref_step(env, a)
+        orc.step(np.array(a)[None])
+        if t % 8:
+            continue
+        st = orc.get_state()
+        for ls in sets:
+            want = env.get_global_image(image_layers=[wh.ImageLayer(l) for l in ls], recompute=True)
+            got = global_image_from_state(st, env.goals, ls)
+            assert got.shape == (1,) + want.shape and np.array_equal(got[0], want), (t, ls)
+        shape = (2, env.grid_size[0] + 3, env.grid_size[1] + 2)
+        want = env.get_global_image(image_layers=[wh.ImageLayer(0), wh.ImageLayer(5)], recompute=True, pad_to_shape=shape)
+        assert np.array_equal(global_image_from_state(st, env.goals, [0, 5], shape)[0], want)
+    if not square:  # rectangular grids: the reference raises IndexError once an agent stands at x >= H or y >= W
+        bad = {k: v.copy() for k, v in orc.get_state().items()}
+        bad["agent_y"][0, 0] = env.grid_size[1]
+        with pytest.raises(IndexError):
+            global_image_from_state(bad, env.goals, [3])
