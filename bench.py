@@ -47,7 +47,7 @@ try:
     ORIG_AFFINITY = set(os.sched_getaffinity(0))  # before pin_rank() narrows it
 except AttributeError:
     ORIG_AFFINITY = None
-KERNEL_SOURCES = ("rware_kernels.h", "rware_cdna4.h", "rware_pcg64.h", "rware_capi.hip", "rware_static_table.h")
+KERNEL_SOURCES = ("rware_kernels.h", "rware_cdna4.h", "rware_pcg64.h", "rware_static_table.h", "rware_static.hip", "rware_generic.hip")
 
 
 def kernel_sources_sha() -> str:

@@ -97,8 +97,8 @@ enum rw_buffer_kind {
                                                    it (every other buffer is current after every step)           */
     /* The five agent arrays are DERIVED VIEWS as well (round 3): the kernels keep an agent as ONE packed dword
      * (cell, dir, has_delivered, carried shelf) — one load stream and one store stream per step instead of five each.
-     * rw_read / rw_get_buffer of these kinds unpack the records first (call rw_get_buffer again to bring a pointer
-     * borrowed earlier up to date: it is stable); rw_write of one of them re-packs all five.                       */
+     * rw_read / rw_get_buffer of these kinds unpack the records first; rw_write of one of them re-packs all five;
+     * rw_refresh_grid brings pointers borrowed earlier up to date.                                                  */
     RW_BUF_AGENT_X = 5,      /* int32   [B][N]     Agent.x (:86)                                  */
     RW_BUF_AGENT_Y = 6,      /* int32   [B][N]     Agent.y                                        */
     RW_BUF_AGENT_DIR = 7,    /* int32   [B][N]     rw_direction                                   */
@@ -203,9 +203,9 @@ int rw_device_free(rw_engine *eng, void *dev_ptr);
 int rw_copy_to_device(rw_engine *eng, void *dev_dst, const void *host_src, size_t bytes);
 int rw_copy_to_host(rw_engine *eng, void *host_dst, const void *dev_src, size_t bytes);
 
-/* bring RW_BUF_GRID up to date with the steps enqueued so far (two small kernels on the engine's stream; a no-op when
- * nothing ran since the last refresh).  For callers that hold a borrowed pointer / a zero-copy tensor of the grid.
- * (The agent views: rw_get_buffer(kind) again — same pointer, refreshed.) */
+/* bring the derived views — RW_BUF_GRID and RW_BUF_AGENT_X .. RW_BUF_AGENT_DELIVERED — up to date with the steps enqueued so
+ * far (three small kernels on the engine's stream; a no-op when nothing ran since the last refresh).  For callers that
+ * hold a borrowed pointer / a zero-copy tensor of one of them. */
 int rw_refresh_grid(rw_engine *eng);
 
 /* recompute RW_BUF_OBS from the current state (after rw_write of state buffers) */
@@ -219,6 +219,9 @@ int rw_sync(rw_engine *eng);
 int rw_get_buffer(rw_engine *eng, int kind, void **dev_ptr, size_t *bytes);
 /* synchronous copies between a buffer and host memory (state inspection / injection) */
 int rw_read(rw_engine *eng, int kind, void *host_dst, size_t bytes);
+/* the step() return tuple (:944-946) to host memory in one round trip: RW_BUF_OBS / REWARDS / TERMINATED (/ FEATURES) copied
+ * back to back, one synchronisation; any pointer may be NULL (skipped).  `truncated` is always False (:942): nothing to read. */
+int rw_read_outputs(rw_engine *eng, float *obs, float *rewards, uint8_t *terminated, float *features);
 int rw_write(rw_engine *eng, int kind, const void *host_src, size_t bytes);
 /* rebuild RW_BUF_GRID exactly like Warehouse._recalc_grid (:749-755) from explicit shelf
  * positions (host int32 [B][S][2] = (x,y) per shelf id; later ids overwrite earlier) and the

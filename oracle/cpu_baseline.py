@@ -168,11 +168,14 @@ def time_reference(env_id: str, seconds: float, procs: int):
 
 def measure(env_id: str, port_seconds: float = 5.0, ref_seconds: float = 6.0) -> dict:
     """The `cpu_baseline` object of bench.py's JSON line."""
-    P, model = host_cores(), cpu_model()
+    P_sched, model, quota = host_cores(), cpu_model(), cpu_quota()
+    # processes of the aggregate legs: one per CPU the job can actually run on at once — the schedulable set, capped by
+    # the container's CPU quota (more single-threaded processes than that only time-slice)
+    P = P_sched if not quota else max(1, min(P_sched, int(quota + 0.5)))
     port_1 = time_port(env_id, port_seconds, 1)
     port_p = time_port(env_id, port_seconds, P) if P > 1 else port_1
     out = {
-        "unit": "agent-steps/s", "cores": P, "cpu_model": model, "cpu_quota_cores": cpu_quota(),
+        "unit": "agent-steps/s", "cores": P, "cpu_model": model, "cpu_quota_cores": quota, "schedulable_cpus": P_sched,
         "port": {"single": port_1, "aggregate": port_p, "processes": P,
                  "what": "oracle/rware_oracle.c (C restatement of Warehouse.step + FLATTENED obs), 512 envs per process"},
     }

@@ -52,7 +52,7 @@ class RwInfo(C.Structure):
 
 EXPORTS = (
     "rw_create", "rw_destroy", "rw_last_error", "rw_reset", "rw_step", "rw_step_device",
-    "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_sync", "rw_get_buffer", "rw_read", "rw_write",
+    "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_sync", "rw_get_buffer", "rw_read", "rw_read_outputs", "rw_write",
     "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
     "rw_abi_version", "rw_debug_timeline", "rw_device_malloc", "rw_device_free", "rw_copy_to_device",
     "rw_copy_to_host", "rw_snapshot_create", "rw_snapshot_save", "rw_snapshot_restore", "rw_snapshot_destroy",
@@ -110,6 +110,7 @@ def load(path: str | None = None):
     lib.rw_sync.argtypes = [vp]
     lib.rw_get_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.rw_read.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.rw_read_outputs.argtypes = [vp, vp, vp, vp, vp]
     lib.rw_write.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.rw_recalc_grid.argtypes = [vp, vp, i32]
     lib.rw_get_info.argtypes = [vp, C.POINTER(RwInfo)]
@@ -309,6 +310,16 @@ class Engine:
         out = np.empty(self.shapes[name], dtype=BUF_DTYPE.get(name, np.int32))
         self._check(self.lib.rw_read(self._h, BUF[name], out.ctypes.data, out.nbytes))
         return out
+
+    def read_outputs(self, want_features=False):
+        """obs, rewards, terminated (uint8), features-or-None as fresh host arrays: one C call, one synchronisation."""
+        obs = np.empty(self.shapes["obs"], np.float32)
+        rew = np.empty(self.shapes["rewards"], np.float32)
+        term = np.empty(self.shapes["terminated"], np.uint8)
+        feat = np.empty(self.shapes["features"], np.float32) if want_features else None
+        self._check(self.lib.rw_read_outputs(self._h, obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
+                                             feat.ctypes.data if want_features else None))
+        return obs, rew, term, feat
 
     def write(self, name, array):
         a = np.ascontiguousarray(array, dtype=BUF_DTYPE.get(name, np.int32)).reshape(self.shapes[name])

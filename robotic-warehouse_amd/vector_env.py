@@ -318,11 +318,25 @@ class WarehouseVecEnv(_VectorEnvBase):
             # the flag buffers are uint8 0/1: reinterpreted as bool, not cast (a cast is a torch kernel per flag per step
             # around a ~7 us step kernel)
             return self._observations(), v["rewards"], v["terminated_bool"], v["truncated_bool"], {}
-        obs = self._observations()
-        rew = self._gather("rewards")
-        term = self._gather("terminated").astype(bool)
-        trunc = self._gather("truncated").astype(bool)
-        return obs, rew, term, trunc, {}
+        # host arrays: the whole return tuple in one round trip per device (`truncated` is always False, :942 — nothing to read)
+        if self._index_layers:
+            self.sync()  # IndexError where the reference's _make_img_obs raises it
+        want_f = self.observation_type == ObservationType.IMAGE_DICT
+        if len(self.engines) > 1:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+
+                self._pool = ThreadPoolExecutor(len(self.engines))
+            parts = list(self._pool.map(lambda eng: eng.read_outputs(want_f), self.engines))
+            obs, rew, term = (np.concatenate([p[k] for p in parts], axis=0) for k in range(3))
+            feat = np.concatenate([p[3] for p in parts], axis=0) if want_f else None
+        else:
+            obs, rew, term, feat = self.engines[0].read_outputs(want_f)
+        if self._dict_obs:
+            obs = self.dict_from_flat(obs)
+        elif want_f:
+            obs = {"image": obs, "features": feat}
+        return obs, rew, term.view(np.bool_), np.zeros(self.num_envs, np.bool_), {}
 
     def rollout(self, actions, want_obs=True):
         """Open-loop rollout: `actions` (T, B, N) -> (obs (T,B,N,L), rewards (T,B,N), terminated (T,B)).
