@@ -61,6 +61,16 @@ namespace {
 #define RW_TINY(N, Q) RW_STATIC(11, 10, N, Q, 32, 1, 16, 256, 0)
 #define RW_SMALL(N, Q) RW_STATIC(20, 10, N, Q, 80, 1, 16, 256, 0)
 #define RW_MEDIUM(N, Q) RW_STATIC(20, 16, N, Q, 144, 1, 16, 256, 0)
+// 6 and 8 agents: half-size workgroups (8 envs = 48 / 64 agents, one agent wavefront) for the smaller batches, listed in front
+// of the 16-env build of the same shape (first match wins).  Measured, round 3, same box (us per step, E = 8 vs 16):
+//   small-8ag   B = 8192 8.05 vs 9.14 | 16384 10.33 vs 11.60 | 32768 19.9 vs 17.6      medium-8ag  7.98 vs 9.06 | 10.23 vs 11.70 | 20.1 vs 21.4
+//   small-6ag   B = 8192 7.42 vs 8.42 | 16384  9.37 vs  9.85 | 32768 16.2 vs 14.5      medium-6ag-hard 7.25 vs 8.27 | 10.83 vs 9.84 | 17.2 vs 14.7
+//   tiny-6ag-hard        7.53 vs 8.48 |       11.25 vs  9.92 |       17.1 vs 14.4
+// -> 8 agents: up to 16384 envs; 6 agents: up to 8192 envs.
+#define RW_E8_MAXB(N) ((N) >= 8 ? 16384 : 8192)
+#define RW_TINY_E8(N, Q) RW_STATIC(11, 10, N, Q, 32, 1, 8, 256, RW_E8_MAXB(N)), RW_TINY(N, Q)
+#define RW_SMALL_E8(N, Q) RW_STATIC(20, 10, N, Q, 80, 1, 8, 256, RW_E8_MAXB(N)), RW_SMALL(N, Q)
+#define RW_MEDIUM_E8(N, Q) RW_STATIC(20, 16, N, Q, 144, 1, 8, 256, RW_E8_MAXB(N)), RW_MEDIUM(N, Q)
 
 const StaticEntry kEntries[] = {
 #if RW_STATIC_GROUP == 0
@@ -93,17 +103,17 @@ const StaticEntry kEntries[] = {
     // ---- the task grid of the RWARE benchmark papers (Papoudakis et al. 2021; Christianos et al. 2020): tiny / small /
     // medium x 2, 4, 6, 8 agents x easy / normal / hard.  request_queue_size = int(n_agents * {2, 1, 0.5})
     // (rware/__init__.py:14-21).  Shapes already listed in group 0 are not repeated.
-    RW_TINY(2, 4), RW_TINY(4, 8), RW_TINY(6, 12), RW_TINY(8, 16),          // -easy
-    RW_TINY(4, 4), RW_TINY(6, 6), RW_TINY(8, 8),                           // normal (tiny-2ag: group 0)
-    RW_TINY(2, 1), RW_TINY(4, 2), RW_TINY(6, 3), RW_TINY(8, 4),            // -hard
+    RW_TINY(2, 4), RW_TINY(4, 8), RW_TINY_E8(6, 12), RW_TINY_E8(8, 16),    // -easy
+    RW_TINY(4, 4), RW_TINY_E8(6, 6), RW_TINY_E8(8, 8),                     // normal (tiny-2ag: group 0)
+    RW_TINY(2, 1), RW_TINY(4, 2), RW_TINY_E8(6, 3), RW_TINY_E8(8, 4),      // -hard
 #elif RW_STATIC_GROUP == 3
-    RW_SMALL(2, 4), RW_SMALL(4, 8), RW_SMALL(6, 12), RW_SMALL(8, 16),      // -easy
-    RW_SMALL(2, 2), RW_SMALL(6, 6), RW_SMALL(8, 8),                        // normal (small-4ag: group 0)
-    RW_SMALL(2, 1), RW_SMALL(4, 2), RW_SMALL(6, 3), RW_SMALL(8, 4),        // -hard
+    RW_SMALL(2, 4), RW_SMALL(4, 8), RW_SMALL_E8(6, 12), RW_SMALL_E8(8, 16),  // -easy
+    RW_SMALL(2, 2), RW_SMALL_E8(6, 6), RW_SMALL_E8(8, 8),                  // normal (small-4ag: group 0)
+    RW_SMALL(2, 1), RW_SMALL(4, 2), RW_SMALL_E8(6, 3), RW_SMALL_E8(8, 4),    // -hard
 #elif RW_STATIC_GROUP == 4
-    RW_MEDIUM(2, 4), RW_MEDIUM(4, 8), RW_MEDIUM(6, 12), RW_MEDIUM(8, 16),  // -easy
-    RW_MEDIUM(2, 2), RW_MEDIUM(4, 4), RW_MEDIUM(6, 6), RW_MEDIUM(8, 8),    // normal
-    RW_MEDIUM(2, 1), RW_MEDIUM(4, 2), RW_MEDIUM(8, 4),                     // -hard (medium-6ag-hard: group 0)
+    RW_MEDIUM(2, 4), RW_MEDIUM(4, 8), RW_MEDIUM_E8(6, 12), RW_MEDIUM_E8(8, 16),  // -easy
+    RW_MEDIUM(2, 2), RW_MEDIUM(4, 4), RW_MEDIUM_E8(6, 6), RW_MEDIUM_E8(8, 8),  // normal
+    RW_MEDIUM(2, 1), RW_MEDIUM(4, 2), RW_MEDIUM_E8(8, 4),                   // -hard (medium-6ag-hard: group 0)
 #elif RW_STATIC_GROUP == 5
     // ---- size-static builds (N == 0: any agent count / queue length): every other registered id, sensor_range 1
     RW_STATIC(11, 10, 0, 0, 32, 1, 16, 256, 0),    // rware-tiny-*
@@ -120,6 +130,9 @@ const StaticEntry kEntries[] = {
 #undef RW_STATIC_MSG
 #undef RW_STATIC_POS
 #undef RW_TINY
+#undef RW_TINY_E8
+#undef RW_SMALL_E8
+#undef RW_MEDIUM_E8
 #undef RW_SMALL
 #undef RW_MEDIUM
 }  // namespace

@@ -655,7 +655,8 @@ def test_paper_task_grid_runs_exact_shape_builds(env_id):
     kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
     B = 16
     env = rware_amd.WarehouseVecEnv(B, library=LIB, **kw)
-    assert env.engines[0].info.specialised == 1 and env.engines[0].info.envs_per_workgroup == 16
+    # (6 and 8 agents: the half-size-workgroup build serves batches up to 16384 envs)
+    assert env.engines[0].info.specialised == 1 and env.engines[0].info.envs_per_workgroup == (8 if kw["n_agents"] >= 6 else 16)
     orc = OracleVecEnv(B, **kw)
     assert np.array_equal(env.reset(seed=4)[0], orc.reset(seed=4))
     rng = np.random.default_rng(6)
