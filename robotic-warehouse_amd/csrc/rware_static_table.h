@@ -72,6 +72,14 @@ namespace {
 #define RW_SMALL_E8(N, Q) RW_STATIC(20, 10, N, Q, 80, 1, 8, 256, RW_E8_MAXB(N)), RW_SMALL(N, Q)
 #define RW_MEDIUM_E8(N, Q) RW_STATIC(20, 16, N, Q, 144, 1, 8, 256, RW_E8_MAXB(N)), RW_MEDIUM(N, Q)
 
+// 2 agents: double-size workgroups (32 envs = 64 agents, one full agent wavefront) from 16384 envs up — the 16-env build in
+// front of it serves the smaller batches, and again behind it the batches that are no multiple of 32.  Measured, round 3,
+// same box (E = 16 vs 32): small-2ag B = 4096 4.38 vs 4.41 | 16384 5.87 vs 5.70 | 65536 13.8 vs 10.6; tiny-2ag 4.45 vs 4.44 |
+// 5.96 vs 5.79 | 12.8 vs 10.3.  (The pattern across N = 2, 4, 6, 8: about 64 agents per workgroup.)
+#define RW_TINY_E32(N, Q) RW_STATIC(11, 10, N, Q, 32, 1, 16, 256, 16383), RW_STATIC(11, 10, N, Q, 32, 1, 32, 256, 0), RW_TINY(N, Q)
+#define RW_SMALL_E32(N, Q) RW_STATIC(20, 10, N, Q, 80, 1, 16, 256, 16383), RW_STATIC(20, 10, N, Q, 80, 1, 32, 256, 0), RW_SMALL(N, Q)
+#define RW_MEDIUM_E32(N, Q) RW_STATIC(20, 16, N, Q, 144, 1, 16, 256, 16383), RW_STATIC(20, 16, N, Q, 144, 1, 32, 256, 0), RW_MEDIUM(N, Q)
+
 const StaticEntry kEntries[] = {
 #if RW_STATIC_GROUP == 0
     // ---- the BASELINE.json tasks (+ their batch-size / geometry variants)
@@ -79,13 +87,14 @@ const StaticEntry kEntries[] = {
     // half-size workgroups for batches that leave the CUs short of workgroups at E = 16 (measured, round 2:
     // medium-6ag-hard B=8192 9.16 -> 7.98 us, B=4096 7.86 -> 6.71; B=16384 11.2 vs 13.1 the other way round)
     RW_STATIC(20, 16, 6, 3, 144, 1, 8, 256, 8192),
-    RW_STATIC(11, 10, 2, 2, 32, 1, 16, 256, 0),    // rware-tiny-2ag
+    RW_TINY_E32(2, 2),                             // rware-tiny-2ag (BASELINE config 2 runs the 16-env build: B = 4096)
     RW_STATIC(20, 10, 4, 4, 80, 1, 16, 256, 0),    // rware-small-4ag (headline)
     // (small-4ag with 8 envs per workgroup: since the agent phases run in registers the 16-env build wins at every batch
     //  size — B=1024 4.77 vs 4.81 us, 4096 5.35 vs 5.63, 16384 7.87 vs 10.3 — so this one only serves batches that are
     //  a multiple of 8 but not of 16, or an explicit geometry)
     RW_STATIC(20, 10, 4, 4, 80, 1, 8, 256, 0),
     RW_STATIC(20, 16, 6, 3, 144, 1, 16, 256, 0),   // rware-medium-6ag-hard
+    // (large-16ag r=2, round 3, same box: E = 8 36.2 us at B = 16384 vs 38.4 with E = 4 and 37.1 with E = 16; B = 4096: 14.6 vs 13.8 with E = 4)
     RW_STATIC(29, 16, 16, 16, 224, 2, 8, 256, 0),  // rware-large-16ag, sensor_range = 2
 #elif RW_STATIC_GROUP == 1
     // ---- the "next" observation kinds callers hit first: IMAGE / IMAGE_DICT (any layer list, directional
@@ -103,17 +112,17 @@ const StaticEntry kEntries[] = {
     // ---- the task grid of the RWARE benchmark papers (Papoudakis et al. 2021; Christianos et al. 2020): tiny / small /
     // medium x 2, 4, 6, 8 agents x easy / normal / hard.  request_queue_size = int(n_agents * {2, 1, 0.5})
     // (rware/__init__.py:14-21).  Shapes already listed in group 0 are not repeated.
-    RW_TINY(2, 4), RW_TINY(4, 8), RW_TINY_E8(6, 12), RW_TINY_E8(8, 16),    // -easy
+    RW_TINY_E32(2, 4), RW_TINY(4, 8), RW_TINY_E8(6, 12), RW_TINY_E8(8, 16),    // -easy
     RW_TINY(4, 4), RW_TINY_E8(6, 6), RW_TINY_E8(8, 8),                     // normal (tiny-2ag: group 0)
-    RW_TINY(2, 1), RW_TINY(4, 2), RW_TINY_E8(6, 3), RW_TINY_E8(8, 4),      // -hard
+    RW_TINY_E32(2, 1), RW_TINY(4, 2), RW_TINY_E8(6, 3), RW_TINY_E8(8, 4),      // -hard
 #elif RW_STATIC_GROUP == 3
-    RW_SMALL(2, 4), RW_SMALL(4, 8), RW_SMALL_E8(6, 12), RW_SMALL_E8(8, 16),  // -easy
-    RW_SMALL(2, 2), RW_SMALL_E8(6, 6), RW_SMALL_E8(8, 8),                  // normal (small-4ag: group 0)
-    RW_SMALL(2, 1), RW_SMALL(4, 2), RW_SMALL_E8(6, 3), RW_SMALL_E8(8, 4),    // -hard
+    RW_SMALL_E32(2, 4), RW_SMALL(4, 8), RW_SMALL_E8(6, 12), RW_SMALL_E8(8, 16),  // -easy
+    RW_SMALL_E32(2, 2), RW_SMALL_E8(6, 6), RW_SMALL_E8(8, 8),                  // normal (small-4ag: group 0)
+    RW_SMALL_E32(2, 1), RW_SMALL(4, 2), RW_SMALL_E8(6, 3), RW_SMALL_E8(8, 4),    // -hard
 #elif RW_STATIC_GROUP == 4
-    RW_MEDIUM(2, 4), RW_MEDIUM(4, 8), RW_MEDIUM_E8(6, 12), RW_MEDIUM_E8(8, 16),  // -easy
-    RW_MEDIUM(2, 2), RW_MEDIUM(4, 4), RW_MEDIUM_E8(6, 6), RW_MEDIUM_E8(8, 8),  // normal
-    RW_MEDIUM(2, 1), RW_MEDIUM(4, 2), RW_MEDIUM_E8(8, 4),                   // -hard (medium-6ag-hard: group 0)
+    RW_MEDIUM_E32(2, 4), RW_MEDIUM(4, 8), RW_MEDIUM_E8(6, 12), RW_MEDIUM_E8(8, 16),  // -easy
+    RW_MEDIUM_E32(2, 2), RW_MEDIUM(4, 4), RW_MEDIUM_E8(6, 6), RW_MEDIUM_E8(8, 8),  // normal
+    RW_MEDIUM_E32(2, 1), RW_MEDIUM(4, 2), RW_MEDIUM_E8(8, 4),                   // -hard (medium-6ag-hard: group 0)
 #elif RW_STATIC_GROUP == 5
     // ---- size-static builds (N == 0: any agent count / queue length): every other registered id, sensor_range 1
     RW_STATIC(11, 10, 0, 0, 32, 1, 16, 256, 0),    // rware-tiny-*
@@ -131,6 +140,9 @@ const StaticEntry kEntries[] = {
 #undef RW_STATIC_POS
 #undef RW_TINY
 #undef RW_TINY_E8
+#undef RW_TINY_E32
+#undef RW_SMALL_E32
+#undef RW_MEDIUM_E32
 #undef RW_SMALL_E8
 #undef RW_MEDIUM_E8
 #undef RW_SMALL

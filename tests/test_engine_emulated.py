@@ -715,6 +715,34 @@ def test_agent_arrays_are_derived_views_of_the_packed_records():
     env.close()
 
 
+def test_two_agent_tasks_take_double_size_workgroups_from_16384_envs():
+    """2 agents: the 32-env build (64 agents = one full agent wavefront) from 16384 envs up, the 16-env build below and for
+    batches that are no multiple of 32; pinned here through the explicit geometry and checked against the oracle."""
+    kw = rware_amd.env_kwargs("rware-small-2ag-hard-v1")
+    kw["max_steps"] = 15
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    B = 64
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=32, threads_per_workgroup=256, **kw)
+    assert env.engines[0].info.specialised == 1 and env.engines[0].info.envs_per_workgroup == 32
+    small = rware_amd.WarehouseVecEnv(B, library=LIB, **kw)
+    assert small.engines[0].info.envs_per_workgroup == 16          # default geometry below 16384 envs
+    small.close()
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=8)[0], orc.reset(seed=8))
+    rng = np.random.default_rng(1)
+    for t in range(24):
+        a = rng.choice(5, size=(B, 2), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+    acts = rng.choice(5, size=(10, B, 2), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+    obs, rew, term = env.rollout(acts)
+    for k in range(10):
+        o2, r2, d2 = orc.step_autoreset(acts[k], "next_step")
+        assert np.array_equal(obs[k], o2) and np.array_equal(rew[k], r2), k
+    env.close()
+
+
 def test_seed_and_global_image_methods():
     """The rest of Warehouse's public surface: seed() (:962-964) re-seeds the streams without resetting; get_global_image()
     (:966-1040) with the reference's cache semantics."""

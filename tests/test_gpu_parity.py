@@ -789,10 +789,11 @@ def test_paper_task_grid_exact_shape_builds_match_oracle(env_id):
     kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
     B, N = 512, kw["n_agents"]
     # 6 and 8 agents have two builds (8 envs per workgroup up to 16384 envs, 16 beyond): alternate which one is pinned
-    geom = (16, 256) if N >= 6 and len(env_id) % 2 else (0, 0)
+    # (2 agents: 16 envs per workgroup below 16384 envs, 32 from there on — every 2-agent id is pinned to the 32-env build here)
+    geom = (16, 256) if N >= 6 and len(env_id) % 2 else (32, 256) if N == 2 else (0, 0)
     env = rware_amd.WarehouseVecEnv(B, envs_per_workgroup=geom[0], threads_per_workgroup=geom[1], **kw)
     assert env.engines[0].info.specialised == 1
-    assert env.engines[0].info.envs_per_workgroup == (16 if geom[0] or N < 6 else 8)
+    assert env.engines[0].info.envs_per_workgroup == (geom[0] if geom[0] else 16 if N < 6 else 8)
     orc = OracleVecEnv(B, **kw)
     assert np.array_equal(env.reset(seed=31)[0], orc.reset(seed=31))
     rng = np.random.default_rng(8)
