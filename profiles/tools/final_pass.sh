@@ -19,7 +19,10 @@ python profiles/tools/timeline_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/$
 python profiles/tools/timeline_probe.py rware-small-4ag-v1 262144 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_B262144.txt
 TL_OBS_TYPE=2 python profiles/tools/timeline_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_image.txt
 python profiles/tools/timeline_probe.py rware-medium-6ag-hard-v1 8192 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_medium6.txt
+TL_SENSOR_RANGE=2 python profiles/tools/timeline_probe.py rware-large-16ag-v1 16384 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_large16_r2.txt
+python profiles/tools/timeline_probe.py rware-small-8ag-v1 16384 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_small8.txt
 python profiles/tools/k20_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_k20_probe.txt
+python profiles/tools/api_rates.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_api_rates.txt
 bash profiles/tools/unprofiled.sh $TAG > gpurun_out/${TAG}_unprofiled.txt
 cat gpurun_out/${TAG}_unprofiled.txt
 python - <<PY

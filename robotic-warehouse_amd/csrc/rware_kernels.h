@@ -4,12 +4,13 @@
 // phase of rware.warehouse.Warehouse.step (rware/warehouse.py:804-946) and the FLATTENED
 // observation gather (:598-674), with the per-env working set staged in LDS:
 //
-//   P0  HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): the agent SoA, the request queue, the
-//       actions and the env's SHELF layer.  The kernel reads the shelf layer from a compact
-//       shadow (uint8/uint16 per cell, `shelf_shadow`) rather than from the exported int32 grid:
-//       the grid is 93 % of a step's read bytes, the shadow is 1/8 of it.  The agent layer is not
-//       read at all — it is rebuilt in LDS from the agent coordinates.  The int32 grid
-//       [B][2][H][W] stays current in HBM (patched below) as the buffer callers see.
+//   P0  HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): the packed agent records (one dword per
+//       agent, rec_pack below), the request queue, the actions and the env's SHELF layer.  The
+//       kernel reads the shelf layer from a compact shadow (uint8/uint16 per cell,
+//       `shelf_shadow`) rather than from the exported int32 grid: the grid is 93 % of a step's
+//       read bytes, the shadow is 1/8 of it.  The agent layer is not read at all — it is rebuilt
+//       in LDS from the agent coordinates.  The int32 grid [B][2][H][W] and the five int32 agent
+//       arrays callers see are DERIVED VIEWS, rebuilt on demand by small host-path kernels.
 //   AG  the per-agent phases, one lane per (env, agent), all agents of an env inside ONE
 //       wavefront, ordered by wave-local LDS syncs (no workgroup barrier); written branch-free
 //       (a wavefront holds every action and heading at once); a wave-uniform ballot skips the
@@ -20,8 +21,8 @@
 //             _recalc_grid                                   (:880-901, :749-755)
 //         P5  goals, request replacement (numpy-exact PCG64 draw), rewards, termination (:903-942)
 //   RS  on-device reset for autoreset / rw_reset, numpy-exact draws (rare path)   (:757-802)
-//   WB  state write-back in three roles: per-env counters/flags + queue; agent SoA + rewards
-//       (coalesced); the grid/shadow patch of the <= 2N cells per layer that changed.
+//   WB  state write-back in three roles: per-env counters/flags + queue; agent records + rewards
+//       (coalesced); the shadow patch of the <= 2N shelf cells that changed.
 //   OS  the self part of the observation (own coordinates, load, heading, on-highway).
 //   P7  observation (:598-674): per (agent, window row) the 7-bit cell codes are OR-ed into ONE
 //       contiguous bit string per workgroup (bit g == obs element g of the chunk), so float4 #q is
@@ -161,7 +162,8 @@ enum : int { TL_START = 0, TL_ZEROED, TL_DMA_ISSUED, TL_ENV_LOADED, TL_LOADED, T
 // LDS carve-up, in dwords.  Every sub-array starts on a 16-byte boundary.
 struct LdsLayout {
     // DMA destinations, contiguous in exactly this order (the static builds fill them with ONE linear
-    // LDS-DMA stream): shelf layer, agent SoA, actions, queue, highway bitmap, per-env counters/flags
+    // LDS-DMA stream): shelf layer, agent arrays (the packed records land in `ax` and are unpacked in place; in the
+    // kDirect builds the agent lanes publish them), actions, queue, highway bitmap, per-env counters/flags
     int gs, ax, ay, dir, carry, deliv, act, queue, hw, dsteps, dinact, dflag, dma_end;
     int pos;  // POSITION layout: the chunk's shelf positions take the first DMA slot; `gs` then lies in the cleared block
     int ga, zero_end;  // cleared every launch
@@ -310,7 +312,7 @@ template <typename Dummy = void>
 __global__ void rware_pack_agents_kernel(uint32_t *rec, const int32_t *ax, const int32_t *ay, const int32_t *adir,
                                          const int32_t *acarry, const int32_t *adeliv, size_t n, int W) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        rec[i] = rec_pack(ay[i] * W + ax[i], adir[i] & 3, adeliv[i], acarry[i] & 0x3fff);
+        rec[i] = rec_pack((ay[i] * W + ax[i]) & 0x3fff, adir[i] & 3, adeliv[i], acarry[i] & 0x3fff);
 }
 
 // Rebuilds the exported int32 grid [B][2][H][W] (rware/warehouse.py:749-755, _recalc_grid) from the state the kernels keep:
@@ -1218,7 +1220,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             ev[ENVI_INACTIVE] = 0;
         }
         __syncthreads();
-        // write the reset envs back: shelf shadow (the exported int32 grid is derived from it on demand), agent SoA, queue,
+        // write the reset envs back: shelf shadow (the exported int32 grid is derived from it on demand), agent records, queue,
         // counters, self bits
         for (int c = tid; c < ne * HW; c += T) {
             const int e = c / HW;
