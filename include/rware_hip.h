@@ -246,6 +246,9 @@ typedef struct rw_info {
     int32_t device_id, compute_units;
     int32_t specialised;  /* 1: a kernel build with this task's shapes folded in at compile time is in use */
     int32_t state_layout; /* 0: the shelf layer is staged from the per-cell shadow; 1: from the per-shelf position array (big batches) */
+    int32_t build_kind;   /* which build of the step kernel runs: 0 generic (every shape at run time), 1 exact-shape, 2 agent-count-
+                             static (shapes + agent count folded in, request-queue length at run time), 3 size-static (grid folded in,
+                             agent count and queue length at run time).  (Occupies what was alignment padding: same struct size.) */
     int64_t algorithmic_bytes_per_env_step; /* SURVEY.md §8(d) formula                           */
     char device_name[128];
     char arch_name[64];

@@ -45,7 +45,7 @@ class RwInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "num_envs", "grid_h", "grid_w", "n_agents", "request_queue_size", "n_shelves", "obs_length",
         "envs_per_workgroup", "threads_per_workgroup", "n_workgroups", "lds_bytes", "device_id",
-        "compute_units", "specialised", "state_layout")] + [
+        "compute_units", "specialised", "state_layout", "build_kind")] + [
         ("algorithmic_bytes_per_env_step", C.c_int64),
         ("device_name", C.c_char * 128), ("arch_name", C.c_char * 64)]
 

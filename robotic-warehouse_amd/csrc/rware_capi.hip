@@ -60,6 +60,8 @@ struct rw_engine {
     void *d_shadow = nullptr;  // compact shelf layer (uint8 when S <= 255, else uint16), the kernel's read path
     size_t pos_off = 0;
     uint8_t *d_pos = nullptr;  // [B][S] cell of every shelf: the shelf layer of the POSITION layout (pos_layout), else unused
+    int build_kind = 0;        // rw_info::build_kind
+    bool q_runtime = false;    // the chosen build reads the request-queue length at run time (StaticEntry::Q == -1)
     bool pos_layout = false;   // the step kernels stage the shelf layer from d_pos; d_shadow is then a derived view (sync_shadow)
     bool wide = false;
     bool image = false;        // IMAGE / IMAGE_DICT observation kernels
@@ -101,7 +103,8 @@ using rw_tab::StaticEntry;
 namespace rw_tab {
 const StaticEntry *static_group(int group, int *n) {
     using fn_t = const StaticEntry *(*)(int *);
-    static const fn_t kGroups[kStaticGroups] = {static_group_0, static_group_1, static_group_2, static_group_3, static_group_4, static_group_5};
+    static const fn_t kGroups[kStaticGroups] = {static_group_0, static_group_1, static_group_2, static_group_3, static_group_4, static_group_5,
+                                                static_group_6};
     return kGroups[group](n);
 }
 }  // namespace rw_tab
@@ -392,6 +395,8 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // Pick a specialised build: exact-shape entries before size-static ones, first match wins.
         const bool geom_default = cfg->envs_per_workgroup == 0 && cfg->threads_per_workgroup == 0;
         const StaticEntry *best = nullptr;
+        const char *pq = getenv("RWARE_PREFER_QRT");
+        const bool prefer_qrt = pq && pq[0] == '1';
         for (int exact = 1; exact >= 0 && !best; --exact)
             for (int grp = 0; grp < rw_tab::kStaticGroups && !best; ++grp) {
             int n_se = 0;
@@ -410,7 +415,10 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
                     for (int l = 0; l < n_layers && l < 8; ++l) packed |= (uint32_t)layers[l] << (4 * l);
                     if (se.NL != n_layers || se.layers != packed || se.directional != (cfg->image_directional ? 1 : 0)) continue;
                 }
-                const bool shape = se.H == H && se.W == W && se.S == S && se.R == R && (se.N == 0 || (se.N == N && se.Q == Q));
+                // (Q == -1: an agent-count-static build — any queue length up to 2 N, read at run time)
+                const bool q_ok = se.Q == Q || (se.Q < 0 && Q <= 2 * se.N);
+                if (prefer_qrt && se.N != 0 && se.Q >= 0 && !se.image && se.M == 0) continue;  // (test / A-B hook: skip the exact (N, Q) builds)
+                const bool shape = se.H == H && se.W == W && se.S == S && se.R == R && (se.N == 0 || (se.N == N && q_ok));
                 if (!shape || B % se.E != 0) continue;
                 if (geom_default ? (se.max_B == 0 || B <= se.max_B) : (E == se.E && T == se.T)) { best = &se; break; }
             }
@@ -422,12 +430,15 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             eng->kernel_rollout = best->fn_rollout;
             eng->specialised = true;
             eng->pos_layout = best->pos != 0;
+            eng->q_runtime = best->Q < 0;
+            eng->build_kind = best->N == 0 ? 3 : best->Q < 0 ? 2 : 1;
         }
     }
     eng->E = E;
     eng->T = T;
     eng->n_wg = (B + E - 1) / E;
-    eng->lds_bytes = sizeof(int32_t) * (size_t)rw::make_lds_layout(E, N, Q, HW, SW, eng->OW, cell_bytes, AM, eng->pos_layout ? S : 0).total;
+    // (an agent-count-static build reserves 2 N queue slots per env in LDS whatever Q is)
+    eng->lds_bytes = sizeof(int32_t) * (size_t)rw::make_lds_layout(E, N, eng->q_runtime ? 2 * N : Q, HW, SW, eng->OW, cell_bytes, AM, eng->pos_layout ? S : 0).total;
     if (eng->lds_bytes > 160 * 1024) {
         fail(eng, RW_ERR_INVALID_ARG, "LDS footprint %zu B exceeds 160 KiB; lower envs_per_workgroup", eng->lds_bytes);
         return bail(RW_ERR_INVALID_ARG);
@@ -948,6 +959,7 @@ int rw_get_info(const rw_engine *eng, rw_info *out) {
     out->compute_units = eng->prop.multiProcessorCount;
     out->specialised = eng->specialised ? 1 : 0;
     out->state_layout = eng->pos_layout ? 1 : 0;
+    out->build_kind = eng->build_kind;
     // A = 8HW + 4N + 40N + 4Q + 16 + 4NL + 4N + 4
     out->algorithmic_bytes_per_env_step =
         8LL * p.HW + 4LL * p.N + 40LL * p.N + 4LL * p.Q + 16 + 4LL * p.N * eng->L + 4LL * p.N + 4;

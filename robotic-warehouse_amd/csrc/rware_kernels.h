@@ -226,6 +226,8 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
 // at run time — one such build covers every registered id of a warehouse size.
 struct DynamicCfg {
     static constexpr int kH = 0, kW = 0, kN = 0, kQ = 0, kS = 0, kE = 0, kT = 0, kM = 0;
+    static constexpr bool kQrt = false;
+    static constexpr int kQcap = 0;
     static constexpr int kNL = 0, kDirectional = -1;
     static constexpr uint32_t kLayers = 0;
     static constexpr bool kPos = false;
@@ -237,7 +239,12 @@ struct DynamicCfg {
 // whole lines instead of scattered 1-byte patches — the layout for batches whose traffic no longer fits the Infinity Cache.
 template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_, int M_ = 0, int NL_ = 0, uint32_t LAYERS_ = 0, int DIR_ = -1, bool POS_ = false>
 struct StaticCfg {
-    static constexpr int kH = H_, kW = W_, kN = N_, kQ = Q_, kS = S_, kE = E_, kT = T_, kM = M_;
+    // Q_ < 0 (with N_ != 0): an "agent-count-static" build — everything of an exact-shape build except the request-queue
+    // length, which is read at run time (any Q <= 2 N_: the easy / normal / hard variants of a task and custom queue sizes
+    // share ONE build).  The LDS carve-up reserves the 2 N_ slots, so every offset stays a compile-time constant.
+    static constexpr bool kQrt = N_ != 0 && Q_ < 0;
+    static constexpr int kQcap = kQrt ? 2 * N_ : Q_;
+    static constexpr int kH = H_, kW = W_, kN = N_, kQ = kQrt ? 0 : Q_, kS = S_, kE = E_, kT = T_, kM = M_;
     static constexpr int kNL = NL_, kDirectional = DIR_;
     static constexpr uint32_t kLayers = LAYERS_;
     static constexpr bool kPos = POS_;
@@ -391,7 +398,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const int e0 = blockIdx.x * E;
     const int ne = Cfg::kE ? E : min(E, p.B - e0);  // the static kernels are only launched with B % E == 0
     if (ne <= 0) return;
-    const int N = Cfg::kN ? Cfg::kN : p.N, Q = Cfg::kN ? Cfg::kQ : p.Q;
+    const int N = Cfg::kN ? Cfg::kN : p.N, Q = (Cfg::kN && !Cfg::kQrt) ? Cfg::kQ : p.Q;
+    const int QL = Cfg::kQrt ? Cfg::kQcap : Q;  // queue slots the LDS carve-up reserves per env
     const int H = Cfg::kH ? Cfg::kH : p.H, W = Cfg::kW ? Cfg::kW : p.W, HW = H * W;
     const int S = Cfg::kS ? Cfg::kS : p.S, SW = (S + 32) / 32, B = p.B;
     const int nea = ne * N;
@@ -420,6 +428,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     if constexpr (!kClearFirst) {
         keep_sgpr_ptr(g_shadow, q_rec, q_queue, q_steps, q_inact, q_hw, q_need);
         keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
+        if constexpr (Cfg::kQrt) keep_sgpr(Q);  // (the stage-in of the queue needs it)
     }
     // IMAGE kernels: the layer list and its switches belong to the same batch — the image gather used to fetch them where
     // it uses them (one scalar-cache round trip per layer, per goal cell and per switch, inside the phase that stands between
@@ -464,7 +473,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     constexpr bool kPos = Cfg::kPos;  // shelf layer staged from / written back to the position array (see StaticCfg)
     static_assert(!kPos || (kRegAG && Cfg::kE != 0 && sizeof(CellT) == 1 && Cfg::kH * Cfg::kW <= 256 && (Cfg::kE * Cfg::kS) % 16 == 0),
                   "the position layout: exact-shape register builds, cell index in a byte, chunk 16-byte granular");
-    const LdsLayout lo = make_lds_layout(E, N, Q, HW, SW, OW, (int)sizeof(CellT), AM, kPos ? S : 0);
+    const LdsLayout lo = make_lds_layout(E, N, QL, HW, SW, OW, (int)sizeof(CellT), AM, kPos ? S : 0);
     uint8_t *const s_pos = reinterpret_cast<uint8_t *>(smem + (kPos ? lo.pos : lo.gs));  // (kPos only)
     uint8_t *const g_pos = p.shelf_pos;
     CellT *s_gs = reinterpret_cast<CellT *>(smem + lo.gs);
@@ -582,7 +591,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // Static build: every DMA destination is contiguous in LDS and every source chunk is a whole
         // number of 16-byte pieces, so the chunk is ONE linear stream — thread t moves LDS piece t;
         // its HBM source is picked from the segment table (all pointers fetched in one scalar batch).
-        static_assert((Cfg::kE * Cfg::kN) % 4 == 0 && (Cfg::kE * Cfg::kQ) % 4 == 0 && Cfg::kE % 4 == 0, "chunk not 16-byte granular");
+        static_assert((Cfg::kE * Cfg::kN) % 4 == 0 && (Cfg::kE * Cfg::kQcap) % 4 == 0 && Cfg::kE % 4 == 0, "chunk not 16-byte granular");
         static_assert(!kMsg || Cfg::kN == 0 || Cfg::kM != 0, "an exact-shape _MSG build needs its communication bits at compile time");
         static_assert(kPos || (Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0, "shelf chunk not 16-byte granular");
         const char *src[12] = {
@@ -608,8 +617,10 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 if (k >= 2 && k <= 5) continue;  // (filled by unpack_records, not by DMA)
                 if (kDirect && ((k >= 1 && k <= 6) || k >= 9)) continue;  // agent records, actions, counters, flags: in registers
                 const int pieces = (seg[k + 1] - seg[k]) >> 2;
+                // (run-time queue length: the slot holds 2 N entries per env, the chunk in HBM is [E][Q] — contiguous, E * Q / 4 pieces)
+                const int have = (Cfg::kQrt && k == 7) ? (E * Q) >> 2 : pieces;
                 for (int c = 0; c < pieces; c += 64, ++job)
-                    if (job % dma_w == wave_s && c + lane < pieces)
+                    if (job % dma_w == wave_s && c + lane < have)
                         lds_dma_b128(src[k] + (size_t)(c + lane) * 16, smem + seg[k] + 4 * c);
             }
             if constexpr (kMsg && !kDirect) {  // the agents' stored messages: a 13th array, outside the contiguous block
@@ -694,6 +705,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         lds_barrier();
     }
     keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
+    if constexpr (Cfg::kQrt) keep_sgpr(Q);
     RW_MARK(TL_LOADED);
 
     // kRollout == false is the single-step kernel (rw_step / rw_reset / rw_refresh_obs): no loop at all.
@@ -798,7 +810,8 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     //           at the top of the kernel.
     //   else    the sub-phases exchange through LDS arrays under wave_sync() (any N up to 64, run-time shapes).
     if constexpr (kRegAG) {
-    constexpr int KN = Cfg::kN, KG = 64 / KN, KQ = Cfg::kQ, QS = (KQ + KN - 1) / KN;
+    constexpr int KN = Cfg::kN, KG = 64 / KN, QS = (Cfg::kQcap + KN - 1) / KN;
+    const int KQ = Cfg::kQrt ? Q : Cfg::kQ;  // (a compile-time constant unless the build reads the queue length at run time)
     static_assert(Cfg::kH * Cfg::kW < 0x8000, "cell indices are packed into 16 bits");
     for (int eb = wave * KG; eb < ne; eb += nw * KG) {  // wave-uniform
         const int g = lane / KN, a_idx = lane - g * KN;
@@ -860,8 +873,12 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         const int sh_tg = gS[tg0], shelf_here = gS[st], sh_g0 = gS[k_goal0], sh_g1 = gS[k_goal1];
         const uint32_t hw_word = s_hw[st >> 5];
         int qv[QS > 0 ? QS : 1];  // the queue slots this lane publishes in the requested-shelf bitmap
+        const int eq = Cfg::kQrt ? __mul24(e, KQ) : e * KQ;  // row of the env in the LDS queue
 #pragma unroll
-        for (int q = 0; q < QS; ++q) qv[q] = s_queue[e * KQ + min(a_idx + q * KN, KQ - 1)];
+        for (int q = 0; q < QS; ++q) {
+            if (Cfg::kQrt && q * KN >= KQ) { qv[q] = 0; continue; }  // (scalar test: a slot group beyond the run-time queue length)
+            qv[q] = s_queue[eq + (Cfg::kQrt ? max(min(a_idx + q * KN, KQ - 1), 0) : min(a_idx + q * KN, KQ - 1))];
+        }
         const int occ_w = kEarly ? in.occ_w : occupant_of(in, carry, a_idx, lane_base);  // (issued beside the LDS reads above)
         if (kDirect && t == 0 && mine && a_idx == 0) {  // the env's leader lane publishes the flags and counters the other
             // phases read (from its registers; LDS stores issued while the reads above are in flight)
@@ -1000,7 +1017,10 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             }
             wave_sync();
 #pragma unroll
-            for (int q = 0; q < QS; ++q) qv[q] = s_queue[e * KQ + min(a_idx + q * KN, KQ - 1)];  // a request may have been replaced
+            for (int q = 0; q < QS; ++q) {  // a request may have been replaced
+                if (Cfg::kQrt && q * KN >= KQ) continue;
+                qv[q] = s_queue[eq + (Cfg::kQrt ? max(min(a_idx + q * KN, KQ - 1), 0) : min(a_idx + q * KN, KQ - 1))];
+            }
         } else if (leader) {  // nothing on a goal: counters and termination from registers
             const int inact = ev_inact + 1, steps = ev_steps + 1;
             const int done = ((k_max_inactivity && inact >= k_max_inactivity) || (k_max_steps && steps >= k_max_steps)) ? 1 : 0;
@@ -1017,8 +1037,10 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // rebuilds their bitmap.
         if (mine) {
 #pragma unroll
-            for (int q = 0; q < QS; ++q)
+            for (int q = 0; q < QS; ++q) {
+                if (Cfg::kQrt && q * KN >= KQ) continue;  // (scalar)
                 if (a_idx + q * KN < KQ) atomicOr(&s_req[e * SW + (qv[q] >> 5)], 1u << (qv[q] & 31));
+            }
         }
     }
     } else {

@@ -24,7 +24,7 @@ struct StaticEntry {
     step_kernel_t fn, fn_rollout;
 };
 
-enum : int { kStaticGroups = 6 };
+enum : int { kStaticGroups = 7 };
 const StaticEntry *static_group(int group, int *n);   // rware_capi.hip's view: dispatches to the per-group tables below
 const StaticEntry *static_group_0(int *n);
 const StaticEntry *static_group_1(int *n);
@@ -32,6 +32,7 @@ const StaticEntry *static_group_2(int *n);
 const StaticEntry *static_group_3(int *n);
 const StaticEntry *static_group_4(int *n);
 const StaticEntry *static_group_5(int *n);
+const StaticEntry *static_group_6(int *n);
 
 }  // namespace rw_tab
 
@@ -79,6 +80,15 @@ namespace {
 #define RW_TINY_E32(N, Q) RW_STATIC(11, 10, N, Q, 32, 1, 16, 256, 16383), RW_STATIC(11, 10, N, Q, 32, 1, 32, 256, 0), RW_TINY(N, Q)
 #define RW_SMALL_E32(N, Q) RW_STATIC(20, 10, N, Q, 80, 1, 16, 256, 16383), RW_STATIC(20, 10, N, Q, 80, 1, 32, 256, 0), RW_SMALL(N, Q)
 #define RW_MEDIUM_E32(N, Q) RW_STATIC(20, 16, N, Q, 144, 1, 16, 256, 16383), RW_STATIC(20, 16, N, Q, 144, 1, 32, 256, 0), RW_MEDIUM(N, Q)
+
+// agent-count-static entries (Q == -1) with the geometry variants of their agent count
+#define RW_QRT_12(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 16, 256, 16383), RW_STATIC(H, W, N, -1, S, 1, 32, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 16, 256, 0)
+#define RW_QRT_34(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 16, 256, 0)
+// (these builds hold the run-time queue length and what depends on it in scalar registers — 104 SGPRs, 7 wavefronts per SIMD
+//  instead of 8 — so their 8-env variant serves batches of up to 7 workgroups per CU: 14336 envs, not 16384.  Forcing the
+//  register budget of 8 wavefronts (amdgpu_waves_per_eu) was measured: small-8ag B = 16384 12.73 -> 11.14 us, but +0.1 .. +0.4 us
+//  wherever the batch fits anyway — the spilled scalars cost more than they buy.)
+#define RW_QRT_58(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 8, 256, ((N) >= 7 ? 14336 : 8192)), RW_STATIC(H, W, N, -1, S, 1, 16, 256, 0)
 
 const StaticEntry kEntries[] = {
 #if RW_STATIC_GROUP == 0
@@ -129,6 +139,11 @@ const StaticEntry kEntries[] = {
     RW_STATIC(20, 10, 0, 0, 80, 1, 16, 256, 0),    // rware-small-*
     RW_STATIC(20, 16, 0, 0, 144, 1, 16, 256, 0),   // rware-medium-*
     RW_STATIC(29, 16, 0, 0, 224, 1, 16, 256, 0),   // rware-large-*
+#elif RW_STATIC_GROUP == 6
+    // ---- agent-count-static builds (Q == -1: request-queue length read at run time, any Q <= 2 N): the easy / normal / hard
+    // variants of a task and custom queue sizes share one build.  Geometry by the 64-agents-per-workgroup rule.
+    RW_QRT_12(20, 10, 80, 1), RW_QRT_12(20, 10, 80, 2), RW_QRT_34(20, 10, 80, 3), RW_QRT_34(20, 10, 80, 4),
+    RW_QRT_58(20, 10, 80, 5), RW_QRT_58(20, 10, 80, 6), RW_QRT_58(20, 10, 80, 7), RW_QRT_58(20, 10, 80, 8),
 #else
 #error "RW_STATIC_GROUP out of range"
 #endif
@@ -140,6 +155,9 @@ const StaticEntry kEntries[] = {
 #undef RW_STATIC_POS
 #undef RW_TINY
 #undef RW_TINY_E8
+#undef RW_QRT_12
+#undef RW_QRT_34
+#undef RW_QRT_58
 #undef RW_TINY_E32
 #undef RW_SMALL_E32
 #undef RW_MEDIUM_E32

@@ -43,6 +43,7 @@ namespace rw { extern int32_t smem[]; }
 inline unsigned long long wall_clock64() {
     return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10;
 }
+inline int __mul24(int a, int b) { return a * b; }  // (v_mul_i32_i24 on the GPU: both factors fit 24 bits where it is used)
 inline void __syncthreads() { pthread_barrier_wait(emu_barrier); }
 inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }

@@ -768,3 +768,55 @@ def test_seed_and_global_image_methods():
     img2 = env.get_global_image([2], recompute=True)
     assert img2.shape == (4, 1, 11, 10) and np.array_equal(img2[:, 0] > 0, env.get_state()["grid"][:, 0] > 0)
     env.close()
+
+
+@pytest.mark.parametrize("env_id,extra", [
+    ("rware-small-3ag-v1", {}), ("rware-small-5ag-easy-v1", {}), ("rware-small-7ag-hard-v1", {}), ("rware-small-1ag-hard-v1", {}),
+    ("rware-small-1ag-easy-v1", {}), ("rware-small-4ag-v1", {"request_queue_size": 5}), ("rware-small-6ag-v1", {"request_queue_size": 1}),
+    ("rware-small-8ag-v1", {"request_queue_size": 11}), ("rware-small-2ag-v1", {"request_queue_size": 3}),
+])
+def test_agent_count_static_builds_read_the_queue_length_at_run_time(env_id, extra):
+    """Tasks without an exact (N, Q) entry run the agent-count-static build of their size and agent count (Q == -1 in
+    rware_static_table.h: any queue length up to 2 N, the LDS carve-up reserves 2 N slots): against the oracle across an
+    autoreset, per-step launches and a fused rollout; Q = 0 (1 agent, hard) included."""
+    kw = rware_amd.env_kwargs(env_id)
+    kw.update(extra)
+    kw["max_steps"] = 18
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    B, N = 32, kw["n_agents"]
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, **kw)
+    assert env.engines[0].info.specialised == 1
+    assert env.engines[0].info.build_kind == 2 and env.engines[0].info.envs_per_workgroup == (8 if N >= 5 else 16)
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=14)[0], orc.reset(seed=14))
+    rng = np.random.default_rng(16)
+    for t in range(26):
+        a = rng.choice(5, size=(B, N), p=[.1, .5, .1, .1, .2]).astype(np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+    acts = rng.choice(5, size=(12, B, N), p=[.1, .5, .1, .1, .2]).astype(np.int32)
+    obs, rew, term = env.rollout(acts)
+    for k in range(12):
+        o2, r2, d2 = orc.step_autoreset(acts[k], "next_step")
+        assert np.array_equal(obs[k], o2) and np.array_equal(rew[k], r2) and np.array_equal(term[k], d2.astype(bool)), k
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    env.close()
+
+
+@pytest.mark.parametrize("name,tile", [("small-4ag", 4), ("small-8ag-global-inact", 16)])
+def test_agent_count_static_builds_replay_reference_golden(monkeypatch, name, tile):
+    """The reference's golden traces on the agent-count-static builds (RWARE_PREFER_QRT=1 makes rw_create skip the exact
+    (N, Q) entries of the task grid): deliveries, queue replacement and termination with the queue length a run-time value."""
+    monkeypatch.setenv("RWARE_PREFER_QRT", "1")
+    monkeypatch.setenv("RWARE_STATE_LAYOUT", "shadow")
+    meta, z = gu.load_fixture(name)
+    kw = gu.ctor_kwargs(meta)
+    if name == "small-4ag":
+        kw = dict(kw)
+    be = EngineBackend(meta["E"], library=LIB, tile=tile, **kw)
+    assert be.env.engines[0].info.build_kind == 2
+    assert gu.replay(be, meta, z, steps=200) > 0
+    be.env.close()
