@@ -104,7 +104,7 @@ namespace rw_tab {
 const StaticEntry *static_group(int group, int *n) {
     using fn_t = const StaticEntry *(*)(int *);
     static const fn_t kGroups[kStaticGroups] = {static_group_0, static_group_1, static_group_2, static_group_3, static_group_4, static_group_5,
-                                                static_group_6};
+                                                static_group_6, static_group_7, static_group_8, static_group_9};
     return kGroups[group](n);
 }
 }  // namespace rw_tab

@@ -24,7 +24,7 @@ struct StaticEntry {
     step_kernel_t fn, fn_rollout;
 };
 
-enum : int { kStaticGroups = 7 };
+enum : int { kStaticGroups = 10 };
 const StaticEntry *static_group(int group, int *n);   // rware_capi.hip's view: dispatches to the per-group tables below
 const StaticEntry *static_group_0(int *n);
 const StaticEntry *static_group_1(int *n);
@@ -33,6 +33,9 @@ const StaticEntry *static_group_3(int *n);
 const StaticEntry *static_group_4(int *n);
 const StaticEntry *static_group_5(int *n);
 const StaticEntry *static_group_6(int *n);
+const StaticEntry *static_group_7(int *n);
+const StaticEntry *static_group_8(int *n);
+const StaticEntry *static_group_9(int *n);
 
 }  // namespace rw_tab
 
@@ -89,6 +92,8 @@ namespace {
 //  register budget of 8 wavefronts (amdgpu_waves_per_eu) was measured: small-8ag B = 16384 12.73 -> 11.14 us, but +0.1 .. +0.4 us
 //  wherever the batch fits anyway — the spilled scalars cost more than they buy.)
 #define RW_QRT_58(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 8, 256, ((N) >= 7 ? 14336 : 8192)), RW_STATIC(H, W, N, -1, S, 1, 16, 256, 0)
+#define RW_QRT_SIZE(H, W, S) RW_QRT_12(H, W, S, 1), RW_QRT_12(H, W, S, 2), RW_QRT_34(H, W, S, 3), RW_QRT_34(H, W, S, 4), \
+                             RW_QRT_58(H, W, S, 5), RW_QRT_58(H, W, S, 6), RW_QRT_58(H, W, S, 7), RW_QRT_58(H, W, S, 8)
 
 const StaticEntry kEntries[] = {
 #if RW_STATIC_GROUP == 0
@@ -142,8 +147,13 @@ const StaticEntry kEntries[] = {
 #elif RW_STATIC_GROUP == 6
     // ---- agent-count-static builds (Q == -1: request-queue length read at run time, any Q <= 2 N): the easy / normal / hard
     // variants of a task and custom queue sizes share one build.  Geometry by the 64-agents-per-workgroup rule.
-    RW_QRT_12(20, 10, 80, 1), RW_QRT_12(20, 10, 80, 2), RW_QRT_34(20, 10, 80, 3), RW_QRT_34(20, 10, 80, 4),
-    RW_QRT_58(20, 10, 80, 5), RW_QRT_58(20, 10, 80, 6), RW_QRT_58(20, 10, 80, 7), RW_QRT_58(20, 10, 80, 8),
+    RW_QRT_SIZE(20, 10, 80),     // small
+#elif RW_STATIC_GROUP == 7
+    RW_QRT_SIZE(11, 10, 32),     // tiny
+#elif RW_STATIC_GROUP == 8
+    RW_QRT_SIZE(20, 16, 144),    // medium
+#elif RW_STATIC_GROUP == 9
+    RW_QRT_SIZE(29, 16, 224),    // large
 #else
 #error "RW_STATIC_GROUP out of range"
 #endif
@@ -156,6 +166,7 @@ const StaticEntry kEntries[] = {
 #undef RW_TINY
 #undef RW_TINY_E8
 #undef RW_QRT_12
+#undef RW_QRT_SIZE
 #undef RW_QRT_34
 #undef RW_QRT_58
 #undef RW_TINY_E32

@@ -774,6 +774,8 @@ def test_seed_and_global_image_methods():
     ("rware-small-3ag-v1", {}), ("rware-small-5ag-easy-v1", {}), ("rware-small-7ag-hard-v1", {}), ("rware-small-1ag-hard-v1", {}),
     ("rware-small-1ag-easy-v1", {}), ("rware-small-4ag-v1", {"request_queue_size": 5}), ("rware-small-6ag-v1", {"request_queue_size": 1}),
     ("rware-small-8ag-v1", {"request_queue_size": 11}), ("rware-small-2ag-v1", {"request_queue_size": 3}),
+    ("rware-tiny-3ag-v1", {}), ("rware-medium-5ag-easy-v1", {}), ("rware-large-7ag-v1", {}), ("rware-large-2ag-hard-v1", {}),
+    ("rware-large-4ag-v1", {}),
 ])
 def test_agent_count_static_builds_read_the_queue_length_at_run_time(env_id, extra):
     """Tasks without an exact (N, Q) entry run the agent-count-static build of their size and agent count (Q == -1 in

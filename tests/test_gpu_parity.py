@@ -811,3 +811,37 @@ def test_paper_task_grid_exact_shape_builds_match_oracle(env_id):
     for k in so:
         assert np.array_equal(st[k], so[k]), k
     env.close()
+
+
+OFF_GRID = ["rware-tiny-3ag-v1", "rware-tiny-7ag-easy-v1", "rware-small-1ag-hard-v1", "rware-small-5ag-v1", "rware-medium-3ag-hard-v1",
+            "rware-medium-7ag-v1", "rware-large-2ag-v1", "rware-large-4ag-easy-v1", "rware-large-6ag-hard-v1", "rware-large-8ag-v1"]
+
+
+@pytest.mark.parametrize("env_id", OFF_GRID)
+def test_agent_count_static_builds_match_oracle(env_id):
+    """Registered ids without an exact (N, Q) entry — odd agent counts, the large warehouse — run the agent-count-static
+    build of their size and agent count (request-queue length read at run time): against the oracle on every env, per-step
+    launches and a fused rollout, across autoresets."""
+    kw = rware_amd.env_kwargs(env_id)
+    kw["max_steps"] = 45
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    B, N = 512, kw["n_agents"]
+    env = rware_amd.WarehouseVecEnv(B, **kw)
+    assert env.engines[0].info.build_kind == 2
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=41)[0], orc.reset(seed=41))
+    rng = np.random.default_rng(9)
+    for t in range(60):
+        a = rng.choice(5, size=(B, N), p=[.1, .5, .1, .1, .2]).astype(np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+    acts = rng.choice(5, size=(40, B, N), p=[.1, .5, .1, .1, .2]).astype(np.int32)
+    obs, rew, term = env.rollout(acts)
+    for k in range(40):
+        o2, r2, d2 = orc.step_autoreset(acts[k], "next_step")
+        assert np.array_equal(obs[k], o2) and np.array_equal(rew[k], r2) and np.array_equal(term[k], d2.astype(bool)), k
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    env.close()
