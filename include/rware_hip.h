@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RW_ABI_VERSION 1
+#define RW_ABI_VERSION 2
 
 typedef struct rw_engine rw_engine;
 
@@ -78,7 +78,17 @@ enum rw_autoreset {
  * literally: NULL then means the default stream, and the engine's launches are ordered with everything
  * else the caller enqueues there (a policy writing the action tensor before, a learner reading the
  * observation tensor after) without any explicit synchronisation. */
-enum rw_stream_flags { RW_STREAM_USE_GIVEN = 1 };
+enum rw_stream_flags {
+    RW_STREAM_USE_GIVEN = 1,
+    /* How the observation stream is stored.  Default (neither bit): the engine decides — non-temporal stores (the observation
+     * lines are written once and not re-read by the engine: with the hint they do not displace the state the next step
+     * reads) wherever that was measured faster, which is everywhere except workgroups with a large observation chunk
+     * (16 agents) below the Infinity Cache size.  A learner that reads the observations right behind the step finds
+     * non-temporal lines in HBM rather than in the cache: RW_OBS_STORES_CACHED keeps them cached, RW_OBS_STORES_STREAM forces
+     * the hint.  (Also RWARE_OBS_STORES=cached|stream in the environment, for A/B runs.) */
+    RW_OBS_STORES_CACHED = 2,
+    RW_OBS_STORES_STREAM = 4
+};
 
 /* Device buffers (all env-major, C-contiguous).  Replaces the attributes callers read off the
  * reference object: env.grid (:302), env.agents[i].{x,y,dir,carrying_shelf,has_delivered}
@@ -252,6 +262,8 @@ typedef struct rw_info {
     int64_t algorithmic_bytes_per_env_step; /* SURVEY.md §8(d) formula                           */
     char device_name[128];
     char arch_name[64];
+    int32_t obs_stores_stream; /* 1: the observation stream is stored with the non-temporal hint (rw_stream_flags) */
+    int32_t reserved[7];
 } rw_info;
 int rw_get_info(const rw_engine *eng, rw_info *out);
 

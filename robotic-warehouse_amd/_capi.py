@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "librware_hip.so")
 
-RW_ABI_VERSION = 1
+RW_ABI_VERSION = 2
 RW_OK, RW_ERR_INVALID_ARG, RW_ERR_INVALID_ACTION, RW_ERR_HIP, RW_ERR_UNSUPPORTED, RW_ERR_NO_DEVICE, RW_ERR_INDEX = 0, -1, -2, -3, -4, -5, -6
 
 BUF = {
@@ -27,6 +27,7 @@ BUF_DTYPE = {
 }
 
 RW_STREAM_USE_GIVEN = 1  # rw_stream_flags: `stream` is taken literally, NULL == the device's default stream
+RW_OBS_STORES_CACHED, RW_OBS_STORES_STREAM = 2, 4  # rw_stream_flags: keep the observation lines cached / force the non-temporal hint
 
 AUTORESET = {"disabled": 0, None: 0, "next_step": 1, "same_step": 2}
 
@@ -47,7 +48,7 @@ class RwInfo(C.Structure):
         "envs_per_workgroup", "threads_per_workgroup", "n_workgroups", "lds_bytes", "device_id",
         "compute_units", "specialised", "state_layout", "build_kind")] + [
         ("algorithmic_bytes_per_env_step", C.c_int64),
-        ("device_name", C.c_char * 128), ("arch_name", C.c_char * 64)]
+        ("device_name", C.c_char * 128), ("arch_name", C.c_char * 64), ("obs_stores_stream", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 EXPORTS = (
@@ -161,7 +162,7 @@ class Engine:
                  max_inactivity_steps, max_steps, reward_type, normalised_coordinates=False,
                  autoreset_mode="next_step", device_id=0, envs_per_workgroup=0,
                  threads_per_workgroup=0, stream=None, library=None, observation_type=1,
-                 image_layers=(), image_directional=True, msg_bits=0, use_given_stream=False):
+                 image_layers=(), image_directional=True, msg_bits=0, use_given_stream=False, obs_stores=None):
         self.lib = load(library)
         self._h = C.c_void_p()
         self._arena, self.arena_allocations = {}, 0  # rollout_host's device tapes (grow-only; freed in close())
@@ -173,7 +174,8 @@ class Engine:
             int(reward_type), int(bool(normalised_coordinates)), AUTORESET[autoreset_mode], len(layout.goals),
             int(device_id), int(envs_per_workgroup), int(threads_per_workgroup),
             int(observation_type), int(bool(image_directional)), len(image_layers),
-            (C.c_int32 * 8)(*[int(l) for l in image_layers]), int(msg_bits), RW_STREAM_USE_GIVEN if use_given_stream else 0,
+            (C.c_int32 * 8)(*[int(l) for l in image_layers]), int(msg_bits),
+            (RW_STREAM_USE_GIVEN if use_given_stream else 0) | {None: 0, "auto": 0, "cached": RW_OBS_STORES_CACHED, "stream": RW_OBS_STORES_STREAM}[obs_stores],
             hw.ctypes.data, goals.ctypes.data, C.c_void_p(stream or 0))
         rc = self.lib.rw_create(C.byref(cfg), C.byref(self._h))
         if rc != RW_OK:

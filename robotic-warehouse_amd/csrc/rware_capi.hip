@@ -48,6 +48,7 @@ struct rw_engine {
     hipEvent_t h_actions_free = nullptr;  // recorded after the staging buffer's copy to the device
     void (*kernel)(const rw::Params *, const int32_t *, const int32_t, const int32_t, float *, float *, uint8_t *, const uint8_t *, uint64_t *, const int64_t, const int64_t, const int64_t, const int64_t) = nullptr;  // the step kernel instance this engine launches
     void (*kernel_rollout)(const rw::Params *, const int32_t *, const int32_t, const int32_t, float *, float *, uint8_t *, const uint8_t *, uint64_t *, const int64_t, const int64_t, const int64_t, const int64_t) = nullptr;  // its fused multi-step (rollout) sibling
+    rw_tab::step_kernel_t kernel_nt = nullptr;  // the per-step kernel with non-temporal observation stores, where the build has one
     rw::Params *d_prm = nullptr;  // device copy of `prm` (constant for the engine's lifetime)
     rw::LaunchArgs la{};          // per-launch defaults: the engine's own output buffers
     bool specialised = false;
@@ -427,6 +428,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             E = best->E;
             T = best->T;
             eng->kernel = best->fn;
+            eng->kernel_nt = best->fn_nt;
             eng->kernel_rollout = best->fn_rollout;
             eng->specialised = true;
             eng->pos_layout = best->pos != 0;
@@ -448,6 +450,9 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->lds_bytes);
         if (lds_err == hipSuccess)
             lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(eng->kernel_rollout),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->lds_bytes);
+        if (lds_err == hipSuccess && eng->kernel_nt)
+            lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(eng->kernel_nt),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->lds_bytes);
         RW_HIP_C(lds_err);
     }
@@ -528,6 +533,24 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.autoreset = cfg->autoreset_mode;
     p.normalised = cfg->normalised_coordinates ? 1 : 0;
     p.envs_per_wg = E;
+    {
+        // Observation stores: non-temporal (stream) or cached.  Measured rule (round 3, same-box A/Bs, profiles/EXPERIMENTS.md):
+        // the hint wins wherever the workgroup runs in service-wave mode (a small observation chunk: every registered task
+        // except the 16-agent ones — small-4ag B = 16384 7.13 -> 6.17 us, medium-6ag-hard 7.25 -> 6.26) and wherever a step's
+        // observations outgrow the Infinity Cache (large-16ag r=2 B = 32768 88.7 -> 81.6); it loses for large observation
+        // chunks below that size (large-16ag r=2 B = 16384 36.2 -> 43.1).
+        const long long chunk = (long long)E * N * eng->L;                    // floats of one workgroup's observations
+        const bool service_wave = T == 256 && chunk <= 8192;                    // (the kernel's `split`)
+        const double obs_mb = (double)B * N * eng->L * 4 / 1e6;
+        bool nt = service_wave || obs_mb > 240.0;
+        const char *pref = getenv("RWARE_OBS_STORES");
+        if (cfg->stream_flags & RW_OBS_STORES_CACHED) nt = false;
+        if (cfg->stream_flags & RW_OBS_STORES_STREAM) nt = true;
+        if (pref && !strcmp(pref, "cached")) nt = false;
+        if (pref && !strcmp(pref, "stream")) nt = true;
+        p.nt_obs = nt ? 1 : 0;
+        if (nt && eng->kernel_nt) eng->kernel = eng->kernel_nt;  // (exact builds: the choice is a kernel, not a branch)
+    }
     p.magic_n = rw::rw_magic18(N);
     p.groups_per_wave = 64 / N;
     p.HWW = HWW;
@@ -960,6 +983,7 @@ int rw_get_info(const rw_engine *eng, rw_info *out) {
     out->specialised = eng->specialised ? 1 : 0;
     out->state_layout = eng->pos_layout ? 1 : 0;
     out->build_kind = eng->build_kind;
+    out->obs_stores_stream = p.nt_obs;
     // A = 8HW + 4N + 40N + 4Q + 16 + 4NL + 4N + 4
     out->algorithmic_bytes_per_env_step =
         8LL * p.HW + 4LL * p.N + 40LL * p.N + 4LL * p.Q + 16 + 4LL * p.N * eng->L + 4LL * p.N + 4;

@@ -46,6 +46,12 @@ template <typename... Ts>
 __device__ __forceinline__ void keep_sgpr_ptr(Ts... p) {
     (keep_sgpr_ptr1(p), ...);
 }
+// store_f4_nt(dst, v): a 16-byte store with the non-temporal hint (global_store_dwordx4 ... nt)
+__device__ __forceinline__ void store_f4_nt(float4 *dst, float4 v) {
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    f4_t vv = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(vv, reinterpret_cast<f4_t *>(dst));
+}
 // opaque(x): the value, with everything the optimiser knew about its bits forgotten
 __device__ __forceinline__ uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
 // uniform(x): tells the compiler a value is wave-uniform (v_readfirstlane), so tests on it become scalar branches

@@ -99,6 +99,7 @@ struct Params {
     int32_t HWW;                       // dwords of the highway bitmap = (HW+31)/32
     int32_t n_goals, max_inactivity, max_steps, reward_type, autoreset, normalised;
     int32_t envs_per_wg;
+    int32_t nt_obs;                    // 1: the observation stream is stored with the non-temporal hint (see ST)
     int32_t groups_per_wave;           // envs whose agents share one wavefront = 64 / N
     uint32_t magic_n;                  // ceil(2^18 / N): x / N == (x * magic) >> 18 for x * N < 2^18
     int32_t goal_cells[MAX_GOALS];     // cell index y*W+x per goal, list order
@@ -228,6 +229,7 @@ struct DynamicCfg {
     static constexpr int kH = 0, kW = 0, kN = 0, kQ = 0, kS = 0, kE = 0, kT = 0, kM = 0;
     static constexpr bool kQrt = false;
     static constexpr int kQcap = 0;
+    static constexpr int kNT = -1;   // observation stores: cached or non-temporal by Params::nt_obs, at run time
     static constexpr int kNL = 0, kDirectional = -1;
     static constexpr uint32_t kLayers = 0;
     static constexpr bool kPos = false;
@@ -237,8 +239,13 @@ struct DynamicCfg {
 // POS_: the shelf layer lives in HBM as one cell index per shelf (Params::shelf_pos) instead of one shelf id per cell
 // (the shadow): 80 instead of 200 bytes per small-4ag env to stage in, and a write-back that is one coalesced store of
 // whole lines instead of scattered 1-byte patches — the layout for batches whose traffic no longer fits the Infinity Cache.
-template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_, int M_ = 0, int NL_ = 0, uint32_t LAYERS_ = 0, int DIR_ = -1, bool POS_ = false>
+// NT_: how the observation stream is stored — 0 cached, 1 with the non-temporal hint (two builds of the per-step kernel, picked
+// by rw_create), -1 by Params::nt_obs at run time (the size-static builds: two copies of the expansion pass in one kernel
+// cost 2 % at the headline batch and 9 % past the Infinity Cache, measured, so the exact builds do not do that).
+template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_, int M_ = 0, int NL_ = 0, uint32_t LAYERS_ = 0, int DIR_ = -1, bool POS_ = false,
+          int NT_ = 0>
 struct StaticCfg {
+    static constexpr int kNT = N_ == 0 ? -1 : NT_;
     // Q_ < 0 (with N_ != 0): an "agent-count-static" build — everything of an exact-shape build except the request-queue
     // length, which is read at run time (any Q <= 2 N_: the easy / normal / hard variants of a task and custom queue sizes
     // share ONE build).  The LDS carve-up reserves the 2 N_ slots, so every offset stays a compile-time constant.
@@ -416,7 +423,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     const uint32_t *const q_hw = p.highway_bits;
     const uint8_t *const q_need = p.need_reset;
     const int k_reward_type = p.reward_type, k_max_inactivity = p.max_inactivity, k_max_steps = p.max_steps;
-    const int k_autoreset = p.autoreset, k_n_goals = p.n_goals, k_normalised = p.normalised;
+    const int k_autoreset = p.autoreset, k_n_goals = p.n_goals, k_normalised = p.normalised, k_nt = p.nt_obs;
     const int k_goal0 = p.goal_cells[0], k_goal1 = p.goal_cells[1];
     // (exact-shape builds whose LDS carve-up is a compile-time constant clear their scratch regions while this batch is in
     //  flight and pin it afterwards — kClearFirst, below; the others pin it here)
@@ -427,7 +434,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                                  Cfg::kN != 0 && Cfg::kE != 0 && (!kImage || Cfg::kNL > 0) && (!kMsg || Cfg::kM != 0);
     if constexpr (!kClearFirst) {
         keep_sgpr_ptr(g_shadow, q_rec, q_queue, q_steps, q_inact, q_hw, q_need);
-        keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
+        keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised, k_nt);
         if constexpr (Cfg::kQrt) keep_sgpr(Q);  // (the stage-in of the queue needs it)
     }
     // IMAGE kernels: the layer list and its switches belong to the same batch — the image gather used to fetch them where
@@ -514,7 +521,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
     if constexpr (kClearFirst) {  // the LDS clear needs no parameter: it runs under the scalar batch's (cold) round trip
         clear_scratch();
         keep_sgpr_ptr(g_shadow, q_rec, q_queue, q_steps, q_inact, q_hw, q_need);
-        keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
+        keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised, k_nt);
     }
     const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : q_need;  // OP_RESET: all-ones when no mask was given
     int r_x = 0, r_y = 0, r_d = 0, r_carry = 0, r_deliv = 0, r_act = ACT_NOOP, r_flag = 0, r_steps = 0, r_inact = 0;
@@ -704,7 +711,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         unpack_records();
         lds_barrier();
     }
-    keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised);
+    keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised, k_nt);
     if constexpr (Cfg::kQrt) keep_sgpr(Q);
     RW_MARK(TL_LOADED);
 
@@ -1576,8 +1583,13 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // 16-byte store at (uniform) out + a per-lane byte offset the optimiser cannot take apart: it then keeps
         // the scalar-base form of the store instead of rebuilding a 64-bit per-lane address for every pass.
         // (Not inline asm: hipcc must see the store to respect the write-data hazard of 128-bit stores.)
-        auto store4 = [&](uint32_t byte_off, float4 v) {
-            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(out) + (size_t)opaque(byte_off)) = v;
+        // `nt` (a std::bool_constant tag): store with the non-temporal hint.  Whole 128-byte lines written exactly once are a
+        // pure stream; with the hint they no longer displace the state the next launch reads back, and at the headline batch
+        // the step goes 7.13 -> 6.17 us, past the Infinity Cache 70.2 -> 60.2 us (round 3; round 1 measured the opposite on
+        // the old two-pass expansion, whose second pass re-touched lines).  Per engine, by Params::nt_obs (rw_create's rule).
+        auto store4 = [&](auto nt, uint32_t byte_off, float4 v) {
+            float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<char *>(out) + (size_t)opaque(byte_off));
+            if constexpr (decltype(nt)::value) store_f4_nt(dst, v); else *dst = v;
         };
         auto expand = [&](int q4) -> float4 {  // float4 #q4 of the chunk == nibble #q4 of the bit string
             return spread((s_obits[q4 >> 3] >> ((q4 & 7) << 2)) & 0xFu);
@@ -1595,11 +1607,17 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // (the coordinates travel as bytes: layouts wider or taller than 256 cells take the two-pass form as well — a
         //  compile-time fact in the exact-shape and size-static builds)
         const bool xy_bytes = !kRollout && !k_normalised && W <= 256 && H <= 256;  // workgroup-uniform
-        if (worker && xy_bytes) {
-            const int shift = (tid & 7) << 2, words_per_pass = TW >> 3;  // (TW % 8 == 0)
-            const uint32_t *wp = s_obits + (tid >> 3);
+        auto single_pass = [&](auto nt) {
+            // (the thread index through an opaque copy: otherwise the address arithmetic of BOTH copies of the pass is hoisted in
+            //  front of the branch that picks one — large-16ag r=2: 102 VGPRs instead of 60, 4 workgroups per CU instead of 7)
+            // (only in the builds that hold both copies: with one copy the hoisting is wanted — the address arithmetic then runs
+            //  while the workgroup waits at the bit-string barrier)
+            int tq = tid;
+            if constexpr (Cfg::kNT < 0) asm volatile("" : "+v"(tq));
+            const int shift = (tq & 7) << 2, words_per_pass = TW >> 3;  // (TW % 8 == 0)
+            const uint32_t *wp = s_obits + (tq >> 3);
             const int dm = (4 * TW) % L, di = (4 * TW) / L;
-            int m = (4 * tid + 3) % L, ai = (4 * tid + 3) / L;
+            int m = (4 * tq + 3) % L, ai = (4 * tq + 3) / L;
             const int passes = (nf4 + TW - 1) / TW;  // a compile-time constant in the specialised builds (full unroll)
             // in groups of 8 passes: first the LDS reads of all 8 in one unconditional batch (a read past the string still
             // lands inside the workgroup's LDS; the agent index is clamped), then the 8 expansions
@@ -1619,7 +1637,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (k0 + j >= passes) break;
-                    const int q4 = tid + (k0 + j) * TW;
+                    const int q4 = tq + (k0 + j) * TW;
                     if (q4 < nf4) {
                         const uint32_t bits = (((wv[j] >> shift) & 0xFu) * 0x00204081u) & 0x01010101u;
                         // x goes to byte 3 - m, y to byte 4 - m of this float4 (m == 4: x was the last float of the one before)
@@ -1630,9 +1648,16 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                         v.y = (float)((b >> 8) & 0xFFu);
                         v.z = (float)((b >> 16) & 0xFFu);
                         v.w = (float)(b >> 24);
-                        store4((uint32_t)q4 << 4, v);
+                        store4(nt, (uint32_t)q4 << 4, v);
                     }
                 }
+            }
+        };
+        if (worker && xy_bytes) {
+            if constexpr (Cfg::kNT == 1) single_pass(std::true_type{});
+            else if constexpr (Cfg::kNT == 0) single_pass(std::false_type{});
+            else {  // (two copies of the pass, one taken: a scalar branch on a workgroup-uniform flag)
+                if (k_nt) single_pass(std::true_type{}); else single_pass(std::false_type{});
             }
         }
         // normalised coordinates are fractions: bulk pass over every float4 that holds no coordinate slot (all but ~2 in
@@ -1651,7 +1676,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 for (int j = 0; j < 8; ++j) {
                     if (k0 + j >= passes) break;
                     const int q4 = tid + (k0 + j) * TW;
-                    if (q4 < nf4 && m >= 5) store4((uint32_t)q4 << 4, spread((wv[j] >> shift) & 0xFu));
+                    if (q4 < nf4 && m >= 5) store4(std::false_type{}, (uint32_t)q4 << 4, spread((wv[j] >> shift) & 0xFu));
                     m += dm;
                     m = (m >= L) ? m - L : m;
                 }
@@ -1700,7 +1725,10 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
                 v.y = (float)((b >> 8) & 0xFFu);
                 v.z = (float)((b >> 16) & 0xFFu);
                 v.w = (float)(b >> 24);
-                *reinterpret_cast<float4 *>(reinterpret_cast<char *>(out) + (size_t)opaque((uint32_t)q4 << 4)) = v;
+                float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<char *>(out) + (size_t)opaque((uint32_t)q4 << 4));
+                // (AGENT_DIRECTION patches its cells afterwards: cached)
+                const bool nt = Cfg::kNT == 1 ? true : Cfg::kNT == 0 ? false : (k_nt != 0);
+                if (nt && !(k_transposed & 1)) store_f4_nt(dst, v); else *dst = v;
             }
         }
         if (worker)

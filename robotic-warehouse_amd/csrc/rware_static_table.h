@@ -22,6 +22,7 @@ struct StaticEntry {
     int pos;    // 1: POSITION state layout (rw::StaticCfg POS_), picked for batches of at least `min_B` envs
     int min_B;
     step_kernel_t fn, fn_rollout;
+    step_kernel_t fn_nt;  // the per-step kernel with non-temporal observation stores (nullptr: `fn` switches at run time)
 };
 
 enum : int { kStaticGroups = 10 };
@@ -42,25 +43,32 @@ const StaticEntry *static_group_9(int *n);
 #ifdef RW_STATIC_GROUP  // ------------------------------------------------------------ only inside rware_static.hip
 namespace rw_tab {
 namespace {
+// (fn_nt: the same per-step kernel with NT_ = 1; size-static entries, N == 0, switch at run time and carry nullptr)
+#define RW_NT_OR_NULL(N, ...) ((N) != 0 ? (step_kernel_t)__VA_ARGS__ : (step_kernel_t) nullptr)
 #define RW_STATIC(H, W, N, Q, S, R, E, T, MAXB)                                                                   \
     {H, W, N, Q, S, R, E, T, MAXB, 0, 0, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true>}
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true>,                   \
+     RW_NT_OR_NULL(N, rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, false, 1>, false>)}
 #define RW_STATIC_IMAGE(H, W, N, Q, S, R, E, T, MAXB)                                                             \
     {H, W, N, Q, S, R, E, T, MAXB, 1, 0, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false, rw::OBS_IMAGE>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true, rw::OBS_IMAGE>}
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true, rw::OBS_IMAGE>,   \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, false, 1>, false, rw::OBS_IMAGE>}
 // ... with the layer list and the directional switch baked in (the gather's per-layer selects fold away)
 #define RW_STATIC_IMAGE_LAYERS(H, W, N, Q, S, R, E, T, MAXB, NL, LAYERS, DIR)                                      \
     {H, W, N, Q, S, R, E, T, MAXB, 1, 0, NL, LAYERS, DIR, 0, 0,                                                     \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, false, rw::OBS_IMAGE>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, true, rw::OBS_IMAGE>}
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, true, rw::OBS_IMAGE>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR, false, 1>, false, rw::OBS_IMAGE>}
 #define RW_STATIC_MSG(H, W, N, Q, S, R, E, T, MAXB, M)                                                            \
     {H, W, N, Q, S, R, E, T, MAXB, 0, M, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, false, rw::OBS_FLATTENED_MSG>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, true, rw::OBS_FLATTENED_MSG>}
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, true, rw::OBS_FLATTENED_MSG>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M, 0, 0u, -1, false, 1>, false, rw::OBS_FLATTENED_MSG>}
 // FLATTENED builds on the POSITION state layout, for batches of at least MINB envs (a step's traffic past the Infinity Cache)
 #define RW_STATIC_POS(H, W, N, Q, S, R, E, T, MINB)                                                                \
     {H, W, N, Q, S, R, E, T, 0, 0, 0, 0, 0u, -1, 1, MINB,                                                           \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true>, false>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true>, true>}
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true>, true>, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true, 1>, false>}
 // the three registered warehouse sizes of the RWARE papers (rware/__init__.py:7-12): grid, shelves
 #define RW_TINY(N, Q) RW_STATIC(11, 10, N, Q, 32, 1, 16, 256, 0)
 #define RW_SMALL(N, Q) RW_STATIC(20, 10, N, Q, 80, 1, 16, 256, 0)
@@ -159,6 +167,7 @@ const StaticEntry kEntries[] = {
 #endif
 };
 #undef RW_STATIC
+#undef RW_NT_OR_NULL
 #undef RW_STATIC_IMAGE
 #undef RW_STATIC_IMAGE_LAYERS
 #undef RW_STATIC_MSG

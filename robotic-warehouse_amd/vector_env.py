@@ -121,7 +121,8 @@ class WarehouseVecEnv(_VectorEnvBase):
                  image_observation_layers=None, image_observation_directional: bool = True,
                  normalised_coordinates: bool = False, render_mode=None, *,
                  autoreset_mode: str = "next_step", devices=None, output: str = "numpy",
-                 envs_per_workgroup: int = 0, threads_per_workgroup: int = 0, library: str | None = None):
+                 envs_per_workgroup: int = 0, threads_per_workgroup: int = 0, library: str | None = None,
+                 obs_stores: str | None = None):
         if not 0 <= int(msg_bits) <= 16:
             raise ValueError("msg_bits must be in 0..16")
         self.msg_bits = int(msg_bits)
@@ -192,7 +193,10 @@ class WarehouseVecEnv(_VectorEnvBase):
                 stream=stream, use_given_stream=(output == "torch"), library=library,
                 observation_type=engine_obs_type.value,
                 image_layers=[l.value for l in layers] if image else (),
-                image_directional=image_observation_directional, msg_bits=self.msg_bits))
+                image_directional=image_observation_directional, msg_bits=self.msg_bits,
+                # None / "auto": the engine's measured rule; "cached": observation lines stay in the cache hierarchy for a
+                # learner that reads them right behind the step; "stream": non-temporal stores (rw_stream_flags)
+                obs_stores=obs_stores))
         self._bounds = [b for b in self._bounds if b[1] > b[0]]
         self.shard_bounds = list(self._bounds)  # env range [lo, hi) of every engine / device, in order
         self.devices = devices[: len(self.engines)]

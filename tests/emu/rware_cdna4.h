@@ -27,6 +27,7 @@ template <typename... Ts> inline void keep_sgpr(const Ts &...) {}
 template <typename... Ts> inline void keep_sgpr_ptr(const Ts &...) {}
 inline void keep_vgpr(int, int) {}
 inline uint32_t opaque(uint32_t x) { return x; }
+inline void store_f4_nt(float4 *dst, float4 v) { *dst = v; }  // (the hint has no host meaning)
 inline int uniform(int x) { return x; }
 inline void lds_barrier() { pthread_barrier_wait(emu_barrier); }
 inline void wave_sync() { pthread_barrier_wait(emu_wave_barrier); }

@@ -822,3 +822,23 @@ def test_agent_count_static_builds_replay_reference_golden(monkeypatch, name, ti
     assert be.env.engines[0].info.build_kind == 2
     assert gu.replay(be, meta, z, steps=200) > 0
     be.env.close()
+
+
+def test_observation_store_policy_is_a_create_time_choice():
+    """rw_stream_flags RW_OBS_STORES_CACHED / _STREAM (and the engine's own rule when neither is given) only change HOW the
+    observation lines are stored; rw_info reports the choice, the results are the same."""
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    envs = {pol: rware_amd.WarehouseVecEnv(16, library=LIB, obs_stores=pol, **kw) for pol in (None, "cached", "stream")}
+    assert envs[None].engines[0].info.obs_stores_stream == 1       # service-wave workgroups: the hint by default
+    assert envs["cached"].engines[0].info.obs_stores_stream == 0 and envs["stream"].engines[0].info.obs_stores_stream == 1
+    big = rware_amd.WarehouseVecEnv(8, library=LIB, **dict(rware_amd.env_kwargs("rware-large-16ag-v1"), sensor_range=2))
+    assert big.engines[0].info.obs_stores_stream == 0              # a large observation chunk per workgroup, below the cache size
+    big.close()
+    obs = {pol: e.reset(seed=2)[0] for pol, e in envs.items()}
+    rng = np.random.default_rng(0)
+    for t in range(6):
+        a = rng.integers(0, 5, size=(16, 4), dtype=np.int32)
+        obs = {pol: e.step(a)[0] for pol, e in envs.items()}
+        assert np.array_equal(obs[None], obs["cached"]) and np.array_equal(obs[None], obs["stream"])
+    for e in envs.values():
+        e.close()

@@ -845,3 +845,33 @@ def test_agent_count_static_builds_match_oracle(env_id):
     for k in so:
         assert np.array_equal(st[k], so[k]), k
     env.close()
+
+
+@pytest.mark.parametrize("env_id,extra,B", [("rware-small-4ag-v1", {}, 4096), ("rware-small-4ag-v1", {"observation_type": 2}, 2048),
+                                            ("rware-large-16ag-v1", {"sensor_range": 2}, 512), ("rware-small-12ag-v1", {}, 1024)])
+def test_observation_store_policy_does_not_change_results(env_id, extra, B):
+    """Non-temporal vs cached observation stores (two builds of the exact kernels, a run-time switch in the others): the
+    default rule, forced `cached` and forced `stream` give bit-identical steps against the oracle."""
+    kw = rware_amd.env_kwargs(env_id)
+    kw.update(extra)
+    kw["max_steps"] = 30
+    N = kw["n_agents"]
+    envs = {pol: rware_amd.WarehouseVecEnv(B, obs_stores=pol, **kw) for pol in (None, "cached", "stream")}
+    assert envs["cached"].engines[0].info.obs_stores_stream == 0 and envs["stream"].engines[0].info.obs_stores_stream == 1
+    okw = {k: v for k, v in kw.items() if k != "observation_type"}
+    okw["reward_type"] = rware_amd.enums.enum_value(okw["reward_type"])
+    orc = OracleVecEnv(B, **okw) if "observation_type" not in extra else None
+    obs = {pol: e.reset(seed=6)[0] for pol, e in envs.items()}
+    if orc is not None:
+        assert np.array_equal(obs[None], orc.reset(seed=6))
+    rng = np.random.default_rng(2)
+    for t in range(45):
+        a = rng.choice(5, size=(B, N), p=[.1, .5, .1, .1, .2]).astype(np.int32)
+        out = {pol: e.step(a) for pol, e in envs.items()}
+        for pol in ("cached", "stream"):
+            assert np.array_equal(out[None][0], out[pol][0]) and np.array_equal(out[None][1], out[pol][1]), (pol, t)
+        if orc is not None:
+            o2, r2, d2 = orc.step_autoreset(a, "next_step")
+            assert np.array_equal(out[None][0], o2) and np.array_equal(out[None][1], r2), t
+    for e in envs.values():
+        e.close()
