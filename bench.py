@@ -225,6 +225,7 @@ def hbm_regime_leg(torch, rware_amd, local_rank, env_id, sha):
             "peak": HBM_PEAK_GBPS, "peak_measured": HBM_MEASURED_GBPS, "unit_bw": "GB/s",
             "state_layout": "position" if int(getattr(info, "state_layout", 0)) else "shadow",
             "envs_per_workgroup": int(info.envs_per_workgroup), "kernel_specialised": bool(info.specialised),
+            "observation_stores": "non-temporal" if int(info.obs_stores_stream) else "cached",
         }
         if note:
             out["traffic_note"] = note
@@ -487,7 +488,9 @@ def main():
                                   else "a HIP graph holding one pass over the action tape (captured rw_step_tape_device), replayed"
                                   if args.submit == "graph" else "one Python/ctypes call per step"),
                 "envs_per_workgroup": int(info.envs_per_workgroup), "threads_per_workgroup": int(info.threads_per_workgroup),
-                "kernel_specialised": bool(info.specialised),
+                "kernel_specialised": bool(info.specialised), "kernel_build_kind": int(info.build_kind),
+                "observation_stores": "non-temporal (the engine's default rule for this shape; rw_stream_flags / obs_stores= overrides)"
+                                      if int(info.obs_stores_stream) else "cached",
                 "device": info.device_name.decode(), "arch": info.arch_name.decode(),
             },
             "roofline": {
