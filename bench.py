@@ -223,7 +223,6 @@ def hbm_regime_leg(torch, rware_amd, local_rank, env_id, sha):
             "frac_physical": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
             "frac_physical_of_measured_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_MEASURED_GBPS) if traffic else None,
             "peak": HBM_PEAK_GBPS, "peak_measured": HBM_MEASURED_GBPS, "unit_bw": "GB/s",
-            "state_layout": "position" if int(getattr(info, "state_layout", 0)) else "shadow",
             "envs_per_workgroup": int(info.envs_per_workgroup), "kernel_specialised": bool(info.specialised),
             "observation_stores": "non-temporal" if int(info.obs_stores_stream) else "cached",
         }

@@ -255,7 +255,8 @@ typedef struct rw_info {
     int32_t envs_per_workgroup, threads_per_workgroup, n_workgroups, lds_bytes;
     int32_t device_id, compute_units;
     int32_t specialised;  /* 1: a kernel build with this task's shapes folded in at compile time is in use */
-    int32_t state_layout; /* 0: the shelf layer is staged from the per-cell shadow; 1: from the per-shelf position array (big batches) */
+    int32_t state_layout; /* always 0 since round 3 (a per-shelf position layout for big batches existed in between: obsolete with
+                             non-temporal observation stores) */
     int32_t build_kind;   /* which build of the step kernel runs: 0 generic (every shape at run time), 1 exact-shape, 2 agent-count-
                              static (shapes + agent count folded in, request-queue length at run time), 3 size-static (grid folded in,
                              agent count and queue length at run time).  (Occupies what was alignment padding: same struct size.) */

@@ -59,11 +59,8 @@ struct rw_engine {
     void *slab = nullptr;      // the single device allocation behind every buffer below
     size_t shadow_off = 0;
     void *d_shadow = nullptr;  // compact shelf layer (uint8 when S <= 255, else uint16), the kernel's read path
-    size_t pos_off = 0;
-    uint8_t *d_pos = nullptr;  // [B][S] cell of every shelf: the shelf layer of the POSITION layout (pos_layout), else unused
     int build_kind = 0;        // rw_info::build_kind
     bool q_runtime = false;    // the chosen build reads the request-queue length at run time (StaticEntry::Q == -1)
-    bool pos_layout = false;   // the step kernels stage the shelf layer from d_pos; d_shadow is then a derived view (sync_shadow)
     bool wide = false;
     bool image = false;        // IMAGE / IMAGE_DICT observation kernels
     int msg_bits = 0;          // communication bits per agent (FLATTENED only)
@@ -135,22 +132,6 @@ int rebuild_shadow(rw_engine *eng) {
     else
         hipLaunchKernelGGL((rw::rware_shadow_kernel<uint8_t>), dim3(blocks), dim3(256), 0, eng->stream,
                            (const int32_t *)eng->buf[RW_BUF_GRID].ptr, (uint8_t *)eng->d_shadow, B, HW);
-    if (eng->pos_layout)  // the kernels read the shelf layer from the position array: bring it along
-        hipLaunchKernelGGL((rw::rware_pos_from_shadow_kernel<>), dim3(blocks), dim3(256), 0, eng->stream,
-                           (const uint8_t *)eng->d_shadow, eng->d_pos, B, HW, eng->prm.S);
-    RW_HIP(eng, hipGetLastError());
-    return RW_OK;
-}
-
-// POSITION layout: the shadow is a derived view of the position array; rebuilt before anything reads it
-int sync_shadow(rw_engine *eng) {
-    if (!eng->pos_layout) return RW_OK;
-    const int B = eng->prm.B, HW = eng->prm.HW, S = eng->prm.S;
-    const size_t n = (size_t)B * S;
-    const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    RW_HIP(eng, hipMemsetAsync(eng->d_shadow, 0, (size_t)B * HW, eng->stream));
-    hipLaunchKernelGGL((rw::rware_shadow_from_pos_kernel<>), dim3(blocks), dim3(256), 0, eng->stream,
-                       (const uint8_t *)eng->d_pos, (uint8_t *)eng->d_shadow, B, HW, S);
     RW_HIP(eng, hipGetLastError());
     return RW_OK;
 }
@@ -158,7 +139,6 @@ int sync_shadow(rw_engine *eng) {
 // RW_BUF_GRID is a derived view: brought up to date from the shelf shadow and the agent coordinates when it is asked for
 int refresh_grid(rw_engine *eng) {
     if (!eng->grid_stale) return RW_OK;
-    { const int rc = sync_shadow(eng); if (rc != RW_OK) return rc; }
     const int B = eng->prm.B, HW = eng->prm.HW, N = eng->prm.N;
     const size_t n = (size_t)B * HW, na = (size_t)B * N;
     // (grid-stride loops, one wavefront per workgroup, 64 cells / agents per thread: a few thousand workgroups at the big batches)
@@ -406,11 +386,6 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
                 const StaticEntry &se = tab[k_se];
                 if ((se.N != 0) != (exact != 0)) continue;
                 if (se.image != (eng->image ? 1 : 0) || se.M != eng->msg_bits) continue;
-                if (se.pos) {  // RWARE_STATE_LAYOUT=pos|shadow overrides the batch-size rule (test hook)
-                    const char *pref = getenv("RWARE_STATE_LAYOUT");
-                    const bool force = pref && !strcmp(pref, "pos"), never = pref && !strcmp(pref, "shadow");
-                    if (never || (!force && B < se.min_B)) continue;
-                }
                 if (se.NL > 0) {  // a baked-in layer list serves exactly that list
                     uint32_t packed = 0;
                     for (int l = 0; l < n_layers && l < 8; ++l) packed |= (uint32_t)layers[l] << (4 * l);
@@ -431,7 +406,6 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             eng->kernel_nt = best->fn_nt;
             eng->kernel_rollout = best->fn_rollout;
             eng->specialised = true;
-            eng->pos_layout = best->pos != 0;
             eng->q_runtime = best->Q < 0;
             eng->build_kind = best->N == 0 ? 3 : best->Q < 0 ? 2 : 1;
         }
@@ -440,7 +414,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     eng->T = T;
     eng->n_wg = (B + E - 1) / E;
     // (an agent-count-static build reserves 2 N queue slots per env in LDS whatever Q is)
-    eng->lds_bytes = sizeof(int32_t) * (size_t)rw::make_lds_layout(E, N, eng->q_runtime ? 2 * N : Q, HW, SW, eng->OW, cell_bytes, AM, eng->pos_layout ? S : 0).total;
+    eng->lds_bytes = sizeof(int32_t) * (size_t)rw::make_lds_layout(E, N, eng->q_runtime ? 2 * N : Q, HW, SW, eng->OW, cell_bytes, AM).total;
     if (eng->lds_bytes > 160 * 1024) {
         fail(eng, RW_ERR_INVALID_ARG, "LDS footprint %zu B exceeds 160 KiB; lower envs_per_workgroup", eng->lds_bytes);
         return bail(RW_ERR_INVALID_ARG);
@@ -492,8 +466,6 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         if (k == RW_BUF_ACTIONS) {  // the shelf shadow rides with the hot set
             eng->shadow_off = slab_bytes;
             slab_bytes += up(szB * HW * cell_bytes + 16);
-            eng->pos_off = slab_bytes;
-            slab_bytes += up(szB * S + 16);
         }
     }
     RW_HIP_C(hipMalloc(&eng->slab, slab_bytes));
@@ -501,7 +473,6 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     for (int k = 0; k < RW_BUF_KIND_COUNT; ++k) eng->buf[k].ptr = (char *)eng->slab + off[k];
     eng->d_shadow = (char *)eng->slab + eng->shadow_off;
     eng->d_rec = (uint32_t *)((char *)eng->slab + eng->rec_off);
-    eng->d_pos = (uint8_t *)eng->slab + eng->pos_off;
     const int HWW = (HW + 31) / 32;
     // the static kernels stage the bitmap in whole 16-byte pieces: allocate (and zero) the rounded-up size
     const size_t hw_bytes = sizeof(uint32_t) * (size_t)rw::rw_up4(HWW);
@@ -569,7 +540,6 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.steps = (int32_t *)eng->buf[RW_BUF_STEPS].ptr;
     p.inactive = (int32_t *)eng->buf[RW_BUF_INACTIVE].ptr;
     p.shelf_shadow = eng->d_shadow;
-    p.shelf_pos = eng->d_pos;
     p.rng = (uint64_t *)eng->buf[RW_BUF_RNG].ptr;
     p.need_reset = (uint8_t *)eng->buf[RW_BUF_NEED_RESET].ptr;
     p.truncated = (uint8_t *)eng->buf[RW_BUF_TRUNCATED].ptr;
@@ -790,7 +760,6 @@ std::vector<std::pair<void *, size_t>> state_pieces(rw_engine *eng) {
     v.emplace_back(eng->d_rec, (size_t)eng->prm.B * eng->prm.N * sizeof(uint32_t));  // the agents: their packed records
     for (int k : kinds) v.emplace_back(eng->buf[k].ptr, eng->buf[k].bytes);
     v.emplace_back(eng->d_shadow, (size_t)eng->prm.B * eng->prm.HW * (eng->wide ? 2 : 1));
-    if (eng->pos_layout) v.emplace_back(eng->d_pos, (size_t)eng->prm.B * eng->prm.S);
     return v;
 }
 }  // namespace
@@ -981,7 +950,7 @@ int rw_get_info(const rw_engine *eng, rw_info *out) {
     out->device_id = eng->cfg.device_id;
     out->compute_units = eng->prop.multiProcessorCount;
     out->specialised = eng->specialised ? 1 : 0;
-    out->state_layout = eng->pos_layout ? 1 : 0;
+    out->state_layout = 0;  // (the per-shelf position layout of round 2/3 is gone: with non-temporal observation stores the shadow wins at every batch size)
     out->build_kind = eng->build_kind;
     out->obs_stores_stream = p.nt_obs;
     // A = 8HW + 4N + 40N + 4Q + 16 + 4NL + 4N + 4

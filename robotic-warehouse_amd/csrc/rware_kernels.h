@@ -104,7 +104,6 @@ struct Params {
     uint32_t magic_n;                  // ceil(2^18 / N): x / N == (x * magic) >> 18 for x * N < 2^18
     int32_t goal_cells[MAX_GOALS];     // cell index y*W+x per goal, list order
     const int32_t *shelf_init;     // [HW] shelf layer right after reset: ids 1..S row-major on non-highway cells
-    uint8_t *shelf_pos;            // [B][S] cell of shelf id k+1 — the shelf layer of the POSITION state layout (Cfg::kPos), else unused
     // state (device)
     // exported int32 views RW_BUF_AGENT_X .. _DELIVERED: derived from `arec` on demand (rware_unpack_agents_kernel), never
     // touched by the step kernels — five store streams and five load streams per step that the step does not issue
@@ -166,7 +165,6 @@ struct LdsLayout {
     // LDS-DMA stream): shelf layer, agent arrays (the packed records land in `ax` and are unpacked in place; in the
     // kDirect builds the agent lanes publish them), actions, queue, highway bitmap, per-env counters/flags
     int gs, ax, ay, dir, carry, deliv, act, queue, hw, dsteps, dinact, dflag, dma_end;
-    int pos;  // POSITION layout: the chunk's shelf positions take the first DMA slot; `gs` then lies in the cleared block
     int ga, zero_end;  // cleared every launch
     int tgt, nxt, depth, win, rew, mv, msg, fx, fy, req, obits, envi, misc, total;
 };
@@ -178,14 +176,12 @@ RW_HD int rw_up4(int x) { return (x + 3) & ~3; }
 RW_HD uint32_t rw_magic18(int d) { return d > 0 ? (uint32_t)(((1u << 18) + (uint32_t)d - 1u) / (uint32_t)d) : 0u; }
 RW_HD int rw_div18(int x, uint32_t magic) { return (int)(((uint32_t)x * magic) >> 18); }
 
-RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int cell_bytes, int act_words = 1, int pos_shelves = 0) {
+RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int cell_bytes, int act_words = 1) {
     LdsLayout l;
     int o = 0;
     const int en = rw_up4(E * N);
-    l.pos = -1;
     l.gs = o;
-    if (pos_shelves) { l.pos = o; o += rw_up4((E * pos_shelves + 3) / 4); }   // 1 byte per shelf
-    else o += rw_up4((E * HW * cell_bytes + 3) / 4);  // shelf layer, CellT per cell
+    o += rw_up4((E * HW * cell_bytes + 3) / 4);  // shelf layer, CellT per cell
     l.ax = o;     o += en;
     l.ay = o;     o += en;
     l.dir = o;    o += en;
@@ -199,7 +195,6 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
     l.dflag = o;  o += rw_up4((E + 3) / 4);                    // bytes
     l.dma_end = o;
     l.ga = o;     o += rw_up4((E * HW + 3) / 4);               // agent layer, 1 byte per cell: id | 0x80 if loaded
-    if (pos_shelves) { l.gs = o; o += rw_up4((E * HW * cell_bytes + 3) / 4); }  // rebuilt from the positions every launch
     l.zero_end = o;
     l.tgt = o;    o += en;
     l.nxt = o;    o += en;
@@ -232,18 +227,13 @@ struct DynamicCfg {
     static constexpr int kNT = -1;   // observation stores: cached or non-temporal by Params::nt_obs, at run time
     static constexpr int kNL = 0, kDirectional = -1;
     static constexpr uint32_t kLayers = 0;
-    static constexpr bool kPos = false;
 };
 // M_: communication bits (the _MSG kernels).  NL_ / LAYERS_ / DIR_ (IMAGE kernels): a layer list baked in — NL_ layer ids,
 // 4 bits each, first layer in the low nibble — and the `image_observation_directional` switch; NL_ == 0: any list, at run time.
-// POS_: the shelf layer lives in HBM as one cell index per shelf (Params::shelf_pos) instead of one shelf id per cell
-// (the shadow): 80 instead of 200 bytes per small-4ag env to stage in, and a write-back that is one coalesced store of
-// whole lines instead of scattered 1-byte patches — the layout for batches whose traffic no longer fits the Infinity Cache.
 // NT_: how the observation stream is stored — 0 cached, 1 with the non-temporal hint (two builds of the per-step kernel, picked
 // by rw_create), -1 by Params::nt_obs at run time (the size-static builds: two copies of the expansion pass in one kernel
 // cost 2 % at the headline batch and 9 % past the Infinity Cache, measured, so the exact builds do not do that).
-template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_, int M_ = 0, int NL_ = 0, uint32_t LAYERS_ = 0, int DIR_ = -1, bool POS_ = false,
-          int NT_ = 0>
+template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_, int M_ = 0, int NL_ = 0, uint32_t LAYERS_ = 0, int DIR_ = -1, int NT_ = 0>
 struct StaticCfg {
     static constexpr int kNT = N_ == 0 ? -1 : NT_;
     // Q_ < 0 (with N_ != 0): an "agent-count-static" build — everything of an exact-shape build except the request-queue
@@ -254,7 +244,6 @@ struct StaticCfg {
     static constexpr int kH = H_, kW = W_, kN = N_, kQ = kQrt ? 0 : Q_, kS = S_, kE = E_, kT = T_, kM = M_;
     static constexpr int kNL = NL_, kDirectional = DIR_;
     static constexpr uint32_t kLayers = LAYERS_;
-    static constexpr bool kPos = POS_;
 };
 constexpr int packed_transposed_layers(uint32_t packed, int n) {  // Params::transposed_layers of a packed list
     int t = 0;
@@ -359,26 +348,6 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
     }
 }
 
-// POSITION state layout (Cfg::kPos): the two conversions between the position array and the shelf shadow the host paths use
-// (after a host write of the grid: shadow -> positions; before the grid view / a snapshot is built: positions -> a zeroed shadow)
-template <typename Dummy = void>
-__global__ void rware_pos_from_shadow_kernel(const uint8_t *shadow, uint8_t *pos, int B, int HW, int S) {
-    const size_t n = (size_t)B * HW;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t e = i / HW;
-        const int id = shadow[i];
-        if (id) pos[e * S + id - 1] = (uint8_t)(i - e * HW);
-    }
-}
-template <typename Dummy = void>
-__global__ void rware_shadow_from_pos_kernel(const uint8_t *pos, uint8_t *shadow, int B, int HW, int S) {
-    const size_t n = (size_t)B * S;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t e = i / S;
-        shadow[e * HW + pos[i]] = (uint8_t)(i - e * S + 1);
-    }
-}
-
 template <int R, typename CellT, typename Cfg, bool kRollout, int kObs = OBS_FLATTENED>
 __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L0 = 8 + 7 * CELLS, OW0 = (L0 + 31) / 32;
@@ -477,12 +446,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
 #endif
     RW_MARK(TL_START);
 
-    constexpr bool kPos = Cfg::kPos;  // shelf layer staged from / written back to the position array (see StaticCfg)
-    static_assert(!kPos || (kRegAG && Cfg::kE != 0 && sizeof(CellT) == 1 && Cfg::kH * Cfg::kW <= 256 && (Cfg::kE * Cfg::kS) % 16 == 0),
-                  "the position layout: exact-shape register builds, cell index in a byte, chunk 16-byte granular");
-    const LdsLayout lo = make_lds_layout(E, N, QL, HW, SW, OW, (int)sizeof(CellT), AM, kPos ? S : 0);
-    uint8_t *const s_pos = reinterpret_cast<uint8_t *>(smem + (kPos ? lo.pos : lo.gs));  // (kPos only)
-    uint8_t *const g_pos = p.shelf_pos;
+    const LdsLayout lo = make_lds_layout(E, N, QL, HW, SW, OW, (int)sizeof(CellT), AM);
     CellT *s_gs = reinterpret_cast<CellT *>(smem + lo.gs);
     uint8_t *s_ga = reinterpret_cast<uint8_t *>(smem + lo.ga);
     int32_t *s_ax = smem + lo.ax, *s_ay = smem + lo.ay, *s_dir = smem + lo.dir;
@@ -600,9 +564,9 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         // its HBM source is picked from the segment table (all pointers fetched in one scalar batch).
         static_assert((Cfg::kE * Cfg::kN) % 4 == 0 && (Cfg::kE * Cfg::kQcap) % 4 == 0 && Cfg::kE % 4 == 0, "chunk not 16-byte granular");
         static_assert(!kMsg || Cfg::kN == 0 || Cfg::kM != 0, "an exact-shape _MSG build needs its communication bits at compile time");
-        static_assert(kPos || (Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0, "shelf chunk not 16-byte granular");
+        static_assert((Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0, "shelf chunk not 16-byte granular");
         const char *src[12] = {
-            kPos ? reinterpret_cast<const char *>(g_pos + (size_t)e0 * S) : reinterpret_cast<const char *>(g_shadow + (size_t)e0 * HW),
+            reinterpret_cast<const char *>(g_shadow + (size_t)e0 * HW),
             // the chunk's packed records go to the `ax` slot and are unpacked in place behind the barrier (unpack_records);
             // the ay / dir / carry / deliv slots have no DMA source any more (entries 2..5 are skipped below)
             reinterpret_cast<const char *>(q_rec + (size_t)e0 * N), nullptr, nullptr, nullptr, nullptr,
@@ -611,7 +575,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             reinterpret_cast<const char *>(q_queue + (size_t)e0 * Q), reinterpret_cast<const char *>(q_hw),
             reinterpret_cast<const char *>(q_steps + e0), reinterpret_cast<const char *>(q_inact + e0),
             reinterpret_cast<const char *>(flag_src + e0)};
-        const int seg[13] = {kPos ? lo.pos : lo.gs, lo.ax, lo.ay, lo.dir, lo.carry, lo.deliv, lo.act, lo.queue, lo.hw,
+        const int seg[13] = {lo.gs, lo.ax, lo.ay, lo.dir, lo.carry, lo.deliv, lo.act, lo.queue, lo.hw,
                              lo.dsteps, lo.dinact, lo.dflag, lo.dma_end};  // dword offsets, all multiples of 4
         if constexpr (Cfg::kN != 0) {
             // One DMA instruction moves up to 64 pieces of ONE segment (LDS base + lane * 16), so the source
@@ -679,13 +643,6 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             unpack_records();
             lds_barrier();
         }
-        if constexpr (kPos) {  // the shelf layer of the chunk from its positions: one byte store per shelf into the cleared block
-            for (int k = tid; k < Cfg::kE * Cfg::kS; k += T) {
-                const int e = k / Cfg::kS;
-                s_gs[e * HW + s_pos[k]] = (CellT)(k - e * Cfg::kS + 1);
-            }
-            lds_barrier();
-        }
     } else {
         dma_in(smem + lo.gs, reinterpret_cast<const int32_t *>(g_shadow + (size_t)e0 * HW),
                (ne * HW * (int)sizeof(CellT) + 3) >> 2, tid, T);
@@ -739,12 +696,6 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         lds_barrier();  // the previous step's expansion has finished reading the bit string
         clear_scratch();
         lds_barrier();
-        if constexpr (kPos) {  // (the shelf layer lies in the cleared block: put it back from the positions, which are current)
-            for (int k = tid; k < Cfg::kE * Cfg::kS; k += T) {
-                const int e = k / Cfg::kS;
-                s_gs[e * HW + s_pos[k]] = (CellT)(k - e * Cfg::kS + 1);
-            }
-        }
         for (int e = tid; e < ne; e += T) {
             int32_t *ev = s_envi + e * ENVI_W;
             const int rs = (k_autoreset == AR_NEXT_STEP) ? ev[ENVI_DONE] : 0;
@@ -1002,7 +953,6 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         if (mcar) gS[st] = 0;  // incremental _recalc_grid (:749-755): clear phase ...
         wave_lds_order();
         if (mcar) gS[tg] = (CellT)carry;  // ... then set phase, for the whole wavefront in this order
-        if (kPos && mcar) s_pos[e * S + carry - 1] = (uint8_t)tg;  // position layout: where that shelf stands now
         // the agent layer was zeroed at the start of the step: final position only (id | 0x80 if loaded)
         if (mine && !ev_reset) gA[moved ? tg : st] = (uint8_t)((a_idx + 1) | (carry ? 0x80 : 0));
         // ------------------------------------------------------------ P5: goals, rewards, termination (:903-942)
@@ -1216,7 +1166,6 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;
             s_ga[c] = 0;
             s_gs[c] = (CellT)p.shelf_init[c - e * HW];
-            if (kPos && s_gs[c]) s_pos[e * S + (int)s_gs[c] - 1] = (uint8_t)(c - e * HW);
         }
         __syncthreads();
         for (int e = tid; e < ne; e += T) {
@@ -1254,7 +1203,7 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
         for (int c = tid; c < ne * HW; c += T) {
             const int e = c / HW;
             if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;
-            if (!kPos) g_shadow[(size_t)(e0 + e) * HW + (c - e * HW)] = s_gs[c];  // (positions: written by the write-back below)
+            g_shadow[(size_t)(e0 + e) * HW + (c - e * HW)] = s_gs[c];
         }
         for (int i = tid; i < nea; i += T) {
             const int e = rw_div18(i, mN);
@@ -1342,16 +1291,6 @@ __global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restric
             //  coordinates when somebody asks for it — rw_refresh_grid.  Its scattered 4-byte patches were partial-line
             //  writes; once a batch outgrows the Infinity Cache each of them is a read-modify-write in HBM: 15 % of the
             //  step at B = 262144, measured by ablation.)
-            if constexpr (kPos) {
-                // position layout: the chunk's positions go back as ONE coalesced stream of whole 16-byte pieces (the LDS copy
-                // is current: the agent phases and the reset path update it) — no scattered 1-byte patches, which are
-                // read-modify-writes in HBM once a batch has outgrown the Infinity Cache
-                if (op != OP_OBS) {
-                    const int4 *src = reinterpret_cast<const int4 *>(smem + lo.pos);
-                    int4 *dst = reinterpret_cast<int4 *>(g_pos + (size_t)e0 * S);
-                    for (int k = lane; k < (Cfg::kE * Cfg::kS) >> 4; k += 64) dst[k] = src[k];
-                }
-            } else
             if (op == OP_STEP)
                 for (int i = lane; i < nea; i += 64) {
                     const int mv = s_mv[i], carry = s_carry[i];

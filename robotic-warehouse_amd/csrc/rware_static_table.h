@@ -19,8 +19,6 @@ struct StaticEntry {
     int NL;     // IMAGE builds: > 0 = the layer list baked in (`layers`: 4 bits per id, first layer lowest) with `directional`
     uint32_t layers;
     int directional;
-    int pos;    // 1: POSITION state layout (rw::StaticCfg POS_), picked for batches of at least `min_B` envs
-    int min_B;
     step_kernel_t fn, fn_rollout;
     step_kernel_t fn_nt;  // the per-step kernel with non-temporal observation stores (nullptr: `fn` switches at run time)
 };
@@ -46,29 +44,23 @@ namespace {
 // (fn_nt: the same per-step kernel with NT_ = 1; size-static entries, N == 0, switch at run time and carry nullptr)
 #define RW_NT_OR_NULL(N, ...) ((N) != 0 ? (step_kernel_t)__VA_ARGS__ : (step_kernel_t) nullptr)
 #define RW_STATIC(H, W, N, Q, S, R, E, T, MAXB)                                                                   \
-    {H, W, N, Q, S, R, E, T, MAXB, 0, 0, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
+    {H, W, N, Q, S, R, E, T, MAXB, 0, 0, 0, 0u, -1, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true>,                   \
-     RW_NT_OR_NULL(N, rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, false, 1>, false>)}
+     RW_NT_OR_NULL(N, rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, 1>, false>)}
 #define RW_STATIC_IMAGE(H, W, N, Q, S, R, E, T, MAXB)                                                             \
-    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false, rw::OBS_IMAGE>, \
+    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, 0, 0u, -1, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, false, rw::OBS_IMAGE>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T>, true, rw::OBS_IMAGE>,   \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, false, 1>, false, rw::OBS_IMAGE>}
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, 1>, false, rw::OBS_IMAGE>}
 // ... with the layer list and the directional switch baked in (the gather's per-layer selects fold away)
 #define RW_STATIC_IMAGE_LAYERS(H, W, N, Q, S, R, E, T, MAXB, NL, LAYERS, DIR)                                      \
-    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, NL, LAYERS, DIR, 0, 0,                                                     \
+    {H, W, N, Q, S, R, E, T, MAXB, 1, 0, NL, LAYERS, DIR,                                                           \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, false, rw::OBS_IMAGE>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR>, true, rw::OBS_IMAGE>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR, false, 1>, false, rw::OBS_IMAGE>}
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, NL, LAYERS, DIR, 1>, false, rw::OBS_IMAGE>}
 #define RW_STATIC_MSG(H, W, N, Q, S, R, E, T, MAXB, M)                                                            \
-    {H, W, N, Q, S, R, E, T, MAXB, 0, M, 0, 0u, -1, 0, 0, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, false, rw::OBS_FLATTENED_MSG>, \
+    {H, W, N, Q, S, R, E, T, MAXB, 0, M, 0, 0u, -1, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, false, rw::OBS_FLATTENED_MSG>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, true, rw::OBS_FLATTENED_MSG>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M, 0, 0u, -1, false, 1>, false, rw::OBS_FLATTENED_MSG>}
-// FLATTENED builds on the POSITION state layout, for batches of at least MINB envs (a step's traffic past the Infinity Cache)
-#define RW_STATIC_POS(H, W, N, Q, S, R, E, T, MINB)                                                                \
-    {H, W, N, Q, S, R, E, T, 0, 0, 0, 0, 0u, -1, 1, MINB,                                                           \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true>, false>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true>, true>, \
-     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, 0, 0, 0u, -1, true, 1>, false>}
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M, 0, 0u, -1, 1>, false, rw::OBS_FLATTENED_MSG>}
 // the three registered warehouse sizes of the RWARE papers (rware/__init__.py:7-12): grid, shelves
 #define RW_TINY(N, Q) RW_STATIC(11, 10, N, Q, 32, 1, 16, 256, 0)
 #define RW_SMALL(N, Q) RW_STATIC(20, 10, N, Q, 80, 1, 16, 256, 0)
@@ -106,7 +98,6 @@ namespace {
 const StaticEntry kEntries[] = {
 #if RW_STATIC_GROUP == 0
     // ---- the BASELINE.json tasks (+ their batch-size / geometry variants)
-    RW_STATIC_POS(20, 10, 4, 4, 80, 1, 16, 256, 196608),   // rware-small-4ag past the Infinity Cache (>= 224 MB of observations per step)
     // half-size workgroups for batches that leave the CUs short of workgroups at E = 16 (measured, round 2:
     // medium-6ag-hard B=8192 9.16 -> 7.98 us, B=4096 7.86 -> 6.71; B=16384 11.2 vs 13.1 the other way round)
     RW_STATIC(20, 16, 6, 3, 144, 1, 8, 256, 8192),
@@ -171,7 +162,6 @@ const StaticEntry kEntries[] = {
 #undef RW_STATIC_IMAGE
 #undef RW_STATIC_IMAGE_LAYERS
 #undef RW_STATIC_MSG
-#undef RW_STATIC_POS
 #undef RW_TINY
 #undef RW_TINY_E8
 #undef RW_QRT_12

@@ -518,68 +518,6 @@ def test_grid_is_a_derived_view_refreshed_on_demand():
     env.close()
 
 
-# --------------------------------------------------------------------------- the POSITION state layout (big batches)
-@pytest.fixture
-def pos_layout(monkeypatch):
-    monkeypatch.setenv("RWARE_STATE_LAYOUT", "pos")   # test hook: take the position-layout build whatever the batch size
-
-
-def test_position_layout_replays_reference_golden(pos_layout):
-    """The exact-shape small-4ag build that stages the shelf layer from one cell index per shelf (what batches past the
-    Infinity Cache run): the reference's golden trace, every field, every step."""
-    meta, z = gu.load_fixture("small-4ag")
-    be = EngineBackend(meta["E"], library=LIB, tile=4, **gu.ctor_kwargs(meta))
-    assert be.env.engines[0].info.specialised == 1 and be.env.engines[0].info.state_layout == 1
-    assert gu.replay(be, meta, z, steps=120) > 0
-    be.env.close()
-
-
-@pytest.mark.parametrize("mode", ["next_step", "same_step", "disabled"])
-def test_position_layout_matches_oracle_with_host_writes_and_snapshots(pos_layout, mode):
-    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
-    kw["max_steps"] = 25
-    B = 32
-    env = rware_amd.WarehouseVecEnv(B, autoreset_mode=mode, library=LIB, **kw)
-    assert env.engines[0].info.state_layout == 1
-    okw = dict(kw, reward_type=rware_amd.enums.enum_value(kw["reward_type"]))
-    orc = OracleVecEnv(B, **okw)
-    obs, _ = env.reset(seed=3)
-    assert np.array_equal(obs, orc.reset(seed=3))
-    rng = np.random.default_rng(1)
-
-    def both(n):
-        for t in range(n):
-            a = rng.choice(5, size=(B, 4), p=[.1, .5, .1, .1, .2]).astype(np.int32)
-            obs, rew, term, _, _ = env.step(a)
-            o2, r2, d2 = orc.step_autoreset(a, mode)
-            assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
-        st, so = env.get_state(), orc.get_state()
-        for k in so:
-            assert np.array_equal(st[k], so[k]), k
-        return st
-
-    st = both(40)
-    env.set_state(**{k: st[k] for k in ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry", "agent_delivered",
-                                         "queue", "steps", "inactive", "rng")})   # a host write of the grid: positions rebuilt
-    both(15)
-    tok = env.snapshot()
-    a = rng.integers(0, 5, size=(B, 4)).astype(np.int32)
-    for _ in range(3):
-        env.step(a)
-    env.restore(tok)
-    both(15)
-    # the fused rollout on the same layout
-    acts = rng.choice(5, size=(12, B, 4), p=[.1, .5, .1, .1, .2]).astype(np.int32)
-    _, rew, term = env.rollout(acts, want_obs=False)
-    for k in range(12):
-        o2, r2, d2 = orc.step_autoreset(acts[k], mode)
-        assert np.array_equal(rew[k], r2) and np.array_equal(term[k], d2.astype(bool)), k
-    st, so = env.get_state(), orc.get_state()
-    for k in so:
-        assert np.array_equal(st[k], so[k]), k
-    env.close()
-
-
 # --------------------------------------------------------------------------- round-3 additions (advisor findings)
 @pytest.mark.parametrize("name,geom,tile", [
     ("tiny-2ag", (0, 0), 4),           # pair exchange (N = 2)
@@ -813,7 +751,6 @@ def test_agent_count_static_builds_replay_reference_golden(monkeypatch, name, ti
     """The reference's golden traces on the agent-count-static builds (RWARE_PREFER_QRT=1 makes rw_create skip the exact
     (N, Q) entries of the task grid): deliveries, queue replacement and termination with the queue length a run-time value."""
     monkeypatch.setenv("RWARE_PREFER_QRT", "1")
-    monkeypatch.setenv("RWARE_STATE_LAYOUT", "shadow")
     meta, z = gu.load_fixture(name)
     kw = gu.ctor_kwargs(meta)
     if name == "small-4ag":

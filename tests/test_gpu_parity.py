@@ -587,47 +587,6 @@ def test_bench_two_ranks_through_torchrun():
     _check_bench_line(out, 2, 200, 20, 4096)
 
 
-@pytest.mark.parametrize("mode", ["next_step", "same_step"])
-def test_position_state_layout_matches_oracle(monkeypatch, mode):
-    """The exact-shape small-4ag build on the POSITION state layout (shelf layer staged from one cell index per shelf, written
-    back as one coalesced stream) against the oracle: per-step launches and fused rollouts, across autoresets."""
-    monkeypatch.setenv("RWARE_STATE_LAYOUT", "pos")
-    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
-    kw["max_steps"] = 120
-    B, N = 4096, 4
-    env = rware_amd.WarehouseVecEnv(B, autoreset_mode=mode, **kw)
-    assert env.engines[0].info.specialised == 1 and env.engines[0].info.state_layout == 1
-    orc = OracleVecEnv(B, **dict(kw, reward_type=kw["reward_type"].value))
-    obs, _ = env.reset(seed=17)
-    assert np.array_equal(obs, orc.reset(seed=17))
-    rng = np.random.default_rng(5)
-    for t in range(260):
-        a = rng.choice(5, size=(B, N), p=[.1, .5, .15, .15, .1]).astype(np.int32)
-        obs, rew, term, _, _ = env.step(a)
-        o2, r2, d2 = orc.step_autoreset(a, mode)
-        assert np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
-        if t % 20 == 0:
-            assert np.array_equal(obs, o2), t
-    acts = rng.choice(5, size=(40, B, N), p=[.1, .5, .15, .15, .1]).astype(np.int32)
-    _, rew, term = env.rollout(acts, want_obs=False)
-    for k in range(40):
-        o2, r2, d2 = orc.step_autoreset(acts[k], mode)
-        assert np.array_equal(rew[k], r2) and np.array_equal(term[k], d2.astype(bool)), k
-    st, so = env.get_state(), orc.get_state()
-    for k in so:
-        assert np.array_equal(st[k], so[k]), k
-    assert np.array_equal(env.observations(), orc.obs())
-    env.close()
-
-
-def test_position_state_layout_is_picked_for_cache_exceeding_batches():
-    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
-    big = rware_amd.WarehouseVecEnv(196608, **kw)
-    small = rware_amd.WarehouseVecEnv(16384, **kw)
-    assert big.engines[0].info.state_layout == 1 and small.engines[0].info.state_layout == 0
-    big.close(); small.close()
-
-
 # --------------------------------------------------------------------------- round 3: the Python surface a training loop calls
 def test_step_calls_enqueue_exactly_one_kernel_each():
     """100 `WarehouseVecEnv(output="torch").step(cuda int32 actions)` calls put exactly 100 kernels on the stream: the step
