@@ -506,14 +506,15 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.envs_per_wg = E;
     {
         // Observation stores: non-temporal (stream) or cached.  Measured rule (round 3, same-box A/Bs, profiles/EXPERIMENTS.md):
-        // the hint wins wherever the workgroup runs in service-wave mode (a small observation chunk: every registered task
-        // except the 16-agent ones — small-4ag B = 16384 7.13 -> 6.17 us, medium-6ag-hard 7.25 -> 6.26) and wherever a step's
+        // the hint wins wherever a workgroup's observation chunk is small (every registered task except the 16-agent ones —
+        // small-4ag B = 16384 7.13 -> 6.17 us, medium-6ag-hard 7.25 -> 6.26, large-8ag 12.25 -> 11.1) and wherever a step's
         // observations outgrow the Infinity Cache (large-16ag r=2 B = 32768 88.7 -> 81.6); it loses for large observation
         // chunks below that size (large-16ag r=2 B = 16384 36.2 -> 43.1).
+        // (measured by chunk size: 4544 floats small-4ag, 9088 large-8ag at 16 envs: the hint wins; 18176 large-16ag r=1,
+        //  23424 large-16ag r=2 at 8 envs: it loses below the cache size)
         const long long chunk = (long long)E * N * eng->L;                    // floats of one workgroup's observations
-        const bool service_wave = T == 256 && chunk <= 8192;                    // (the kernel's `split`)
         const double obs_mb = (double)B * N * eng->L * 4 / 1e6;
-        bool nt = service_wave || obs_mb > 240.0;
+        bool nt = chunk <= 12288 || obs_mb > 240.0;
         const char *pref = getenv("RWARE_OBS_STORES");
         if (cfg->stream_flags & RW_OBS_STORES_CACHED) nt = false;
         if (cfg->stream_flags & RW_OBS_STORES_STREAM) nt = true;

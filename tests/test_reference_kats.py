@@ -235,9 +235,9 @@ def test_grid_size_formula(backend, cols, height, rows):
 @pytest.mark.parametrize("max_steps", [1, 100, 200])
 def test_max_steps_terminates(backend, max_steps):
     if backend == "emu-static" and max_steps > 1:
-        max_steps //= 10
+        max_steps //= 20
     elif backend == "emu" and max_steps > 1:
-        max_steps //= 4   # (256 host threads per emulated workgroup: keep the CPU suite short; the GPU runs 100 / 200)
+        max_steps //= 8   # (256 host threads per emulated workgroup: keep the CPU suite short; the GPU runs 100 / 200)
     env = make(backend, 1, max_steps=max_steps)
     for _ in range(max_steps - 1):
         assert env.step([NOOP])[2] is False
