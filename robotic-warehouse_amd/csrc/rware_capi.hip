@@ -511,10 +511,10 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // observations outgrow the Infinity Cache (large-16ag r=2 B = 32768 88.7 -> 81.6); it loses for large observation
         // chunks below that size (large-16ag r=2 B = 16384 36.2 -> 43.1).
         // (measured by chunk size: 4544 floats small-4ag, 9088 large-8ag at 16 envs: the hint wins; 18176 large-16ag r=1,
-        //  23424 large-16ag r=2 at 8 envs: it loses below the cache size)
+        //  23424 large-16ag r=2 at 8 envs: it loses below the cache size; 13632 small-12ag: 18.65 vs 19.02 us, it still wins)
         const long long chunk = (long long)E * N * eng->L;                    // floats of one workgroup's observations
         const double obs_mb = (double)B * N * eng->L * 4 / 1e6;
-        bool nt = chunk <= 12288 || obs_mb > 240.0;
+        bool nt = chunk <= 14336 || obs_mb > 240.0;
         const char *pref = getenv("RWARE_OBS_STORES");
         if (cfg->stream_flags & RW_OBS_STORES_CACHED) nt = false;
         if (cfg->stream_flags & RW_OBS_STORES_STREAM) nt = true;
