@@ -349,7 +349,13 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
 }
 
 template <int R, typename CellT, typename Cfg, bool kRollout, int kObs = OBS_FLATTENED>
-__global__ void __launch_bounds__(256) rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
+__global__ void __launch_bounds__(256)
+#if defined(__HIPCC__)
+// the half-size-workgroup exact builds hold a 16384-env batch only if 8 workgroups fit a CU: ask for that register budget
+// (one of them — 8 agents, 16 queue slots — came out at 66 VGPRs, 7 per CU: 11.7 instead of ~9.6 us per step)
+__attribute__((amdgpu_waves_per_eu((Cfg::kE == 8 && (Cfg::kN == 7 || Cfg::kN == 8) && !Cfg::kQrt && !kRollout) ? 8 : 1, 8)))
+#endif
+rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L0 = 8 + 7 * CELLS, OW0 = (L0 + 31) / 32;
     constexpr bool kImage = (kObs == OBS_IMAGE || kObs == OBS_IMAGE_MSG);
     constexpr bool kMsg = (kObs == OBS_FLATTENED_MSG || kObs == OBS_IMAGE_MSG);  // actions are [Action, message bits...]
