@@ -78,6 +78,10 @@ CASES = [
      {"shelf_columns": 3, "column_height": 3, "shelf_rows": 2, "n_agents": 4, "msg_bits": 1, "sensor_range": 1,
       "request_queue_size": 2, "max_inactivity_steps": 40, "max_steps": 100, "reward_type": 0,
       "observation_type": 2, "image_observation_layers": [0, 1, 2, 3, 4, 5, 6]}, 3, 240, 19000),
+    # round 3: the builds added for odd agent counts, the large warehouse and the 2-agent tasks, pinned to the reference as well
+    ("small-7ag-hard", "rware-small-7ag-hard-v2", {"max_steps": 150}, 2, 320, 20000),
+    ("large-4ag", "rware-large-4ag-v2", {"max_steps": 200}, 2, 320, 21000),
+    ("medium-2ag-easy", "rware-medium-2ag-easy-v2", {"max_steps": 150}, 4, 320, 22000),
     ("imgdict-square-5ag-transposed-northup", None,
      {"shelf_columns": 3, "column_height": 3, "shelf_rows": 2, "n_agents": 5, "msg_bits": 0, "sensor_range": 1,
       "request_queue_size": 3, "max_inactivity_steps": None, "max_steps": 90, "reward_type": 2,

@@ -98,6 +98,9 @@ def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
     ("msg2-small-4ag", (0, 0), 16),              # exact-shape build with 2 communication bits
     ("small-8ag-global-inact", (0, 0), 16),      # N = 8 in registers: 64-bit chain links (round 3)
     ("tiny-4ag-easy-twostage", (0, 0), 16),      # Q > N: two queue slots per agent lane
+    ("small-7ag-hard", (0, 0), 4),               # agent-count-static build, N = 7 (ds_bpermute, 64-bit links), 8-env workgroups
+    ("large-4ag", (0, 0), 8),                    # agent-count-static build on the large warehouse
+    ("medium-2ag-easy", (32, 256), 8),           # 2 agents, the 32-env build (pair exchange), Q = 2 N
 ])
 def test_emulated_exact_shape_builds_match_reference_golden(name, geom, tile):
     """The golden traces of the unmodified reference, replayed on the EXACT-SHAPE kernel builds (the ones the BASELINE

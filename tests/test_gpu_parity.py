@@ -37,6 +37,8 @@ def test_engine_matches_reference_golden(name):
     ("img-small-4ag-directional", (0, 0), 16), ("msg2-small-4ag", (0, 0), 16),
     # round 3: N = 8 in registers (ds_bpermute gathers, 64-bit chain links, row_half_mirror OR); Q > N (two queue slots per lane)
     ("small-8ag-global-inact", (0, 0), 16), ("tiny-4ag-easy-twostage", (0, 0), 16),
+    # agent-count-static builds (N = 7 on 8-env workgroups; the large warehouse) and the 32-env 2-agent build
+    ("small-7ag-hard", (0, 0), 4), ("large-4ag", (0, 0), 8), ("medium-2ag-easy", (32, 256), 8), ("medium-2ag-easy", (0, 0), 4),
 ])
 def test_exact_shape_builds_match_reference_golden(name, geom, tile):
     """The golden traces of the unmodified reference on the EXACT-SHAPE kernel builds (what the BASELINE configs run):
