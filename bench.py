@@ -326,7 +326,10 @@ def main():
     torch.cuda.set_device(local_rank)
     share = os.environ.get("RWARE_BENCH_SHARE_GPU") == "1"
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    placement = pin_rank(torch, int(os.environ.get("LOCAL_RANK", "0")), local_world, (lambda r: r % n_dev) if share else (lambda r: min(r, n_dev - 1)))
+    try:
+        placement = pin_rank(torch, int(os.environ.get("LOCAL_RANK", "0")), local_world, (lambda r: r % n_dev) if share else (lambda r: min(r, n_dev - 1)))
+    except Exception as exc:  # noqa: BLE001  (placement is an optimisation: never let it take a rank down)
+        placement = {"pinned": False, "why": f"pin_rank failed: {exc!r}"}
     dist = None
     if world > 1:
         import torch.distributed as dist

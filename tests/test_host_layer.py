@@ -80,3 +80,59 @@ def test_enums_are_value_compatible():
     assert [a.value for a in rware_amd.Action] == [0, 1, 2, 3, 4]
     assert [d.name for d in rware_amd.Direction] == ["UP", "DOWN", "LEFT", "RIGHT"]
     assert rware_amd.RewardType.TWO_STAGE.value == 2 and rware_amd.ObservationType.FLATTENED.value == 1
+
+
+def test_bench_rank_placement_partitions_physical_cores_per_numa_node(monkeypatch):
+    """bench.pin_rank on a faked 2-socket box (2 NUMA nodes x 16 physical cores x 2 SMT threads, 8 GPUs, 4 per node): every
+    rank gets whole physical cores of its GPU's node, disjoint from the other ranks' — the code path the 8-GPU scaling run
+    takes, which no test box can exercise for real."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    n_phys, nodes = 32, 2
+    sib = {c: (c % n_phys, c % n_phys + n_phys) for c in range(2 * n_phys)}            # cpu c and c + 32 share a core
+    node_of_core = lambda c: (c % n_phys) // (n_phys // nodes)                          # noqa: E731
+
+    def fake_read(path):
+        if path.startswith("/sys/bus/pci/devices/"):
+            bus = int(path.split(":")[1], 16)
+            return str(0 if bus < 4 else 1)                                              # GPUs 0-3 on node 0, 4-7 on node 1
+        if path.startswith("/sys/devices/system/node/node"):
+            k = int(path.split("node")[-1].split("/")[0])
+            cs = [c for c in range(2 * n_phys) if node_of_core(c) == k]
+            return ",".join(str(c) for c in cs)
+        if "thread_siblings_list" in path:
+            c = int(path.split("/cpu/cpu")[1].split("/")[0])
+            return f"{sib[c][0]},{sib[c][1]}"
+        return None
+
+    class Props:
+        def __init__(self, i):
+            self.pci_domain_id, self.pci_bus_id, self.pci_device_id = 0, i, 0
+
+    class FakeTorch:
+        class cuda:
+            @staticmethod
+            def get_device_properties(i):
+                return Props(i)
+
+    masks = {}
+    monkeypatch.setattr(bench, "_read", fake_read)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(2 * n_phys)))
+    monkeypatch.delenv("RWARE_BENCH_NO_PIN", raising=False)
+    for r in range(8):
+        monkeypatch.setattr(os, "sched_setaffinity", lambda pid, m, r=r: masks.__setitem__(r, set(m)))
+        p = bench.pin_rank(FakeTorch, r, 8, lambda k: k)
+        assert p["pinned"] and p["numa_node"] == (0 if r < 4 else 1) and p["physical_cores"] == 4, p
+    for r in range(8):
+        assert all(node_of_core(c) == (0 if r < 4 else 1) for c in masks[r])             # on the GPU's own node
+        assert all((c + n_phys) % (2 * n_phys) in masks[r] for c in masks[r])            # whole cores: both SMT siblings
+        for q in range(r):
+            assert not (masks[r] & masks[q])                                              # disjoint between ranks
+    # fewer physical cores than ranks on a node: report, do not pin
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {0, 32})
+    p = bench.pin_rank(FakeTorch, 1, 8, lambda k: k)
+    assert p["pinned"] is False and "physical cores" in p["why"]
