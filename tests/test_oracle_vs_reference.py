@@ -258,3 +258,48 @@ def test_global_image_matches_the_reference(env_id, extra):
         bad["agent_y"][0, 0] = env.grid_size[1]
         with pytest.raises(IndexError):
             global_image_from_state(bad, env.goals, [3])
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_oracle_matches_the_live_reference_on_random_shapes(case):
+    """24 warehouses the fixtures do not hold — random shelf rows / columns / column height, 1..10 agents, any queue length,
+    sensor range 1..4, all three reward types, optional inactivity limit and normalised coordinates — each 140 steps of the
+    unmodified reference (pinned tie-break) against the C oracle: state incl. the PCG64 stream, observations, rewards, done."""
+    g = np.random.default_rng(5000 + case)
+    rows, cols, height = int(g.integers(1, 4)), int(g.choice([1, 3, 5])), int(g.integers(1, 9))
+    n_agents = int(g.integers(1, 11))
+    shelves = rows * cols * 2 * height - 0  # (upper bound; the goal block removes some)
+    kw = dict(shelf_columns=cols, column_height=height, shelf_rows=rows, n_agents=n_agents, msg_bits=0,
+              sensor_range=int(g.integers(1, 5)), request_queue_size=int(g.integers(0, max(1, min(2 * n_agents, shelves // 3)) + 1)),
+              max_inactivity_steps=(None if g.random() < 0.6 else int(g.integers(15, 60))), max_steps=int(g.integers(40, 120)),
+              reward_type=int(g.integers(0, 3)), normalised_coordinates=bool(g.random() < 0.25))
+    wh = rr.load_reference()
+    env = rr.make_reference_env(None, **dict(kw, reward_type=wh.RewardType(kw["reward_type"])))   # (the reference compares enum members)
+    if env.n_agents > (env.grid_size[0] * env.grid_size[1]) // 2:
+        pytest.skip("more agents than this tiny grid can hold comfortably")
+    orc = OracleVecEnv(1, **kw)
+    seed = 900 + case
+    try:
+        obs, _ = env.reset(seed=seed)
+    except ValueError:
+        pytest.skip("a layout without shelves (one column: it is the goal column): the reference's own reset() raises")
+    if kw["request_queue_size"] >= len(env.shelfs):
+        pytest.skip("as many requests as shelves: the reference's own replacement draw has no candidates (ValueError)")
+    assert np.array_equal(rr.obs_array(obs), orc.reset(seed=seed)[0])
+    pol = np.random.default_rng(seed)
+    done_prev = False
+    for t in range(140):
+        a = rr.scripted_actions(env, pol) if (t // 35) % 2 == 0 else [int(v) for v in pol.choice(5, size=env.n_agents, p=[.1, .55, .1, .1, .15])]
+        if done_prev:  # the reference's caller resets; the oracle's next_step autoreset does the same on this step
+            obs, _ = env.reset()
+            o2, r2, d2 = orc.step_autoreset(np.array(a)[None], "next_step")
+            r, d = [0.0] * env.n_agents, False
+        else:
+            obs, r, d, _, _ = rr.ref_step(env, a)
+            o2, r2, d2 = orc.step_autoreset(np.array(a)[None], "next_step")
+        snap, st = rr.snapshot(env), orc.get_state()
+        for k, v in snap.items():
+            assert np.array_equal(np.asarray(v).reshape(-1), st[k][0].reshape(-1)), (k, t, kw)
+        assert np.array_equal(rr.obs_array(obs), o2[0]), (t, kw)
+        assert np.array_equal(np.asarray(r, np.float32), r2[0]) and bool(d) == bool(d2[0]), (t, kw)
+        done_prev = bool(d)
