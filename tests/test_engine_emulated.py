@@ -784,3 +784,41 @@ def test_observation_store_policy_is_a_create_time_choice():
         assert np.array_equal(obs[None], obs["cached"]) and np.array_equal(obs[None], obs["stream"])
     for e in envs.values():
         e.close()
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_generic_kernel_matches_oracle_on_random_shapes(case):
+    """The generic (every shape at run time) kernel on 12 random warehouses — rows / columns / column height, 1..10 agents,
+    queue length, sensor range 1..4, reward type, inactivity limit, normalised coordinates, ragged batch — against the oracle,
+    per-step launches across autoresets and a fused rollout."""
+    g = np.random.default_rng(7000 + case)
+    rows, cols, height = int(g.integers(1, 4)), int(g.choice([3, 5])), int(g.integers(1, 9))
+    n_agents = int(g.integers(1, 11))
+    kw = dict(shelf_columns=cols, column_height=height, shelf_rows=rows, n_agents=n_agents, msg_bits=0,
+              sensor_range=int(g.integers(1, 5)), request_queue_size=int(g.integers(0, min(2 * n_agents, rows * cols * height // 2) + 1)),
+              max_inactivity_steps=(None if g.random() < 0.6 else int(g.integers(8, 25))), max_steps=int(g.integers(12, 30)),
+              reward_type=int(g.integers(0, 3)), normalised_coordinates=bool(g.random() < 0.25))
+    B = int(g.integers(3, 10))
+    mode = ["next_step", "same_step", "disabled"][case % 3]
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, envs_per_workgroup=4, threads_per_workgroup=int(g.choice([64, 128])), autoreset_mode=mode, **kw)
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=70 + case)[0], orc.reset(seed=70 + case))
+    rng = np.random.default_rng(case)
+    for t in range(40):
+        a = rng.choice(5, size=(B, n_agents), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, mode)
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), (t, kw)
+        if mode == "disabled" and term.any():
+            m = term.astype(np.uint8)
+            assert np.array_equal(env.reset(mask=m)[0], orc.reset(mask=m)), t
+    acts = rng.choice(5, size=(8, B, n_agents), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+    if mode != "disabled":
+        obs, rew, term = env.rollout(acts)
+        for k in range(8):
+            o2, r2, d2 = orc.step_autoreset(acts[k], mode)
+            assert np.array_equal(obs[k], o2) and np.array_equal(rew[k], r2), (k, kw)
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), (k, kw)
+    env.close()
