@@ -836,3 +836,38 @@ def test_observation_store_policy_does_not_change_results(env_id, extra, B):
             assert np.array_equal(out[None][0], o2) and np.array_equal(out[None][1], r2), t
     for e in envs.values():
         e.close()
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_generic_kernel_matches_oracle_on_random_shapes(case):
+    """The generic (every shape at run time) kernel on 24 random warehouses — rows / columns / column height, 1..12 agents,
+    queue length, sensor range 1..5, reward type, inactivity limit, normalised coordinates, ragged batches and odd launch
+    geometries — against the oracle on every env, per-step launches across autoresets and a fused rollout."""
+    g = np.random.default_rng(9000 + case)
+    rows, cols, height = int(g.integers(1, 5)), int(g.choice([3, 5, 7])), int(g.integers(1, 10))
+    n_agents = int(g.integers(1, 13))
+    kw = dict(shelf_columns=cols, column_height=height, shelf_rows=rows, n_agents=n_agents, msg_bits=0,
+              sensor_range=int(g.integers(1, 6)), request_queue_size=int(g.integers(0, min(2 * n_agents, rows * cols * height // 2) + 1)),
+              max_inactivity_steps=(None if g.random() < 0.6 else int(g.integers(8, 25))), max_steps=int(g.integers(20, 60)),
+              reward_type=int(g.integers(0, 3)), normalised_coordinates=bool(g.random() < 0.25))
+    B = int(g.integers(40, 400))
+    mode = ["next_step", "same_step"][case % 2]
+    E, T = int(g.choice([4, 8, 12])), int(g.choice([64, 128, 256]))
+    env = rware_amd.WarehouseVecEnv(B, envs_per_workgroup=E, threads_per_workgroup=T, autoreset_mode=mode, **kw)
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=90 + case)[0], orc.reset(seed=90 + case))
+    rng = np.random.default_rng(case)
+    for t in range(90):
+        a = rng.choice(5, size=(B, n_agents), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, mode)
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), (t, kw, B, E, T)
+    acts = rng.choice(5, size=(30, B, n_agents), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+    obs, rew, term = env.rollout(acts)
+    for k in range(30):
+        o2, r2, d2 = orc.step_autoreset(acts[k], mode)
+        assert np.array_equal(obs[k], o2) and np.array_equal(rew[k], r2) and np.array_equal(term[k], d2.astype(bool)), (k, kw)
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), (k, kw)
+    env.close()
