@@ -111,6 +111,19 @@ class _Space:
         return f"Space(shape={self.shape}, dtype={self.dtype}, n={self.n})"
 
 
+class _CapturedLoop:
+    """What WarehouseVecEnv.capture_loop returns: `steps` (policy, step) rounds in one HIP graph."""
+
+    def __init__(self, graph, stream, keep, steps):
+        self.graph, self.stream, self._keep, self.steps = graph, stream, keep, steps
+
+    def replay(self):
+        import torch
+
+        with torch.cuda.stream(self.stream):
+            self.graph.replay()
+
+
 class WarehouseVecEnv(_VectorEnvBase):
     metadata = {"render_modes": [], "autoreset_mode": "next_step"}
 
@@ -171,6 +184,7 @@ class WarehouseVecEnv(_VectorEnvBase):
             self._bounds.append((lo, lo + n))
             lo += n
         self._torch = None
+        self._stream_handles = []  # (output="torch": the stream every engine enqueues on — torch's current stream at construction)
         self.engines = []
         for dev, (lo, hi) in zip(devices, self._bounds):
             if hi == lo:
@@ -184,6 +198,7 @@ class WarehouseVecEnv(_VectorEnvBase):
                 # which is why the engine is told to take the handle literally (RW_STREAM_USE_GIVEN): launches are
                 # then ordered with the policy / learner ops around them and need no sync
                 stream = torch.cuda.current_stream(dev).cuda_stream
+                self._stream_handles.append(int(stream))
             self.engines.append(_capi.Engine(
                 num_envs=hi - lo, layout=self.layout, n_agents=self.n_agents, sensor_range=self.sensor_range,
                 request_queue_size=self.request_queue_size, max_inactivity_steps=max_inactivity_steps,
@@ -383,6 +398,39 @@ class WarehouseVecEnv(_VectorEnvBase):
         self._live_actions = actions
         eng.step_many_device(actions.data_ptr(), T, obs.data_ptr() if want_obs else 0, rew.data_ptr(), term.data_ptr())
         return obs, rew, term.view(t.bool)
+
+    def capture_loop(self, policy, steps: int = 1, warmup: int = 2):
+        """`steps` rounds of  `actions = policy(obs, rewards, terminated); env.step(actions)`  captured in ONE HIP graph.
+
+        A step is a single ~6 us kernel; a torch policy in front of it is several small kernels (a one-layer policy: 37 us
+        per round issued eagerly, 32 us replayed from a graph — profiles/r03_learner_probe.txt).  Replaying policy + step
+        from a graph removes the host's share of that.  `policy` gets the env's zero-copy output tensors (the same objects every round: they are overwritten in
+        place by the step) and returns an integer CUDA tensor of (B, N) actions; it must be capturable (no host syncs, no
+        data-dependent shapes).  The env has to sit on a non-default stream — construct it under `with torch.cuda.stream(s)` —
+        because a HIP graph cannot be captured on the legacy default stream.  `policy` is called `warmup` times eagerly first
+        (outputs discarded, the env does not step) so that lazy library initialisation happens outside the capture.
+        Returns an object with `.replay()` (enqueue the captured rounds once more on the env's stream) and `.graph`."""
+        t = self._torch
+        if t is None or len(self.engines) != 1:
+            raise ValueError('capture_loop needs output="torch" and a single device')
+        if not self._stream_handles or not self._stream_handles[0]:
+            raise ValueError("the env enqueues on the default stream: construct it under `with torch.cuda.stream(s)` to capture")
+        dev = self.devices[0]
+        s = t.cuda.ExternalStream(self._stream_handles[0], device=f"cuda:{dev}")
+        v = self._torch_views()
+        obs = self._obs_of(v)
+        keep = []
+        with t.cuda.stream(s):
+            for _ in range(max(0, int(warmup))):
+                policy(obs, v["rewards"], v["terminated_bool"])
+            s.synchronize()
+            g = t.cuda.CUDAGraph()
+            with t.cuda.graph(g, stream=s):
+                for _ in range(int(steps)):
+                    a = self._device_actions(policy(obs, v["rewards"], v["terminated_bool"]), self.num_envs, 0)
+                    keep.append(a)  # (allocated from the graph's private pool: alive as long as the graph is)
+                    self.engines[0].step_device(a.data_ptr())
+        return _CapturedLoop(g, s, keep, int(steps))
 
     def snapshot(self):
         """Checkpoint the batched state on the device (grid, agents, queue, counters, RNG streams).

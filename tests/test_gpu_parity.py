@@ -871,3 +871,38 @@ def test_generic_kernel_matches_oracle_on_random_shapes(case):
     for k in so:
         assert np.array_equal(st[k], so[k]), (k, kw)
     env.close()
+
+
+def test_capture_loop_replays_policy_and_step_from_one_graph():
+    """capture_loop: (policy, step) rounds in ONE HIP graph — replayed, they produce what the same rounds produce eagerly."""
+    import torch
+    B, N, K, R = 2048, 4, 5, 12
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        genv = rware_amd.WarehouseVecEnv(B, output="torch", **kw)
+        eenv = rware_amd.WarehouseVecEnv(B, output="torch", **kw)
+        og, _ = genv.reset(seed=3)
+        oe, _ = eenv.reset(seed=3)
+        W = torch.randn(og.shape[-1], 5, device="cuda")
+
+        def policy(obs, rew, term):
+            return (obs.view(-1, obs.shape[-1]) @ W).argmax(-1).view(B, N)      # int64, as a real policy hands it over
+
+        loop = genv.capture_loop(policy, steps=K)
+        assert loop.steps == K
+        for r in range(R):
+            loop.replay()
+            for k in range(K):
+                oe, re_, te, _, _ = eenv.step(policy(oe, None, None))
+        torch.cuda.synchronize()
+        genv.sync(); eenv.sync()
+        for name in ("obs", "rewards", "terminated"):
+            assert torch.equal(genv.device_tensor(name), eenv.device_tensor(name)), name
+    a, b = genv.get_state(), eenv.get_state()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["steps"].max() == K * R
+    with pytest.raises(ValueError):
+        rware_amd.WarehouseVecEnv(64, output="torch", **kw).capture_loop(policy)   # default stream: cannot capture
+    genv.close(); eenv.close()
