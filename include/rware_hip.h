@@ -217,6 +217,11 @@ int rw_copy_to_host(rw_engine *eng, void *host_dst, const void *dev_src, size_t 
  * far (three small kernels on the engine's stream; a no-op when nothing ran since the last refresh).  For callers that
  * hold a borrowed pointer / a zero-copy tensor of one of them. */
 int rw_refresh_grid(rw_engine *eng);
+/* Tell the engine that steps ran which its host side did not see — a HIP graph holding rw_step_device launches was replayed
+ * (replays run without host code) — so that the next rw_read / rw_get_buffer / rw_write of a derived view rebuilds it.  The
+ * engine also notices by itself when one of its launches is being captured (hipStreamIsCapturing) and from then on rebuilds
+ * the derived views on every request; this call is for graphs captured by other means. */
+int rw_mark_views_stale(rw_engine *eng);
 
 /* recompute RW_BUF_OBS from the current state (after rw_write of state buffers) */
 int rw_refresh_obs(rw_engine *eng);
@@ -263,8 +268,14 @@ typedef struct rw_info {
     int64_t algorithmic_bytes_per_env_step; /* SURVEY.md §8(d) formula                           */
     char device_name[128];
     char arch_name[64];
-    int32_t obs_stores_stream; /* 1: the observation stream is stored with the non-temporal hint (rw_stream_flags) */
-    int32_t reserved[7];
+    int32_t obs_stores_stream; /* 1: the per-step kernel stores the observation stream with the non-temporal hint
+                                  (rw_stream_flags); the fused rollout kernel (rw_step_many_device) always stores cached */
+    int32_t reserved0;
+    int64_t engine_bytes_per_env_step; /* bytes this engine's state layout has to move per env-step: shelf shadow (1 or 2 B per
+                                  cell) + packed agent records r/w + actions + queue + counters / flags + observation + rewards +
+                                  terminated (+ messages r/w, IMAGE_DICT features).  The PMC traffic of a step is checked against
+                                  it; bench.py prices `frac_engine` on it (<= 1 by construction)                               */
+    int32_t reserved[4];
 } rw_info;
 int rw_get_info(const rw_engine *eng, rw_info *out);
 

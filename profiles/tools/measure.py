@@ -1,0 +1,47 @@
+"""us per step of explicit (task, batch, geometry, observation-store) combinations, un-profiled, HIP events on the launches.
+    python profiles/tools/measure.py <env_id>:<B>[:<E>[:<stores>[:<sensor_range>]]] ...
+E = 0: the engine's own geometry; stores = auto | cached | stream.  Per-step launches from a device action tape
+(rw_step_tape_device_timed), uniform random actions, next_step autoreset.  One line per spec."""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import rware_amd  # noqa: E402
+
+KIND = {0: "generic", 1: "exact", 2: "agent-count-static", 3: "size-static"}
+for spec in sys.argv[1:]:
+    f = spec.split(":")
+    env_id, B = f[0], int(f[1])
+    E = int(f[2]) if len(f) > 2 else 0
+    stores = f[3] if len(f) > 3 and f[3] != "auto" else None
+    sr = int(f[4]) if len(f) > 4 else 0
+    kw = rware_amd.env_kwargs(env_id)
+    if sr:
+        kw["sensor_range"] = sr
+    N = kw["n_agents"]
+    try:
+        env = rware_amd.WarehouseVecEnv(B, envs_per_workgroup=E, threads_per_workgroup=256 if E else 0, obs_stores=stores, **kw)
+    except Exception as exc:  # noqa: BLE001
+        print(f"{spec:44s} FAILED {exc}")
+        continue
+    eng = env.engines[0]
+    eng.reset(seeds=rware_amd.shard_seeds(0, B))
+    T = 32 if B * N > 1 << 20 else 64
+    tape = torch.from_numpy(np.random.default_rng(1).integers(0, 5, size=(T, B, N), dtype=np.int32)).cuda()
+    K = 2000 if B * N <= 1 << 18 else 400
+    eng.step_tape_device_timed(tape.data_ptr(), T, 0, max(K // 8, 50), 0, 1)
+    torch.cuda.synchronize()
+    best = None
+    for rep in range(2):
+        eng.step_tape_device_timed(tape.data_ptr(), T, 0, K, 0, 1)
+        torch.cuda.synchronize()
+        us = eng.event_elapsed_ms(0, 1) / K * 1e3
+        best = us if best is None else min(best, us)
+    eng.sync()
+    i = eng.info
+    eb = int(i.engine_bytes_per_env_step) * B
+    print(f"{spec:44s} {KIND[int(i.build_kind)]:18s} E {int(i.envs_per_workgroup):2d} {'nt' if int(i.obs_stores_stream) else 'cached':6s} "
+          f"{best:8.3f} us/step {B * N / best / 1e3:7.2f} G a-s/s  engine {eb / 1e6:7.1f} MB -> {eb / best / 1e6:5.2f} TB/s = {eb / best / 8e6:4.2f} of peak", flush=True)
+    env.close()

@@ -129,6 +129,8 @@ def main(out, tag):
         rec["event_ms_per_step"] = b["roofline"]["kernel_ms_per_launch"]
         a_bytes = b["roofline"]["algorithmic_bytes_per_launch"]
         rec["algorithmic_bytes_per_launch"] = a_bytes
+        e_bytes = b["roofline"].get("engine_bytes_per_launch")  # what the engine's layout has to move (rw_info)
+        rec["engine_bytes_per_launch"] = e_bytes
         db = find_db(os.path.join(d, "trace"))
         kt = step_kernel_trace(db) if db else None
         steps_per_launch = 64 if "fused" in name else 1
@@ -159,7 +161,13 @@ def main(out, tag):
             phys = (2.0 * f + w) * 1024.0 / steps_per_launch
             rec["physical_bytes_per_step"] = {"corrected": phys, "lower_bound_uncorrected_fetch": (f + w) * 1024.0 / steps_per_launch,
                                               "fetch_KiB_reported": f, "write_KiB": w}
+            if e_bytes and steps_per_launch == 1:
+                # the self-check of the roofline line: the PMC traffic of a step must be what the layout says it moves
+                ratio = phys / e_bytes
+                rec["physical_over_engine_bytes"] = ratio
+                rec["physical_matches_engine_bytes"] = bool(0.95 <= ratio <= 1.10)
             if us:
+                rec["roofline_on_engine_bytes"] = {"GBps": e_bytes / us / 1e3, "frac_of_8TBps": e_bytes / us / 1e3 / 8000.0} if e_bytes else None
                 rec["roofline_on_physical_bytes"] = {"GBps": phys / us / 1e3, "frac_of_8TBps": phys / us / 1e3 / 8000.0,
                                                      "frac_of_6.29TBps": phys / us / 1e3 / 6290.0}
             if steps_per_launch == 1:
@@ -186,7 +194,7 @@ def main(out, tag):
     lines = [f"sweep {tag}: kernel sources {sha}", f"calibration: {json.dumps({**cal, **factors})}", "",
              "us/step: 'trace avg' = rocprofv3 --stats average; 'b2b' = median of the dispatches that started right behind their predecessor",
              "(the others were submitted late by the profiled host and ran on an idle, cold chip); 'events' = HIP events in the same profiled run.",
-             f"{'config':28s} {'trace avg':>10s} {'b2b':>8s} {'late n':>7s} {'events':>8s} {'A MB':>8s} {'phys MB':>8s} {'frac A/8T':>9s} {'frac phys/8T':>12s} {'phys/6.29T':>10s}"]
+             f"{'config':28s} {'trace avg':>10s} {'b2b':>8s} {'late n':>7s} {'events':>8s} {'A MB':>8s} {'engine MB':>9s} {'phys MB':>8s} {'phys/eng':>8s} {'frac A/8T':>9s} {'frac eng/8T':>11s} {'frac phys/8T':>12s} {'phys/6.29T':>10s}"]
     for r in records:
         if "error" in r:
             lines.append(f"{r['config']:28s} {r['error']}")
@@ -199,8 +207,16 @@ def main(out, tag):
         kt = r.get("kernel_trace", {})
         b2b = kt.get("us_per_step_back_to_back", float("nan"))
         late = kt.get("per_dispatch", {}).get("after_an_idle_gap", {}).get("n", 0)
+        eb = r.get("engine_bytes_per_launch") or float("nan")
+        fe = (r.get("roofline_on_engine_bytes") or {}).get("frac_of_8TBps", float("nan"))
+        ratio = r.get("physical_over_engine_bytes", float("nan"))
+        flag = "" if r.get("physical_matches_engine_bytes", True) else "  <-- outside [0.95, 1.10]"
         lines.append(f"{r['config']:28s} {us:10.3f} {b2b:8.3f} {late:7d} {r['event_ms_per_step'] * 1e3:8.3f} {r['algorithmic_bytes_per_launch'] / 1e6:8.2f} "
-                     f"{ph / 1e6:8.2f} {fa:9.3f} {fp:12.3f} {fm:10.3f}")
+                     f"{eb / 1e6:9.2f} {ph / 1e6:8.2f} {ratio:8.3f} {fa:9.3f} {fe:11.3f} {fp:12.3f} {fm:10.3f}{flag}")
+    bad = [r["config"] for r in records if r.get("physical_matches_engine_bytes") is False]
+    lines.append("")
+    lines.append("physical (PMC) bytes / engine bytes within [0.95, 1.10] for every per-step config" if not bad
+                 else f"PHYSICAL TRAFFIC DOES NOT MATCH THE ENGINE'S BYTE MODEL: {', '.join(bad)}")
     with open(os.path.join(ROOT, "gpurun_out", f"{tag}_sweep.txt"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
     print("\n".join(lines))

@@ -48,12 +48,13 @@ class RwInfo(C.Structure):
         "envs_per_workgroup", "threads_per_workgroup", "n_workgroups", "lds_bytes", "device_id",
         "compute_units", "specialised", "state_layout", "build_kind")] + [
         ("algorithmic_bytes_per_env_step", C.c_int64),
-        ("device_name", C.c_char * 128), ("arch_name", C.c_char * 64), ("obs_stores_stream", C.c_int32), ("reserved", C.c_int32 * 7)]
+        ("device_name", C.c_char * 128), ("arch_name", C.c_char * 64), ("obs_stores_stream", C.c_int32), ("reserved0", C.c_int32),
+        ("engine_bytes_per_env_step", C.c_int64), ("reserved", C.c_int32 * 4)]
 
 
 EXPORTS = (
     "rw_create", "rw_destroy", "rw_last_error", "rw_reset", "rw_step", "rw_step_device",
-    "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_sync", "rw_get_buffer", "rw_read", "rw_read_outputs", "rw_write",
+    "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_mark_views_stale", "rw_sync", "rw_get_buffer", "rw_read", "rw_read_outputs", "rw_write",
     "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
     "rw_abi_version", "rw_debug_timeline", "rw_device_malloc", "rw_device_free", "rw_copy_to_device",
     "rw_copy_to_host", "rw_snapshot_create", "rw_snapshot_save", "rw_snapshot_restore", "rw_snapshot_destroy",
@@ -108,6 +109,7 @@ def load(path: str | None = None):
     lib.rw_step_tape_device_timed.argtypes = [vp, vp, i32, i32, i32, i32, i32]
     lib.rw_refresh_obs.argtypes = [vp]
     lib.rw_refresh_grid.argtypes = [vp]
+    lib.rw_mark_views_stale.argtypes = [vp]
     lib.rw_sync.argtypes = [vp]
     lib.rw_get_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.rw_read.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -303,6 +305,16 @@ class Engine:
     def refresh_grid(self):
         """Brings the exported int32 grid (a derived view) up to date with the steps enqueued so far."""
         self._check(self.lib.rw_refresh_grid(self._h))
+
+    def mark_views_stale(self):
+        """Steps ran that the host side did not see (a replayed HIP graph): the derived views are rebuilt when next asked for."""
+        self._check(self.lib.rw_mark_views_stale(self._h))
+
+    def release_arena(self):
+        """Frees the device tapes rollout_host() keeps between calls (grow-only otherwise, for the engine's lifetime)."""
+        for p, _ in self._arena.values():
+            self._check(self.lib.rw_device_free(self._h, p))
+        self._arena = {}
 
     def sync(self):
         self._check(self.lib.rw_sync(self._h))

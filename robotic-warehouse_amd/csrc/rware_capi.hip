@@ -54,6 +54,8 @@ struct rw_engine {
     bool specialised = false;
     bool grid_stale = false;   // steps / resets have run since RW_BUF_GRID was last rebuilt (refresh_grid)
     bool agents_stale = false; // ... since RW_BUF_AGENT_X .. _DELIVERED were last unpacked from the records (refresh_agents)
+    bool captured = false;     // a launch of this engine was recorded into a HIP graph: replays run without any host code, so the
+                               // two flags above can no longer be trusted — the derived views are rebuilt whenever asked for
     size_t rec_off = 0;
     uint32_t *d_rec = nullptr; // [B][N] packed agent records (rw::rec_pack): the agents' state as the step kernels keep it
     void *slab = nullptr;      // the single device allocation behind every buffer below
@@ -101,8 +103,9 @@ using rw_tab::StaticEntry;
 namespace rw_tab {
 const StaticEntry *static_group(int group, int *n) {
     using fn_t = const StaticEntry *(*)(int *);
-    static const fn_t kGroups[kStaticGroups] = {static_group_0, static_group_1, static_group_2, static_group_3, static_group_4, static_group_5,
-                                                static_group_6, static_group_7, static_group_8, static_group_9};
+    static const fn_t kGroups[kStaticGroups] = {static_group_0,  static_group_1,  static_group_2,  static_group_3,  static_group_4,  static_group_5,
+                                                static_group_6,  static_group_7,  static_group_8,  static_group_9,  static_group_10, static_group_11,
+                                                static_group_12, static_group_13, static_group_14, static_group_15, static_group_16, static_group_17};
     return kGroups[group](n);
 }
 }  // namespace rw_tab
@@ -111,6 +114,11 @@ namespace {
 int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     la.op = op | (la.timeline ? rw::OP_FLAG_TIMELINE : 0);
     if (op != rw::OP_OBS) eng->grid_stale = eng->agents_stale = true;  // the kernels keep the shadow and the packed agent records current, not the int32 views
+    if (!eng->own_stream && !eng->captured) {  // (a stream of the caller's may be capturing; the engine's own stream never is)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(eng->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) eng->captured = true;
+        else (void)hipGetLastError();
+    }
     if (start || stop)  // the events ride on this dispatch (its own start / end timestamps): no marker packets in the stream
         hipExtLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
                               eng->stream, start, stop, 0, (const rw::Params *)eng->d_prm, RW_LAUNCH_ARGS(la));
@@ -138,7 +146,7 @@ int rebuild_shadow(rw_engine *eng) {
 
 // RW_BUF_GRID is a derived view: brought up to date from the shelf shadow and the agent coordinates when it is asked for
 int refresh_grid(rw_engine *eng) {
-    if (!eng->grid_stale) return RW_OK;
+    if (!eng->grid_stale && !eng->captured) return RW_OK;
     const int B = eng->prm.B, HW = eng->prm.HW, N = eng->prm.N;
     const size_t n = (size_t)B * HW, na = (size_t)B * N;
     // (grid-stride loops, one wavefront per workgroup, 64 cells / agents per thread: a few thousand workgroups at the big batches)
@@ -164,7 +172,7 @@ int refresh_grid(rw_engine *eng) {
 bool is_agent_view(int kind) { return kind >= RW_BUF_AGENT_X && kind <= RW_BUF_AGENT_DELIVERED; }
 unsigned agent_blocks(size_t n) { return (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024); }
 int refresh_agents(rw_engine *eng) {
-    if (!eng->agents_stale) return RW_OK;
+    if (!eng->agents_stale && !eng->captured) return RW_OK;
     const size_t n = (size_t)eng->prm.B * eng->prm.N;
     hipLaunchKernelGGL((rw::rware_unpack_agents_kernel<>), dim3(agent_blocks(n)), dim3(256), 0, eng->stream, (const uint32_t *)eng->d_rec,
                        (int32_t *)eng->buf[RW_BUF_AGENT_X].ptr, (int32_t *)eng->buf[RW_BUF_AGENT_Y].ptr, (int32_t *)eng->buf[RW_BUF_AGENT_DIR].ptr,
@@ -376,7 +384,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // Pick a specialised build: exact-shape entries before size-static ones, first match wins.
         const bool geom_default = cfg->envs_per_workgroup == 0 && cfg->threads_per_workgroup == 0;
         const StaticEntry *best = nullptr;
-        const char *pq = getenv("RWARE_PREFER_QRT");
+        const char *pq = getenv("RWARE_PREFER_QRT");  // (test / A-B hook: skip the exact (N, Q) builds)
         const bool prefer_qrt = pq && pq[0] == '1';
         for (int exact = 1; exact >= 0 && !best; --exact)
             for (int grp = 0; grp < rw_tab::kStaticGroups && !best; ++grp) {
@@ -515,11 +523,11 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         const long long chunk = (long long)E * N * eng->L;                    // floats of one workgroup's observations
         const double obs_mb = (double)B * N * eng->L * 4 / 1e6;
         bool nt = chunk <= 14336 || obs_mb > 240.0;
-        const char *pref = getenv("RWARE_OBS_STORES");
-        if (cfg->stream_flags & RW_OBS_STORES_CACHED) nt = false;
-        if (cfg->stream_flags & RW_OBS_STORES_STREAM) nt = true;
+        const char *pref = getenv("RWARE_OBS_STORES");  // (A/B hook: moves the default only — an explicit flag of the caller wins)
         if (pref && !strcmp(pref, "cached")) nt = false;
         if (pref && !strcmp(pref, "stream")) nt = true;
+        if (cfg->stream_flags & RW_OBS_STORES_CACHED) nt = false;
+        if (cfg->stream_flags & RW_OBS_STORES_STREAM) nt = true;
         p.nt_obs = nt ? 1 : 0;
         if (nt && eng->kernel_nt) eng->kernel = eng->kernel_nt;  // (exact builds: the choice is a kernel, not a branch)
     }
@@ -838,6 +846,12 @@ int rw_sync(rw_engine *eng) {
     return RW_OK;
 }
 
+int rw_mark_views_stale(rw_engine *eng) {
+    if (!eng) return RW_ERR_INVALID_ARG;
+    eng->grid_stale = eng->agents_stale = true;
+    return RW_OK;
+}
+
 int rw_refresh_grid(rw_engine *eng) {
     if (!eng) return RW_ERR_INVALID_ARG;
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
@@ -957,6 +971,14 @@ int rw_get_info(const rw_engine *eng, rw_info *out) {
     // A = 8HW + 4N + 40N + 4Q + 16 + 4NL + 4N + 4
     out->algorithmic_bytes_per_env_step =
         8LL * p.HW + 4LL * p.N + 40LL * p.N + 4LL * p.Q + 16 + 4LL * p.N * eng->L + 4LL * p.N + 4;
+    // What THIS layout has to move per env-step: the shelf shadow (read), the packed agent records (read +
+    // write), the actions, the request queue (read; written only on a delivery), steps + inactive (read + write) and the
+    // pending-reset flag (read), the observation, the rewards, `terminated`; with communication bits the stored messages
+    // (read + write); IMAGE_DICT: the feature vectors.  The physical (PMC) traffic of a step is checked against this figure
+    // (profiles/tools/sweep_collect.py), and bench.py's `frac_engine` is priced on it: a fraction of a bandwidth, never above 1.
+    out->engine_bytes_per_env_step =
+        (int64_t)p.HW * (eng->wide ? 2 : 1) + 8LL * p.N + 4LL * p.N * (1 + eng->msg_bits) + 4LL * p.Q + 17 + 4LL * p.N * eng->L +
+        4LL * p.N + 1 + (eng->msg_bits ? 8LL * p.N : 0) + (p.features ? 24LL * p.N : 0);
     snprintf(out->device_name, sizeof out->device_name, "%s", eng->prop.name);
     snprintf(out->arch_name, sizeof out->arch_name, "%s", eng->prop.gcnArchName);
     return RW_OK;

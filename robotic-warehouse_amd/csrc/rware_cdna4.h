@@ -10,21 +10,44 @@
 //   wave_sync                    orders the LDS traffic of ONE wavefront (64 lanes run in
 //                                lockstep, so cross-lane exchange through LDS needs no s_barrier).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
+
+#define RW_GLOBAL __attribute__((address_space(1)))  // (see as_global below)
 
 namespace rw {
 
-__device__ __forceinline__ void lds_dma_b128(const void *g_lane, void *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane,
+__device__ __forceinline__ void lds_dma_b128(const RW_GLOBAL void *g_lane, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(g_lane,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
-__device__ __forceinline__ void lds_dma_b32(const void *g_lane, void *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane,
+__device__ __forceinline__ void lds_dma_b32(const RW_GLOBAL void *g_lane, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(g_lane,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
 }
+// lds_zero_b128_blind(p): 16 bytes of zeros to LDS through an instruction hipcc does not look into.  hipcc orders every LDS
+// write it can see behind an LDS-DMA still in flight (s_waitcnt vmcnt(0): it cannot prove that the destinations differ), which
+// serialises "issue the stage-in DMA, then clear the scratch arrays" into DMA round trip + clear.  The scratch arrays never
+// overlap a DMA destination (rw::LdsLayout), so the clear may run underneath the DMA; the caller waits lgkmcnt(0) itself.
+__device__ __forceinline__ void lds_zero_b128_blind(void *lds_ptr) {
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const v4i_t z = {0, 0, 0, 0};
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_ptr;
+    asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(z));
+}
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// RW_GLOBAL / as_global(p): a pointer that comes out of the parameter block (i.e. was loaded from memory) is a "generic"
+// pointer to hipcc, addressed with flat_* instructions: those tick BOTH memory counters (every later `s_waitcnt lgkmcnt(0)`
+// for an LDS read then also waits for them), cannot take the scalar-base addressing form, and take the long way through the
+// address-aperture check.  as_global says what such a pointer is — device memory — so the accesses become global_*.
+template <typename T>
+__device__ __forceinline__ RW_GLOBAL T *as_global(T *p) { return (RW_GLOBAL T *)p; }
+template <typename T>
+__device__ __forceinline__ const RW_GLOBAL char *as_bytes(const RW_GLOBAL T *p) { return (const RW_GLOBAL char *)p; }
 // HW_ID (hwreg 4): wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]; XCC_ID (hwreg 20): xcc[3:0]
 __device__ __forceinline__ uint32_t hw_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 4); }
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20); }
@@ -41,7 +64,7 @@ __device__ __forceinline__ void keep_sgpr(Ts... v) {
 __device__ __forceinline__ void keep_vgpr(int a, int b) { asm volatile("" ::"v"(a), "v"(b)); }
 // keep_sgpr_ptr(p, q, ...): the same for (wave-uniform) pointers
 template <typename T>
-__device__ __forceinline__ void keep_sgpr_ptr1(const T *p) { asm volatile("" ::"s"(p)); }
+__device__ __forceinline__ void keep_sgpr_ptr1(T p) { asm volatile("" ::"s"(p)); }
 template <typename... Ts>
 __device__ __forceinline__ void keep_sgpr_ptr(Ts... p) {
     (keep_sgpr_ptr1(p), ...);

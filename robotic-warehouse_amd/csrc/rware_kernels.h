@@ -54,10 +54,12 @@
 //                              N hops without either       => i feeds a cycle => fail.
 // The tie rule (lowest agent id among equal depths) is the pinned rule of DESIGN.md §tie-break.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stddef.h>
 #include <stdint.h>
 
 #include <type_traits>
+#endif
 
 #include <rware_cdna4.h>
 
@@ -69,6 +71,12 @@
 #define RW_RARE(c) __builtin_expect(!!(c), 0)
 
 namespace rw {
+
+// (the two type-level helpers the kernel needs, spelled out: the run-time compiler — hipRTC, rware_jit.cpp — has no <type_traits>)
+template <bool C, typename A, typename B> struct pick_type { using type = A; };
+template <typename A, typename B> struct pick_type<false, A, B> { using type = B; };
+struct yes_t { static constexpr bool value = true; };
+struct no_t { static constexpr bool value = false; };
 
 enum : int { OP_STEP = 0, OP_RESET = 1, OP_OBS = 2 };
 enum : int { ACT_NOOP = 0, ACT_FORWARD = 1, ACT_LEFT = 2, ACT_RIGHT = 3, ACT_TOGGLE = 4 };
@@ -257,7 +265,7 @@ constexpr int packed_transposed_layers(uint32_t packed, int n) {  // Params::tra
 // Asynchronous flat dword copy HBM -> LDS through the LDS-DMA path.  dwordx4 pieces (1 KiB per wave
 // instruction) when the source is 16-byte aligned, dword pieces otherwise; `lds_dst` is 16-byte
 // aligned.  Nothing is waited for here.
-__device__ __forceinline__ void dma_in(int32_t *lds_dst, const int32_t *src, int n, int tid, int T) {
+__device__ __forceinline__ void dma_in(int32_t *lds_dst, const RW_GLOBAL int32_t *src, int n, int tid, int T) {
     const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
     if ((((uintptr_t)src) & 15u) == 0) {  // wave-uniform
         const int n4 = n >> 2;
@@ -348,12 +356,15 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
     }
 }
 
+#ifndef RW_AB_OCC8
+#define RW_AB_OCC8 0  // A/B hook (profiles/tools/ab.sh): 1 = ask for the register budget of 8 wavefronts per SIMD in every per-step build
+#endif
 template <int R, typename CellT, typename Cfg, bool kRollout, int kObs = OBS_FLATTENED>
 __global__ void __launch_bounds__(256)
 #if defined(__HIPCC__)
 // the half-size-workgroup exact builds hold a 16384-env batch only if 8 workgroups fit a CU: ask for that register budget
 // (one of them — 8 agents, 16 queue slots — came out at 66 VGPRs, 7 per CU: 11.7 instead of ~9.6 us per step)
-__attribute__((amdgpu_waves_per_eu((Cfg::kE == 8 && (Cfg::kN == 7 || Cfg::kN == 8) && !Cfg::kQrt && !kRollout) ? 8 : 1, 8)))
+__attribute__((amdgpu_waves_per_eu((((RW_AB_OCC8 >= 0) && Cfg::kE == 8 && (Cfg::kN == 7 || Cfg::kN == 8) && !Cfg::kQrt && !kRollout) || (RW_AB_OCC8 > 0 && !kRollout)) ? 8 : 1, 8)))
 #endif
 rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L0 = 8 + 7 * CELLS, OW0 = (L0 + 31) / 32;
@@ -386,40 +397,34 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     const int S = Cfg::kS ? Cfg::kS : p.S, SW = (S + 32) / 32, B = p.B;
     const int nea = ne * N;
     // agent phases with cross-lane exchange in registers (see AG); kDirect: own record fetched straight into registers
-    constexpr bool kRegAG = Cfg::kN >= 1 && Cfg::kN <= 12;  // (the chain links of an env as one word: 4 bits x 6 agents, or 5 bits x 12 in 64)
+    // (every registered agent count, rware/__init__.py:16: the chain links of an env as one word — 4 bits x 6 agents in 32 bits,
+    //  5 bits x 12 in 64, 6 bits x 19 in 128)
+    constexpr bool kRegAG = Cfg::kN >= 1 && Cfg::kN <= 19;
     constexpr bool kDirect = kRegAG && Cfg::kE != 0 && (!kMsg || (Cfg::kM >= 1 && Cfg::kM <= 4));  // (message words: one register each)
     // ONE scalar batch, first thing in the kernel, for every field of the parameter block that the stage-in and the agent
     // phases read: left to itself hipcc fetches each field where it is first used — three dependent scalar-cache round
     // trips in the prologue (every launch starts with cold caches) and more inside the agent phases, which run on one
     // wavefront and cannot hide them.  keep_sgpr*() pins the values in scalar registers right here.
-    CellT *const g_shadow = reinterpret_cast<CellT *>(p.shelf_shadow);
-    uint32_t *const q_rec = p.arec;
-    int32_t *const q_queue = p.queue, *const q_steps = p.steps, *const q_inact = p.inactive;
-    const uint32_t *const q_hw = p.highway_bits;
-    const uint8_t *const q_need = p.need_reset;
+    // (as_global: these pointers were loaded from memory — hipcc would address them with flat_* instructions, see rware_cdna4.h)
+    RW_GLOBAL CellT *const g_shadow = as_global(reinterpret_cast<CellT *>(p.shelf_shadow));
+    RW_GLOBAL uint32_t *const q_rec = as_global(p.arec);
+    RW_GLOBAL int32_t *const q_queue = as_global(p.queue), *const q_steps = as_global(p.steps), *const q_inact = as_global(p.inactive);
+    const RW_GLOBAL uint32_t *const q_hw = as_global(p.highway_bits);
+    RW_GLOBAL uint8_t *const q_need = as_global(p.need_reset);
     const int k_reward_type = p.reward_type, k_max_inactivity = p.max_inactivity, k_max_steps = p.max_steps;
     const int k_autoreset = p.autoreset, k_n_goals = p.n_goals, k_normalised = p.normalised, k_nt = p.nt_obs;
     const int k_goal0 = p.goal_cells[0], k_goal1 = p.goal_cells[1];
-    // (exact-shape builds whose LDS carve-up is a compile-time constant clear their scratch regions while this batch is in
-    //  flight and pin it afterwards — kClearFirst, below; the others pin it here)
-#ifndef RW_CLEAR_FIRST_MODE
-#define RW_CLEAR_FIRST_MODE 0
-#endif
-    constexpr bool kClearFirst = RW_CLEAR_FIRST_MODE != 0 && (RW_CLEAR_FIRST_MODE == 1 || kImage || kMsg) &&
-                                 Cfg::kN != 0 && Cfg::kE != 0 && (!kImage || Cfg::kNL > 0) && (!kMsg || Cfg::kM != 0);
-    if constexpr (!kClearFirst) {
-        keep_sgpr_ptr(g_shadow, q_rec, q_queue, q_steps, q_inact, q_hw, q_need);
-        keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised, k_nt);
-        if constexpr (Cfg::kQrt) keep_sgpr(Q);  // (the stage-in of the queue needs it)
-    }
+    keep_sgpr_ptr(g_shadow, q_rec, q_queue, q_steps, q_inact, q_hw, q_need);
+    keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised, k_nt);
+    if constexpr (Cfg::kQrt) keep_sgpr(Q);  // (the stage-in of the queue needs it)
     // IMAGE kernels: the layer list and its switches belong to the same batch — the image gather used to fetch them where
     // it uses them (one scalar-cache round trip per layer, per goal cell and per switch, inside the phase that stands between
     // the agent phases and the first observation store: 2.5 us against 0.7 us for the FLATTENED gather, r02_timeline_image)
     int k_n_layers = 0, k_directional = 0, k_transposed = 0;
     int k_layer[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float *q_features = nullptr;
+    RW_GLOBAL float *q_features = nullptr;
     if constexpr (kImage) {
-        q_features = p.features;
+        q_features = as_global(p.features);
         keep_sgpr_ptr(q_features);
         if constexpr (Cfg::kNL > 0) {  // the layer list is part of the build: every select on a layer id folds
             k_n_layers = Cfg::kNL;
@@ -484,16 +489,20 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         for (int i = tid; i < ne * SW; i += T) s_req[i] = 0u;
         if (tid == 0) s_misc[0] = 0;
     };
+    // The same clear in whole 16-byte pieces (every sub-array starts on a 16-byte boundary and is padded to one: LdsLayout),
+    // through stores hipcc does not order behind the stage-in DMA (lds_zero_b128_blind): kDmaFirst builds issue the DMA first and
+    // clear underneath its round trip.  The caller waits for the stores (lds_wait) before the barrier.
+    auto clear_scratch_blind = [&]() {
+        const int reg[4][2] = {{lo.ga, lo.zero_end}, {lo.depth, lo.win}, {lo.req, lo.envi}, {lo.misc, lo.total}};  // (req and obits are neighbours)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            for (int i = tid; i < ((reg[r][1] - reg[r][0]) >> 2); i += T) lds_zero_b128_blind(smem + reg[r][0] + 4 * i);
+    };
     // kDirect: every agent lane fetches ITS OWN record (and its env's flags and counters) from HBM straight into registers,
     // first thing in the kernel: the loads fly beside the clear and the stage-in DMA, are complete at the barrier that
     // drains the DMA, and the agent phases start without an LDS read.  The LDS copies the later phases read (window
     // gather, write-back) are written by the agent lanes together with their results.
-    if constexpr (kClearFirst) {  // the LDS clear needs no parameter: it runs under the scalar batch's (cold) round trip
-        clear_scratch();
-        keep_sgpr_ptr(g_shadow, q_rec, q_queue, q_steps, q_inact, q_hw, q_need);
-        keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised, k_nt);
-    }
-    const uint8_t *flag_src = (op == OP_RESET) ? la.reset_mask : q_need;  // OP_RESET: all-ones when no mask was given
+    const RW_GLOBAL uint8_t *flag_src = (op == OP_RESET) ? as_global(la.reset_mask) : q_need;  // OP_RESET: all-ones when no mask was given
     int r_x = 0, r_y = 0, r_d = 0, r_carry = 0, r_deliv = 0, r_act = ACT_NOOP, r_flag = 0, r_steps = 0, r_inact = 0;
     uint32_t r_rec = 0;
     auto unpack_own = [&]() {  // (W is a compile-time constant in the builds that use this)
@@ -514,7 +523,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                                 // so that nothing up here waits for it: the clear and the DMA issue run under its latency)
             if (op == OP_STEP) r_act = la.actions[gi * AM];
             if constexpr (kMsg) {
-                r_msg = p.amsg[gi];
+                r_msg = as_global(p.amsg)[gi];
                 if (op == OP_STEP)
 #pragma unroll
                     for (int k = 0; k < KMW; ++k) r_mw[k] = la.actions[gi * AM + 1 + k];
@@ -552,6 +561,11 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     // were the first thing it issued, so they are back while the other wavefronts' DMA is still in flight — it computes
     // intent and occupant in that window, before the barrier that everything else of the agent phases has to wait for.
     constexpr bool kEarly = kDirect && !kRollout && Cfg::kT >= 128;
+#ifndef RW_AB_DMA_FIRST
+#define RW_AB_DMA_FIRST 0  // A/B hook (profiles/tools/ab.sh)
+#endif
+    // exact-shape per-step builds: stage-in DMA first, scratch clear underneath it (see clear_scratch_blind)
+    constexpr bool kDmaFirst = RW_AB_DMA_FIRST != 0 && Cfg::kE != 0 && Cfg::kN != 0;
     Intent early{ACT_NOOP, 0, 0, 0, 0, -1};
     // builds that stage the agents through LDS: the DMA put the chunk's packed records into the `ax` slot; every thread
     // unpacks its agents in place (reads its own slot before it overwrites it) into the five per-agent LDS arrays
@@ -562,7 +576,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             s_ax[i] = c - y * W; s_ay[i] = y; s_dir[i] = rec_dir(r); s_carry[i] = rec_carry(r); s_deliv[i] = rec_deliv(r);
         }
     };
-    if constexpr (!kClearFirst) clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
+    if constexpr (!kDmaFirst) clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
     RW_MARK(TL_ZEROED);
     if constexpr (Cfg::kE != 0) {
         // Static build: every DMA destination is contiguous in LDS and every source chunk is a whole
@@ -571,16 +585,15 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         static_assert((Cfg::kE * Cfg::kN) % 4 == 0 && (Cfg::kE * Cfg::kQcap) % 4 == 0 && Cfg::kE % 4 == 0, "chunk not 16-byte granular");
         static_assert(!kMsg || Cfg::kN == 0 || Cfg::kM != 0, "an exact-shape _MSG build needs its communication bits at compile time");
         static_assert((Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0, "shelf chunk not 16-byte granular");
-        const char *src[12] = {
-            reinterpret_cast<const char *>(g_shadow + (size_t)e0 * HW),
+        const RW_GLOBAL char *src[12] = {
+            as_bytes(g_shadow + (size_t)e0 * HW),
             // the chunk's packed records go to the `ax` slot and are unpacked in place behind the barrier (unpack_records);
             // the ay / dir / carry / deliv slots have no DMA source any more (entries 2..5 are skipped below)
-            reinterpret_cast<const char *>(q_rec + (size_t)e0 * N), nullptr, nullptr, nullptr, nullptr,
-            reinterpret_cast<const char *>(op == OP_STEP ? la.actions + (size_t)e0 * N * AM
-                                                         : reinterpret_cast<const int32_t *>(q_rec) + (size_t)e0 * N),
-            reinterpret_cast<const char *>(q_queue + (size_t)e0 * Q), reinterpret_cast<const char *>(q_hw),
-            reinterpret_cast<const char *>(q_steps + e0), reinterpret_cast<const char *>(q_inact + e0),
-            reinterpret_cast<const char *>(flag_src + e0)};
+            as_bytes(q_rec + (size_t)e0 * N), nullptr, nullptr, nullptr, nullptr,
+            op == OP_STEP ? as_bytes(as_global(la.actions) + (size_t)e0 * N * AM) : as_bytes(q_rec + (size_t)e0 * N),
+            as_bytes(q_queue + (size_t)e0 * Q), as_bytes(q_hw),
+            as_bytes(q_steps + e0), as_bytes(q_inact + e0),
+            as_bytes(flag_src + e0)};
         const int seg[13] = {lo.gs, lo.ax, lo.ay, lo.dir, lo.carry, lo.deliv, lo.act, lo.queue, lo.hw,
                              lo.dsteps, lo.dinact, lo.dflag, lo.dma_end};  // dword offsets, all multiples of 4
         if constexpr (Cfg::kN != 0) {
@@ -604,8 +617,9 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                 const int pieces = (Cfg::kE * Cfg::kN) >> 2;
                 for (int c = 0; c < pieces; c += 64, ++job)
                     if (job % dma_w == wave_s && c + lane < pieces)
-                        lds_dma_b128(reinterpret_cast<const char *>(p.amsg + (size_t)e0 * N) + (size_t)(c + lane) * 16, smem + lo.msg + 4 * c);
+                        lds_dma_b128(as_bytes(as_global(p.amsg) + (size_t)e0 * N) + (size_t)(c + lane) * 16, smem + lo.msg + 4 * c);
             }
+            if constexpr (kDmaFirst) clear_scratch_blind();  // (under the DMA's round trip)
             if constexpr (kEarly) {
                 constexpr int KN = Cfg::kN, KG = 64 / KN;
                 if (uniform(wave) * KG < Cfg::kE) {  // wave-uniform: a wavefront that runs agent phases
@@ -621,7 +635,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             const int pieces = (lo.dma_end - lo.gs) >> 2;
             for (int b = wave * 64; b < pieces; b += nw * 64) {  // wave-uniform
                 const int t = b + lane;
-                const char *g = src[0] + (size_t)t * 16;
+                const RW_GLOBAL char *g = src[0] + (size_t)t * 16;
 #pragma unroll
                 for (int k = 1; k < 12; ++k)
                     if (t >= ((seg[k] - seg[0]) >> 2)) g = src[k] + (size_t)(t - ((seg[k] - seg[0]) >> 2)) * 16;
@@ -633,6 +647,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         //  the bitmap is allocated rounded up to 16 bytes, the flags sit in the padded slab / the +64 mask buffer)
         RW_MARK(TL_DMA_ISSUED);
         RW_MARK(TL_ENV_LOADED);
+        if constexpr (kDmaFirst) lds_wait();  // (the blind clear: hipcc does not count those stores)
         __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
         if constexpr (!kDirect) {  // (kDirect: the leader lane of each env publishes these from its registers, in AG)
             const uint8_t *s_dflag = reinterpret_cast<const uint8_t *>(smem + lo.dflag);
@@ -650,13 +665,12 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             lds_barrier();
         }
     } else {
-        dma_in(smem + lo.gs, reinterpret_cast<const int32_t *>(g_shadow + (size_t)e0 * HW),
-               (ne * HW * (int)sizeof(CellT) + 3) >> 2, tid, T);
-        dma_in(s_ax, reinterpret_cast<const int32_t *>(q_rec) + (size_t)e0 * N, nea, tid, T);  // packed records -> the `ax` slot
+        dma_in(smem + lo.gs, (const RW_GLOBAL int32_t *)(g_shadow + (size_t)e0 * HW), (ne * HW * (int)sizeof(CellT) + 3) >> 2, tid, T);
+        dma_in(s_ax, (const RW_GLOBAL int32_t *)(q_rec + (size_t)e0 * N), nea, tid, T);  // packed records -> the `ax` slot
         dma_in(s_queue, q_queue + (size_t)e0 * Q, ne * Q, tid, T);
-        if (op == OP_STEP) dma_in(s_act, la.actions + (size_t)e0 * N * AM, nea * AM, tid, T);
-        if (kMsg) dma_in(s_msg, p.amsg + (size_t)e0 * N, nea, tid, T);
-        dma_in(smem + lo.hw, reinterpret_cast<const int32_t *>(q_hw), (HW + 31) / 32, tid, T);
+        if (op == OP_STEP) dma_in(s_act, as_global(la.actions) + (size_t)e0 * N * AM, nea * AM, tid, T);
+        if (kMsg) dma_in(s_msg, as_global(p.amsg) + (size_t)e0 * N, nea, tid, T);
+        dma_in(smem + lo.hw, (const RW_GLOBAL int32_t *)q_hw, (HW + 31) / 32, tid, T);
         RW_MARK(TL_DMA_ISSUED);
         lds_barrier();  // orders the s_misc clear above before the flag writes below
         for (int e = tid; e < ne; e += T) {
@@ -881,10 +895,12 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         }
         // ------------------------------------------------------------ P2b: winner per contested cell
         // larger follower depth wins, then the LOWER agent id; only movers compete.  One word per agent, target cell above
-        // the priority (depth << 4 | 15 - index): agent k beats me iff the cell fields agree and its word is the larger one.
-        // A stationary agent announces a cell nobody can target (0x7fff00 | index) and so neither beats nor is beaten.
-        const uint32_t vme = (nxt != -2) ? ((uint32_t)tg << 8) | ((uint32_t)depth << 4) | (uint32_t)(15 - a_idx)
-                                         : 0x7fff0000u | ((uint32_t)a_idx << 8);
+        // the priority (depth << IB | 2^IB - 1 - index; IB = 4 bits up to 16 agents, 5 beyond): agent k beats me iff the cell
+        // fields agree and its word is the larger one.  A stationary agent announces a cell nobody can target (0x1fff00 | index)
+        // and so neither beats nor is beaten.
+        constexpr int IB = KN <= 16 ? 4 : 5, PW = 2 * IB;  // (a depth is at most N - 1: the same width)
+        const uint32_t vme = (nxt != -2) ? ((uint32_t)tg << PW) | ((uint32_t)depth << IB) | (uint32_t)((1 << IB) - 1 - a_idx)
+                                         : (0x1fff00u | (uint32_t)a_idx) << PW;
         int kv[KN];
         env_gather<KN>((int)vme, lane_base, kv);
         // (A subtract-and-running-minimum form of this test — one compare at the end — passed the host emulation and failed a
@@ -893,25 +909,34 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         int lose = 0;
 #pragma unroll
         for (int k = 0; k < KN; ++k)  // (bitwise on purpose: no short-circuit branches)
-            lose |= ((((uint32_t)kv[k] ^ vme) < 256u) & ((uint32_t)kv[k] > vme)) ? 1 : 0;
+            lose |= ((((uint32_t)kv[k] ^ vme) < (1u << PW)) & ((uint32_t)kv[k] > vme)) ? 1 : 0;
         // ------------------------------------------------------------ P2c: commit (:871-876)
         int commit = (nxt == -1) ? (lose ^ 1) : ((nxt == -2) ? 1 : 0);
         if (chains) {  // walk the chain ahead: i -> nxt(i) -> ... on the gathered links
             // every agent's (nxt + 2 | win << LB) as one field of a word every lane of the env holds: following a link is
             // a shift and a mask (a register array indexed by a run-time agent index would live in scratch memory).
-            // N <= 6: 3 + 1 bits per agent in 32 bits; 7 <= N <= 12: 4 + 1 bits per agent in 64 bits (two OR-reductions).
-            constexpr int LB = KN <= 6 ? 3 : 4, FW = LB + 1;
+            // N <= 6: 3 + 1 bits per agent in 32 bits; 7 <= N <= 12: 4 + 1 bits per agent in 64 bits (two OR-reductions);
+            // 13 <= N <= 19: 5 + 1 bits per agent in 128 bits — ONE gather of every agent's field (N cross-lane moves), the word
+            // assembled in each lane with compile-time shifts (four OR-reductions would be 4 N moves).
+            constexpr int LB = KN <= 6 ? 3 : KN <= 12 ? 4 : 5, FW = LB + 1;
             constexpr uint32_t LM = (1u << LB) - 1u;
-            using links_t = typename std::conditional<KN <= 6, uint32_t, uint64_t>::type;
+            using links_t = typename pick_type<KN <= 6, uint32_t, typename pick_type<KN <= 12, uint64_t, u128>::type>::type;
             links_t links;
             {
-                const links_t own = (links_t)(uint32_t)((nxt + 2) | ((lose ^ 1) << LB)) << (FW * a_idx);
+                const uint32_t own_field = (uint32_t)((nxt + 2) | ((lose ^ 1) << LB));
                 if constexpr (KN <= 6) {
-                    links = (links_t)(uint32_t)env_or<KN>((int)(uint32_t)own, lane_base);
-                } else {
+                    links = (links_t)(uint32_t)env_or<KN>((int)(own_field << (FW * a_idx)), lane_base);
+                } else if constexpr (KN <= 12) {
+                    const uint64_t own = (uint64_t)own_field << (FW * a_idx);
                     const uint32_t lo = (uint32_t)env_or<KN>((int)(uint32_t)own, lane_base);
-                    const uint32_t hi = (uint32_t)env_or<KN>((int)(uint32_t)((uint64_t)own >> 32), lane_base);
+                    const uint32_t hi = (uint32_t)env_or<KN>((int)(uint32_t)(own >> 32), lane_base);
                     links = (links_t)(((uint64_t)hi << 32) | lo);
+                } else {
+                    int fv[KN];
+                    env_gather<KN>((int)own_field, lane_base, fv);
+                    links = 0;
+#pragma unroll
+                    for (int k = 0; k < KN; ++k) links |= (links_t)(uint32_t)fv[k] << (FW * k);
                 }
             }
             int j = a_idx, hops = 0, ok = 1, cm = 0;
@@ -922,7 +947,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                 const int nj = (int)(ent & LM) - 2;
                 ok &= (int)(ent >> LB);
                 ++hops;
-                const int nnj = (int)((uint32_t)(links >> (FW * (nj & (KN <= 6 ? 7 : (nj < 0 ? 0 : 15))))) & LM) - 2;  // nxt of the successor (not used when nj < 0)
+                const int nnj = (int)((uint32_t)(links >> (FW * (nj & (KN <= 6 ? 7 : (nj < 0 ? 0 : 31))))) & LM) - 2;  // nxt of the successor (not used when nj < 0)
                 const bool to_empty = nj == -1;                     // drains into an empty cell
                 const bool back = nj == a_idx;                      // a cycle through me; the 2-swap is refused
                 const bool stuck = (nj >= 0) & (nnj == -2);         // blocked by a stationary agent
@@ -1171,7 +1196,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             const int e = c / HW;
             if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;
             s_ga[c] = 0;
-            s_gs[c] = (CellT)p.shelf_init[c - e * HW];
+            s_gs[c] = (CellT)as_global(p.shelf_init)[c - e * HW];
         }
         __syncthreads();
         for (int e = tid; e < ne; e += T) {
@@ -1216,7 +1241,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;
             const size_t gi = (size_t)e0 * N + i;
             q_rec[gi] = rec_pack(s_ay[i] * W + s_ax[i], s_dir[i], 0, 0);
-            if (kMsg) { s_msg[i] = 0; p.amsg[gi] = 0; }  // fresh Agent objects: message = zeros (:89)
+            if (kMsg) { s_msg[i] = 0; as_global(p.amsg)[gi] = 0; }  // fresh Agent objects: message = zeros (:89)
             rew_t[gi] = s_rew[i];
             if (!kImage) {
                 s_fx[i] = coordf(0, s_ax[i]);
@@ -1227,7 +1252,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                 atomicOr(&s_obits[wd], self << sh);
                 if (sh > 26) atomicOr(&s_obits[wd + 1], self >> (32 - sh));
             } else if (p.features) {
-                float *f = p.features + gi * 6;
+                RW_GLOBAL float *f = as_global(p.features) + gi * 6;
                 const int d = s_dir[i];
                 f[0] = d == 0 ? 1.0f : 0.0f; f[1] = d == 1 ? 1.0f : 0.0f; f[2] = d == 2 ? 1.0f : 0.0f; f[3] = d == 3 ? 1.0f : 0.0f;
                 f[4] = on_highway(s_ay[i] * W + s_ax[i]) ? 1.0f : 0.0f;
@@ -1237,12 +1262,12 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         for (int e = tid; e < ne; e += T) {
             const int32_t *ev = s_envi + e * ENVI_W;
             if (!ev[ENVI_RESET]) continue;
-            for (int k = 0; k < Q; ++k) p.queue[(size_t)(e0 + e) * Q + k] = s_queue[e * Q + k];
-            p.steps[e0 + e] = 0;
-            p.inactive[e0 + e] = 0;
+            for (int k = 0; k < Q; ++k) q_queue[(size_t)(e0 + e) * Q + k] = s_queue[e * Q + k];
+            q_steps[e0 + e] = 0;
+            q_inact[e0 + e] = 0;
             term_t[e0 + e] = (uint8_t)ev[ENVI_DONE];
-            p.truncated[e0 + e] = 0;
-            p.need_reset[e0 + e] = 0;
+            as_global(p.truncated)[e0 + e] = 0;
+            q_need[e0 + e] = 0;
         }
         // fused rollout: a later step's write-back (another wavefront) may store need_reset = 1 for the same env — this
         // path's stores are made visible first (vmcnt drained before the barrier; the path is rare, the wait is free)
@@ -1270,8 +1295,8 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                     const int32_t *ev = s_envi + e * ENVI_W;
                     if (ev[ENVI_RESET]) continue;
                     const int ge = e0 + e;
-                    p.steps[ge] = ev[ENVI_STEPS];
-                    p.inactive[ge] = ev[ENVI_INACTIVE];
+                    q_steps[ge] = ev[ENVI_STEPS];
+                    q_inact[ge] = ev[ENVI_INACTIVE];
                     term_t[ge] = (uint8_t)ev[ENVI_DONE];
                     // Only what changed: RW_BUF_TRUNCATED is zero for the engine's lifetime (the reference never truncates,
                     // :942); need_reset was 0 (the env stepped) and becomes 1 only on termination; the queue changes only
@@ -1279,9 +1304,9 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                     // (fused rollout: only the launch's last step stores the flag — the reset at the top of the following
                     //  step consumes it from LDS, and a store of 1 here would race the RS store of 0 there, which comes from
                     //  another wavefront)
-                    if (ev[ENVI_DONE] && k_autoreset == AR_NEXT_STEP && (!kRollout || t + 1 == n_steps)) p.need_reset[ge] = 1;
+                    if (ev[ENVI_DONE] && k_autoreset == AR_NEXT_STEP && (!kRollout || t + 1 == n_steps)) q_need[ge] = 1;
                     if (ev[ENVI_QDIRTY])
-                        for (int k = 0; k < Q; ++k) p.queue[(size_t)ge * Q + k] = s_queue[e * Q + k];
+                        for (int k = 0; k < Q; ++k) q_queue[(size_t)ge * Q + k] = s_queue[e * Q + k];
                 }
         } else if (role == 1) {  // agent records and rewards: the chunk is contiguous in both [B][N] arrays
             if (op == OP_STEP)
@@ -1290,7 +1315,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                     const size_t gi = (size_t)e0 * N + i;
                     q_rec[gi] = rec_pack(s_ay[i] * W + s_ax[i], s_dir[i], s_deliv[i], s_carry[i]);  // one store stream, not five
                     rew_t[gi] = s_rew[i];
-                    if (kMsg) p.amsg[gi] = s_msg[i];
+                    if (kMsg) as_global(p.amsg)[gi] = s_msg[i];
                 }
         } else if (role == 2) {  // patch the shelf shadow at the two cells a LOADED mover changed
             // (The exported int32 grid, RW_BUF_GRID, is NOT patched here any more: it is rebuilt from the shadow and the agent
@@ -1336,7 +1361,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             if (q_features)  // IMAGE_DICT feature vector: one-hot direction, on_highway, carrying (:730-738)
                 for (int i = lane; i < nea; i += 64) {
                     if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;
-                    float *f = q_features + ((size_t)e0 * N + i) * 6;
+                    RW_GLOBAL float *f = q_features + ((size_t)e0 * N + i) * 6;
                     const int d = s_dir[i];
                     f[0] = d == 0 ? 1.0f : 0.0f; f[1] = d == 1 ? 1.0f : 0.0f; f[2] = d == 2 ? 1.0f : 0.0f; f[3] = d == 3 ? 1.0f : 0.0f;
                     f[4] = on_highway(s_ay[i] * W + s_ax[i]) ? 1.0f : 0.0f;
@@ -1599,10 +1624,10 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             }
         };
         if (worker && xy_bytes) {
-            if constexpr (Cfg::kNT == 1) single_pass(std::true_type{});
-            else if constexpr (Cfg::kNT == 0) single_pass(std::false_type{});
+            if constexpr (Cfg::kNT == 1) single_pass(yes_t{});
+            else if constexpr (Cfg::kNT == 0) single_pass(no_t{});
             else {  // (two copies of the pass, one taken: a scalar branch on a workgroup-uniform flag)
-                if (k_nt) single_pass(std::true_type{}); else single_pass(std::false_type{});
+                if (k_nt) single_pass(yes_t{}); else single_pass(no_t{});
             }
         }
         // normalised coordinates are fractions: bulk pass over every float4 that holds no coordinate slot (all but ~2 in
@@ -1621,7 +1646,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                 for (int j = 0; j < 8; ++j) {
                     if (k0 + j >= passes) break;
                     const int q4 = tid + (k0 + j) * TW;
-                    if (q4 < nf4 && m >= 5) store4(std::false_type{}, (uint32_t)q4 << 4, spread((wv[j] >> shift) & 0xFu));
+                    if (q4 < nf4 && m >= 5) store4(no_t{}, (uint32_t)q4 << 4, spread((wv[j] >> shift) & 0xFu));
                     m += dm;
                     m = (m >= L) ? m - L : m;
                 }

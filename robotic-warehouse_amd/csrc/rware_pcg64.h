@@ -11,7 +11,9 @@
 //   choice     Generator.choice(pop, size=k, replace=False): Floyd's sampling followed by a
 //              Fisher-Yates pass (pop <= 10000).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #define RW_HD __host__ __device__ __forceinline__
 

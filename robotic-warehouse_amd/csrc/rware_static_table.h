@@ -23,7 +23,7 @@ struct StaticEntry {
     step_kernel_t fn_nt;  // the per-step kernel with non-temporal observation stores (nullptr: `fn` switches at run time)
 };
 
-enum : int { kStaticGroups = 10 };
+enum : int { kStaticGroups = 18 };
 const StaticEntry *static_group(int group, int *n);   // rware_capi.hip's view: dispatches to the per-group tables below
 const StaticEntry *static_group_0(int *n);
 const StaticEntry *static_group_1(int *n);
@@ -35,6 +35,14 @@ const StaticEntry *static_group_6(int *n);
 const StaticEntry *static_group_7(int *n);
 const StaticEntry *static_group_8(int *n);
 const StaticEntry *static_group_9(int *n);
+const StaticEntry *static_group_10(int *n);
+const StaticEntry *static_group_11(int *n);
+const StaticEntry *static_group_12(int *n);
+const StaticEntry *static_group_13(int *n);
+const StaticEntry *static_group_14(int *n);
+const StaticEntry *static_group_15(int *n);
+const StaticEntry *static_group_16(int *n);
+const StaticEntry *static_group_17(int *n);
 
 }  // namespace rw_tab
 
@@ -92,6 +100,19 @@ namespace {
 //  register budget of 8 wavefronts (amdgpu_waves_per_eu) was measured: small-8ag B = 16384 12.73 -> 11.14 us, but +0.1 .. +0.4 us
 //  wherever the batch fits anyway — the spilled scalars cost more than they buy.)
 #define RW_QRT_58(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 8, 256, ((N) >= 7 ? 14336 : 8192)), RW_STATIC(H, W, N, -1, S, 1, 16, 256, 0)
+// 9 .. 19 agents (rware/__init__.py:16 registers every count up to 19): 8 envs per workgroup (72 .. 152 agents: two or three
+// agent wavefronts), 4 envs for batches that are no multiple of 8 and as an explicit geometry
+#define RW_QRT_WIDE(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 8, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 4, 256, 0)
+#define RW_QRT_WIDE_A(H, W, S) RW_QRT_WIDE(H, W, S, 9), RW_QRT_WIDE(H, W, S, 10), RW_QRT_WIDE(H, W, S, 11), RW_QRT_WIDE(H, W, S, 12), \
+                               RW_QRT_WIDE(H, W, S, 13), RW_QRT_WIDE(H, W, S, 14)
+#define RW_QRT_WIDE_B(H, W, S) RW_QRT_WIDE(H, W, S, 15), RW_QRT_WIDE(H, W, S, 16), RW_QRT_WIDE(H, W, S, 17), RW_QRT_WIDE(H, W, S, 18), \
+                               RW_QRT_WIDE(H, W, S, 19)
+// (the tiny warehouse: 110 cells — a 4-env shelf chunk is no whole number of 16-byte DMA pieces, so 8 envs only)
+#define RW_QRT_WIDE8(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 8, 256, 0)
+#define RW_QRT_WIDE8_A(H, W, S) RW_QRT_WIDE8(H, W, S, 9), RW_QRT_WIDE8(H, W, S, 10), RW_QRT_WIDE8(H, W, S, 11), RW_QRT_WIDE8(H, W, S, 12), \
+                                RW_QRT_WIDE8(H, W, S, 13), RW_QRT_WIDE8(H, W, S, 14)
+#define RW_QRT_WIDE8_B(H, W, S) RW_QRT_WIDE8(H, W, S, 15), RW_QRT_WIDE8(H, W, S, 16), RW_QRT_WIDE8(H, W, S, 17), RW_QRT_WIDE8(H, W, S, 18), \
+                                RW_QRT_WIDE8(H, W, S, 19)
 #define RW_QRT_SIZE(H, W, S) RW_QRT_12(H, W, S, 1), RW_QRT_12(H, W, S, 2), RW_QRT_34(H, W, S, 3), RW_QRT_34(H, W, S, 4), \
                              RW_QRT_58(H, W, S, 5), RW_QRT_58(H, W, S, 6), RW_QRT_58(H, W, S, 7), RW_QRT_58(H, W, S, 8)
 
@@ -110,6 +131,7 @@ const StaticEntry kEntries[] = {
     RW_STATIC(20, 16, 6, 3, 144, 1, 16, 256, 0),   // rware-medium-6ag-hard
     // (large-16ag r=2, round 3, same box: E = 8 36.2 us at B = 16384 vs 38.4 with E = 4 and 37.1 with E = 16; B = 4096: 14.6 vs 13.8 with E = 4)
     RW_STATIC(29, 16, 16, 16, 224, 2, 8, 256, 0),  // rware-large-16ag, sensor_range = 2
+    RW_STATIC(29, 16, 16, 16, 224, 2, 4, 256, 0),  // (batches that are no multiple of 8; explicit geometry)
 #elif RW_STATIC_GROUP == 1
     // ---- the "next" observation kinds callers hit first: IMAGE / IMAGE_DICT (any layer list, directional
     // or not) and FLATTENED with 1 or 2 communication bits, on the two smallest BASELINE tasks
@@ -143,6 +165,9 @@ const StaticEntry kEntries[] = {
     RW_STATIC(20, 10, 0, 0, 80, 1, 16, 256, 0),    // rware-small-*
     RW_STATIC(20, 16, 0, 0, 144, 1, 16, 256, 0),   // rware-medium-*
     RW_STATIC(29, 16, 0, 0, 224, 1, 16, 256, 0),   // rware-large-*
+    // ... and with sensor_range = 2 (the 5 x 5 window of BASELINE config 5, on every size)
+    RW_STATIC(11, 10, 0, 0, 32, 2, 16, 256, 0), RW_STATIC(20, 10, 0, 0, 80, 2, 16, 256, 0),
+    RW_STATIC(20, 16, 0, 0, 144, 2, 16, 256, 0), RW_STATIC(29, 16, 0, 0, 224, 2, 16, 256, 0),
 #elif RW_STATIC_GROUP == 6
     // ---- agent-count-static builds (Q == -1: request-queue length read at run time, any Q <= 2 N): the easy / normal / hard
     // variants of a task and custom queue sizes share one build.  Geometry by the 64-agents-per-workgroup rule.
@@ -153,6 +178,23 @@ const StaticEntry kEntries[] = {
     RW_QRT_SIZE(20, 16, 144),    // medium
 #elif RW_STATIC_GROUP == 9
     RW_QRT_SIZE(29, 16, 224),    // large
+#elif RW_STATIC_GROUP == 10
+    // ---- agent-count-static builds for 9 .. 19 agents (agent phases in registers, chain links in 64 / 128 bits)
+    RW_QRT_WIDE_A(20, 10, 80),   // small
+#elif RW_STATIC_GROUP == 11
+    RW_QRT_WIDE_B(20, 10, 80),
+#elif RW_STATIC_GROUP == 12
+    RW_QRT_WIDE8_A(11, 10, 32),  // tiny
+#elif RW_STATIC_GROUP == 13
+    RW_QRT_WIDE8_B(11, 10, 32),
+#elif RW_STATIC_GROUP == 14
+    RW_QRT_WIDE_A(20, 16, 144),  // medium
+#elif RW_STATIC_GROUP == 15
+    RW_QRT_WIDE_B(20, 16, 144),
+#elif RW_STATIC_GROUP == 16
+    RW_QRT_WIDE_A(29, 16, 224),  // large
+#elif RW_STATIC_GROUP == 17
+    RW_QRT_WIDE_B(29, 16, 224),
 #else
 #error "RW_STATIC_GROUP out of range"
 #endif
@@ -166,6 +208,12 @@ const StaticEntry kEntries[] = {
 #undef RW_TINY_E8
 #undef RW_QRT_12
 #undef RW_QRT_SIZE
+#undef RW_QRT_WIDE
+#undef RW_QRT_WIDE_A
+#undef RW_QRT_WIDE_B
+#undef RW_QRT_WIDE8
+#undef RW_QRT_WIDE8_A
+#undef RW_QRT_WIDE8_B
 #undef RW_QRT_34
 #undef RW_QRT_58
 #undef RW_TINY_E32

@@ -114,14 +114,16 @@ class _Space:
 class _CapturedLoop:
     """What WarehouseVecEnv.capture_loop returns: `steps` (policy, step) rounds in one HIP graph."""
 
-    def __init__(self, graph, stream, keep, steps):
-        self.graph, self.stream, self._keep, self.steps = graph, stream, keep, steps
+    def __init__(self, graph, stream, keep, steps, engine=None):
+        self.graph, self.stream, self._keep, self.steps, self._engine = graph, stream, keep, steps, engine
 
     def replay(self):
         import torch
 
         with torch.cuda.stream(self.stream):
             self.graph.replay()
+        if self._engine is not None:  # the replayed steps ran without host code: get_state() / set_state() must not trust
+            self._engine.mark_views_stale()  # the engine's "views are current" flags (grid, agent_* arrays)
 
 
 class WarehouseVecEnv(_VectorEnvBase):
@@ -269,7 +271,11 @@ class WarehouseVecEnv(_VectorEnvBase):
         return self._observations(), {}
 
     def step(self, actions):
-        """Warehouse.step (:804-946) for every env; actions (B, N) ints in 0..4 or Action members."""
+        """Warehouse.step (:804-946) for every env; actions (B, N) ints in 0..4 or Action members.
+
+        With output="torch" all four results are zero-copy views of engine memory — the SAME tensor objects every call,
+        overwritten in place by the next step (obs, rewards, terminated; truncated stays False).  A loop that keeps them
+        across steps (`dones.append(terminated)`) must `.clone()` them; output="numpy" returns fresh host arrays."""
         self.step_async(actions)
         return self.step_wait()
 
@@ -430,7 +436,7 @@ class WarehouseVecEnv(_VectorEnvBase):
                     a = self._device_actions(policy(obs, v["rewards"], v["terminated_bool"]), self.num_envs, 0)
                     keep.append(a)  # (allocated from the graph's private pool: alive as long as the graph is)
                     self.engines[0].step_device(a.data_ptr())
-        return _CapturedLoop(g, s, keep, int(steps))
+        return _CapturedLoop(g, s, keep, int(steps), self.engines[0])
 
     def snapshot(self):
         """Checkpoint the batched state on the device (grid, agents, queue, counters, RNG streams).
@@ -446,6 +452,12 @@ class WarehouseVecEnv(_VectorEnvBase):
     def free_snapshot(self, token):
         for eng, h in zip(self.engines, token):
             eng.free_snapshot(h)
+
+    def trim(self):
+        """Releases the device tapes rollout() with host arrays keeps between calls (one rollout(T=100) of 16384 small-4ag
+        envs with observations holds ~1.9 GB per shard until then; they are re-allocated on the next such call)."""
+        for eng in self.engines:
+            eng.release_arena()
 
     def sync(self):
         """Wait for enqueued work; raises ValueError if a device-side action was out of range."""

@@ -3,6 +3,7 @@
 // lane * size; lds_barrier == workgroup barrier; wave_sync == barrier over the 64 threads of a wave.
 #pragma once
 #include <hip/hip_runtime.h>
+#define RW_GLOBAL
 namespace rw {
 inline void lds_dma_b128(const void *g_lane, void *lds_wave_base) {
     memcpy((char *)lds_wave_base + (threadIdx.x & 63u) * 16, g_lane, 16);
@@ -10,6 +11,8 @@ inline void lds_dma_b128(const void *g_lane, void *lds_wave_base) {
 inline void lds_dma_b32(const void *g_lane, void *lds_wave_base) {
     memcpy((char *)lds_wave_base + (threadIdx.x & 63u) * 4, g_lane, 4);
 }
+template <typename T> inline T *as_global(T *p) { return p; }
+template <typename T> inline const char *as_bytes(const T *p) { return (const char *)p; }
 inline uint32_t hw_id() { return 0; }
 inline uint32_t xcc_id() { return 0; }
 extern int emu_wave_any_flag[16];
@@ -29,6 +32,8 @@ inline void keep_vgpr(int, int) {}
 inline uint32_t opaque(uint32_t x) { return x; }
 inline void store_f4_nt(float4 *dst, float4 v) { *dst = v; }  // (the hint has no host meaning)
 inline int uniform(int x) { return x; }
+inline void lds_zero_b128_blind(void *lds_ptr) { memset(lds_ptr, 0, 16); }
+inline void lds_wait() {}
 inline void lds_barrier() { pthread_barrier_wait(emu_barrier); }
 inline void wave_sync() { pthread_barrier_wait(emu_wave_barrier); }
 inline void wave_lds_order() { pthread_barrier_wait(emu_wave_barrier); }  // threads are not in lockstep here: a real barrier

@@ -93,7 +93,7 @@ def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
     ("small-4ag", (0, 0), 2),          # ... and the 8-env build picked for small batches
     ("tiny-2ag", (0, 0), 4),           # pair exchange (N = 2)
     ("medium-6ag-hard", (0, 0), 8),    # ds_bpermute exchange (N = 6), 8-env build
-    ("large-16ag-sr2", (0, 0), 4),     # exact-shape build with the LDS exchange (N = 16)
+    ("large-16ag-sr2", (0, 0), 4),     # exact-shape build, N = 16 in registers (128-bit chain links; round 4)
     ("img-small-4ag-directional", (0, 0), 16),   # exact-shape IMAGE build
     ("msg2-small-4ag", (0, 0), 16),              # exact-shape build with 2 communication bits
     ("small-8ag-global-inact", (0, 0), 16),      # N = 8 in registers: 64-bit chain links (round 3)
@@ -101,6 +101,8 @@ def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
     ("small-7ag-hard", (0, 0), 4),               # agent-count-static build, N = 7 (ds_bpermute, 64-bit links), 8-env workgroups
     ("large-4ag", (0, 0), 8),                    # agent-count-static build on the large warehouse
     ("medium-2ag-easy", (32, 256), 8),           # 2 agents, the 32-env build (pair exchange), Q = 2 N
+    ("small-19ag", (0, 0), 4),                   # agent-count-static build, N = 19: 128-bit chain links, three agent wavefronts
+    ("small-19ag", (4, 256), 2),                 # ... and its 4-env geometry
 ])
 def test_emulated_exact_shape_builds_match_reference_golden(name, geom, tile):
     """The golden traces of the unmodified reference, replayed on the EXACT-SHAPE kernel builds (the ones the BASELINE
@@ -719,6 +721,11 @@ def test_seed_and_global_image_methods():
     ("rware-small-8ag-v1", {"request_queue_size": 11}), ("rware-small-2ag-v1", {"request_queue_size": 3}),
     ("rware-tiny-3ag-v1", {}), ("rware-medium-5ag-easy-v1", {}), ("rware-large-7ag-v1", {}), ("rware-large-2ag-hard-v1", {}),
     ("rware-large-4ag-v1", {}),
+    # 9 .. 19 agents (round 4): agent phases in registers for every registered agent count — ds_bpermute exchange, chain links
+    # in 64 bits (N <= 12) or 128 bits (N >= 13), two or three agent wavefronts per 8-env workgroup
+    ("rware-small-9ag-hard-v1", {}), ("rware-small-10ag-v1", {}), ("rware-small-12ag-easy-v1", {}), ("rware-tiny-13ag-v1", {}),
+    ("rware-medium-14ag-v1", {}), ("rware-medium-16ag-hard-v1", {}), ("rware-large-17ag-v1", {}), ("rware-small-19ag-v1", {}),
+    ("rware-large-16ag-v1", {"request_queue_size": 7}), ("rware-tiny-15ag-easy-v1", {}),
 ])
 def test_agent_count_static_builds_read_the_queue_length_at_run_time(env_id, extra):
     """Tasks without an exact (N, Q) entry run the agent-count-static build of their size and agent count (Q == -1 in
@@ -821,4 +828,33 @@ def test_generic_kernel_matches_oracle_on_random_shapes(case):
     st, so = env.get_state(), orc.get_state()
     for k in so:
         assert np.array_equal(st[k], so[k]), (k, kw)
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,p_forward", [
+    ("rware-tiny-13ag-v1", 0.75), ("rware-tiny-16ag-v1", 0.75), ("rware-tiny-17ag-hard-v1", 0.7), ("rware-tiny-19ag-v1", 0.8),
+    ("rware-tiny-10ag-v1", 0.8), ("rware-tiny-12ag-easy-v1", 0.75),
+])
+def test_crowded_warehouses_resolve_long_chains_in_registers(env_id, p_forward):
+    """9 .. 19 agents on the 110 cells of the tiny warehouse under a forward-heavy policy: long follower chains, contested
+    cells with unequal depths, blocked tails and cycles on nearly every step — the register-exchange agent phases (wide
+    priority words, 128-bit chain links) against the oracle's literal networkx restatement."""
+    kw = rware_amd.env_kwargs(env_id)
+    kw["max_steps"] = 40
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    B, N = 16, kw["n_agents"]
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, **kw)
+    assert env.engines[0].info.build_kind == 2 and env.engines[0].info.envs_per_workgroup == 8
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=31)[0], orc.reset(seed=31))
+    rng = np.random.default_rng(33)
+    rest = (1.0 - p_forward) / 4
+    for t in range(90):
+        a = rng.choice(5, size=(B, N), p=[rest, p_forward, rest, rest, rest]).astype(np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
     env.close()
