@@ -87,7 +87,15 @@ enum rw_stream_flags {
      * non-temporal lines in HBM rather than in the cache: RW_OBS_STORES_CACHED keeps them cached, RW_OBS_STORES_STREAM forces
      * the hint.  (Also RWARE_OBS_STORES=cached|stream in the environment, for A/B runs.) */
     RW_OBS_STORES_CACHED = 2,
-    RW_OBS_STORES_STREAM = 4
+    RW_OBS_STORES_STREAM = 4,
+    /* Run-time specialisation.  A task without an ahead-of-time exact-shape kernel build — a `layout=` string, column_height
+     * != 8, sensor_range 2..5, more than 19 agents (rware/warehouse.py:146-170; ids of rware/__init__.py:83-175) — gets one
+     * compiled by rw_create through hipRTC (a few seconds; cached on disk under $RWARE_JIT_CACHE or ~/.cache/rware_amd/jit)
+     * when the batch has at least 4096 envs; without hipRTC, or when the compile fails, the ahead-of-time generic kernel
+     * runs (rw_info.jit, rw_jit_log say what happened).  RW_JIT_OFF: never.  RW_JIT_FORCE: always — small batches and shapes
+     * that have an ahead-of-time build included (tests, A/B).  (Also RWARE_JIT=off|force in the environment.) */
+    RW_JIT_OFF = 8,
+    RW_JIT_FORCE = 16
 };
 
 /* Device buffers (all env-major, C-contiguous).  Replaces the attributes callers read off the
@@ -270,7 +278,8 @@ typedef struct rw_info {
     char arch_name[64];
     int32_t obs_stores_stream; /* 1: the per-step kernel stores the observation stream with the non-temporal hint
                                   (rw_stream_flags); the fused rollout kernel (rw_step_many_device) always stores cached */
-    int32_t reserved0;
+    int32_t jit;               /* 0: an ahead-of-time build runs; 1: an exact-shape build compiled by this rw_create (hipRTC); 2: the
+                                  same, read from the disk cache; -1: run-time specialisation was tried and is not in use (rw_jit_log) */
     int64_t engine_bytes_per_env_step; /* bytes this engine's state layout has to move per env-step: shelf shadow (1 or 2 B per
                                   cell) + packed agent records r/w + actions + queue + counters / flags + observation + rewards +
                                   terminated (+ messages r/w, IMAGE_DICT features).  The PMC traffic of a step is checked against
@@ -278,6 +287,13 @@ typedef struct rw_info {
     int32_t reserved[4];
 } rw_info;
 int rw_get_info(const rw_engine *eng, rw_info *out);
+/* what the run-time specialisation did for this engine: cache file / compile time, or why it is not in use ("" if not tried) */
+const char *rw_jit_log(const rw_engine *eng);
+/* the compile half of the run-time specialisation, without a device (build checks, cache warm-up on a login node): `shape` =
+ * {sensor_range, H, W, N, Q, S, envs per workgroup, 256, msg_bits, wide shelf ids, observation kind (0 FLATTENED, 1 IMAGE,
+ * 2 FLATTENED + messages), baked image layers, packed layer list, image_directional (-1 for FLATTENED), non-temporal stores};
+ * returns the size of the gfx code object (compiled or found in the disk cache), -1 on failure (`log` says why). */
+int64_t rw_jit_probe(const int32_t shape[15], const char *arch, char *log, size_t log_len);
 
 /* numpy SeedSequence(seed) -> PCG64 initial state, as 6 uint64 in RW_BUF_RNG field order.
  * Pure host function (exposed so tests can check the seeding against numpy). */

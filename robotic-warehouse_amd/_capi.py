@@ -28,6 +28,7 @@ BUF_DTYPE = {
 
 RW_STREAM_USE_GIVEN = 1  # rw_stream_flags: `stream` is taken literally, NULL == the device's default stream
 RW_OBS_STORES_CACHED, RW_OBS_STORES_STREAM = 2, 4  # rw_stream_flags: keep the observation lines cached / force the non-temporal hint
+RW_JIT_OFF, RW_JIT_FORCE = 8, 16  # rw_stream_flags: run-time specialisation (hipRTC) never / always; default: shapes without an exact build, B >= 4096
 
 AUTORESET = {"disabled": 0, None: 0, "next_step": 1, "same_step": 2}
 
@@ -48,13 +49,13 @@ class RwInfo(C.Structure):
         "envs_per_workgroup", "threads_per_workgroup", "n_workgroups", "lds_bytes", "device_id",
         "compute_units", "specialised", "state_layout", "build_kind")] + [
         ("algorithmic_bytes_per_env_step", C.c_int64),
-        ("device_name", C.c_char * 128), ("arch_name", C.c_char * 64), ("obs_stores_stream", C.c_int32), ("reserved0", C.c_int32),
+        ("device_name", C.c_char * 128), ("arch_name", C.c_char * 64), ("obs_stores_stream", C.c_int32), ("jit", C.c_int32),
         ("engine_bytes_per_env_step", C.c_int64), ("reserved", C.c_int32 * 4)]
 
 
 EXPORTS = (
     "rw_create", "rw_destroy", "rw_last_error", "rw_reset", "rw_step", "rw_step_device",
-    "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_mark_views_stale", "rw_sync", "rw_get_buffer", "rw_read", "rw_read_outputs", "rw_write",
+    "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_mark_views_stale", "rw_jit_log", "rw_jit_probe", "rw_sync", "rw_get_buffer", "rw_read", "rw_read_outputs", "rw_write",
     "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
     "rw_abi_version", "rw_debug_timeline", "rw_device_malloc", "rw_device_free", "rw_copy_to_device",
     "rw_copy_to_host", "rw_snapshot_create", "rw_snapshot_save", "rw_snapshot_restore", "rw_snapshot_destroy",
@@ -110,6 +111,10 @@ def load(path: str | None = None):
     lib.rw_refresh_obs.argtypes = [vp]
     lib.rw_refresh_grid.argtypes = [vp]
     lib.rw_mark_views_stale.argtypes = [vp]
+    lib.rw_jit_log.argtypes = [vp]
+    lib.rw_jit_log.restype = C.c_char_p
+    lib.rw_jit_probe.argtypes = [C.POINTER(C.c_int32), C.c_char_p, C.c_char_p, C.c_size_t]
+    lib.rw_jit_probe.restype = C.c_int64
     lib.rw_sync.argtypes = [vp]
     lib.rw_get_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.rw_read.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -131,7 +136,7 @@ def load(path: str | None = None):
     lib.rw_snapshot_restore.argtypes = [vp, vp]
     lib.rw_snapshot_destroy.argtypes = [vp, vp]
     for name in EXPORTS:
-        if name != "rw_last_error":
+        if name not in ("rw_last_error", "rw_jit_log", "rw_jit_probe"):
             getattr(lib, name).restype = C.c_int
     if lib.rw_abi_version() != RW_ABI_VERSION:
         raise RuntimeError(f"{path}: ABI version {lib.rw_abi_version()} != {RW_ABI_VERSION}")
@@ -164,7 +169,7 @@ class Engine:
                  max_inactivity_steps, max_steps, reward_type, normalised_coordinates=False,
                  autoreset_mode="next_step", device_id=0, envs_per_workgroup=0,
                  threads_per_workgroup=0, stream=None, library=None, observation_type=1,
-                 image_layers=(), image_directional=True, msg_bits=0, use_given_stream=False, obs_stores=None):
+                 image_layers=(), image_directional=True, msg_bits=0, use_given_stream=False, obs_stores=None, jit=None):
         self.lib = load(library)
         self._h = C.c_void_p()
         self._arena, self.arena_allocations = {}, 0  # rollout_host's device tapes (grow-only; freed in close())
@@ -177,7 +182,8 @@ class Engine:
             int(device_id), int(envs_per_workgroup), int(threads_per_workgroup),
             int(observation_type), int(bool(image_directional)), len(image_layers),
             (C.c_int32 * 8)(*[int(l) for l in image_layers]), int(msg_bits),
-            (RW_STREAM_USE_GIVEN if use_given_stream else 0) | {None: 0, "auto": 0, "cached": RW_OBS_STORES_CACHED, "stream": RW_OBS_STORES_STREAM}[obs_stores],
+            (RW_STREAM_USE_GIVEN if use_given_stream else 0) | {None: 0, "auto": 0, "cached": RW_OBS_STORES_CACHED, "stream": RW_OBS_STORES_STREAM}[obs_stores]
+            | {None: 0, "auto": 0, False: RW_JIT_OFF, "off": RW_JIT_OFF, True: RW_JIT_FORCE, "force": RW_JIT_FORCE}[jit],
             hw.ctypes.data, goals.ctypes.data, C.c_void_p(stream or 0))
         rc = self.lib.rw_create(C.byref(cfg), C.byref(self._h))
         if rc != RW_OK:
@@ -306,6 +312,9 @@ class Engine:
         """Brings the exported int32 grid (a derived view) up to date with the steps enqueued so far."""
         self._check(self.lib.rw_refresh_grid(self._h))
 
+    def jit_log(self) -> str:
+        return (self.lib.rw_jit_log(self._h) or b"").decode()
+
     def mark_views_stale(self):
         """Steps ran that the host side did not see (a replayed HIP graph): the derived views are rebuilt when next asked for."""
         self._check(self.lib.rw_mark_views_stale(self._h))
@@ -370,3 +379,15 @@ def seed_state(seed: int, library=None) -> np.ndarray:
     rc = load(library).rw_seed_state(C.c_uint64(int(seed)), out.ctypes.data)
     assert rc == RW_OK
     return out
+
+
+def jit_probe(*, sensor_range, H, W, N, Q, S, E, msg_bits=0, obs=0, layers=(), directional=True, nt=1, arch="gfx950", library=None):
+    """Compile (or find cached) the run-time specialised build of a shape without a device; returns (code bytes or -1, log)."""
+    packed = 0
+    for k, l in enumerate(layers):
+        packed |= int(l) << (4 * k)
+    shape = (C.c_int32 * 15)(sensor_range, H, W, N, Q, S, E, 256, msg_bits, 1 if S > 255 else 0, obs, len(layers), packed,
+                             (1 if directional else 0) if obs == 1 else -1, nt)
+    log = C.create_string_buffer(4096)
+    n = load(library).rw_jit_probe(shape, arch.encode(), log, 4096)
+    return int(n), log.value.decode(errors="replace")

@@ -20,6 +20,9 @@
 #include "rware_kernel_table.h"
 #include "rware_kernels.h"
 #include "rware_static_table.h"
+#ifndef RW_NO_JIT
+#include "rware_jit.h"
+#endif
 
 namespace {
 
@@ -54,6 +57,13 @@ struct rw_engine {
     bool specialised = false;
     bool grid_stale = false;   // steps / resets have run since RW_BUF_GRID was last rebuilt (refresh_grid)
     bool agents_stale = false; // ... since RW_BUF_AGENT_X .. _DELIVERED were last unpacked from the records (refresh_agents)
+    // run-time specialised build (rware_jit.cpp): the code object's module and its two kernels; launched instead of `kernel` /
+    // `kernel_rollout` when present
+    hipModule_t jit_module = nullptr;
+    hipFunction_t jit_step = nullptr, jit_rollout = nullptr;
+    int jit_state = 0;         // rw_info::jit
+    int jit_nt = 0;            // the run-time build's observation-store mode
+    std::string jit_log;
     bool captured = false;     // a launch of this engine was recorded into a HIP graph: replays run without any host code, so the
                                // two flags above can no longer be trusted — the derived views are rebuilt whenever asked for
     size_t rec_off = 0;
@@ -118,6 +128,18 @@ int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false, hipE
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(eng->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) eng->captured = true;
         else (void)hipGetLastError();
+    }
+    if (eng->jit_step) {  // a run-time specialised build: the same launch through the module API
+        const rw::Params *cp = eng->d_prm;
+        void *args[13] = {&cp, &la.actions, &la.op, &la.n_steps, &la.obs, &la.rewards, &la.terminated, &la.reset_mask, &la.timeline,
+                          &la.act_stride, &la.obs_stride, &la.rew_stride, &la.term_stride};
+        hipFunction_t f = rollout ? eng->jit_rollout : eng->jit_step;
+        if (start || stop)
+            RW_HIP(eng, hipExtModuleLaunchKernel(f, (uint32_t)eng->n_wg * (uint32_t)eng->T, 1, 1, (uint32_t)eng->T, 1, 1, eng->lds_bytes, eng->stream,
+                                                 args, nullptr, start, stop, 0));
+        else
+            RW_HIP(eng, hipModuleLaunchKernel(f, (uint32_t)eng->n_wg, 1, 1, (uint32_t)eng->T, 1, 1, (uint32_t)eng->lds_bytes, eng->stream, args, nullptr));
+        return RW_OK;
     }
     if (start || stop)  // the events ride on this dispatch (its own start / end timestamps): no marker packets in the stream
         hipExtLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
@@ -418,6 +440,96 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             eng->build_kind = best->N == 0 ? 3 : best->Q < 0 ? 2 : 1;
         }
     }
+    // Observation stores: non-temporal (stream) or cached.  Measured rule (round 3 / 4, same-box A/Bs, profiles/EXPERIMENTS.md):
+    // the hint wins wherever a workgroup's observation chunk is small (every registered task up to 12 agents — small-4ag
+    // B = 16384 7.13 -> 6.17 us, medium-6ag-hard 7.25 -> 6.26, large-8ag 12.25 -> 11.1, small-12ag 16.7 -> 15.8) and wherever a
+    // step's observations outgrow the Infinity Cache (large-16ag r=2 B = 32768 86.3 -> 79.0); it loses for large chunks below
+    // that size (large-16ag r=2 B = 16384 37.3 -> 43.7; small-19ag 28.9 vs 27.6 cached; large-16ag r=1: even).
+    // (by chunk size in floats: 4544 small-4ag, 6816 small-12ag at 8 envs: the hint wins; 9088 large-16ag: even; 10792 small-19ag,
+    //  23424 large-16ag r=2: it loses below the cache size; 9656 small-17ag: 26.1 vs 25.5 cached)
+    auto nt_rule = [&](int e_) {
+        const long long chunk = (long long)e_ * N * eng->L;                    // floats of one workgroup's observations
+        const double obs_mb = (double)B * N * eng->L * 4 / 1e6;
+        bool nt = chunk <= 9500 || obs_mb > 240.0;
+        const char *pref = getenv("RWARE_OBS_STORES");  // (A/B hook: moves the default only — an explicit flag of the caller wins)
+        if (pref && !strcmp(pref, "cached")) nt = false;
+        if (pref && !strcmp(pref, "stream")) nt = true;
+        if (cfg->stream_flags & RW_OBS_STORES_CACHED) nt = false;
+        if (cfg->stream_flags & RW_OBS_STORES_STREAM) nt = true;
+        return nt;
+    };
+#ifndef RW_NO_JIT
+    {
+        // Run-time specialisation (rware_jit.h): a shape without an exact or agent-count-static entry gets an exact-shape build
+        // compiled now (or read from the disk cache) — unless the batch is small (the seconds a compile takes only pay off
+        // on a long run), the caller said no, or hipRTC is not there.  RW_JIT_FORCE: also for small batches and for shapes
+        // that have an ahead-of-time build (tests, A/B).
+        int mode = 0;  // 0 auto, -1 off, 1 force
+        const char *je = getenv("RWARE_JIT");
+        if (je && (!strcmp(je, "0") || !strcmp(je, "off"))) mode = -1;
+        if (je && !strcmp(je, "force")) mode = 1;
+        if (cfg->stream_flags & RW_JIT_OFF) mode = -1;
+        if (cfg->stream_flags & RW_JIT_FORCE) mode = 1;
+        const bool aot_exact = eng->specialised && eng->build_kind != 3;
+        const bool combo_ok = !(eng->image && eng->msg_bits > 0);
+        if (combo_ok && (mode == 1 || (mode == 0 && !aot_exact && B >= 4096))) {
+            const bool geom_given = cfg->envs_per_workgroup != 0 || cfg->threads_per_workgroup != 0;
+            int prefs[5] = {8, 4, 16, 0, 0};
+            if (geom_given) { prefs[0] = cfg->envs_per_workgroup ? cfg->envs_per_workgroup : 16; prefs[1] = 0; }
+            else if (N <= 2) { prefs[0] = B >= 16384 ? 32 : 16; prefs[1] = 16; prefs[2] = 8; prefs[3] = 4; }
+            else if (N <= 4) { prefs[0] = 16; prefs[1] = 8; prefs[2] = 4; }
+            else if (N <= 8) { prefs[0] = B <= 16384 ? 8 : 16; prefs[1] = B <= 16384 ? 16 : 8; prefs[2] = 4; }
+            int je_ = 0;
+            for (int k = 0; k < 5 && !je_; ++k) {
+                const int c = prefs[k];
+                if (c < 4 || c % 4 || B % c) continue;
+                if (((long long)c * HW * cell_bytes) % 16) continue;                         // the stage-in DMA moves whole 16-byte pieces
+                if (N <= 19 && c > 4 * (64 / N)) continue;                                   // every env needs its own agent lanes
+                if ((long long)c * N * N >= (1 << 18)) continue;
+                const size_t lds = sizeof(int32_t) * (size_t)rw::make_lds_layout(c, N, Q, HW, SW, eng->OW, cell_bytes, AM).total;
+                if (lds > 64 * 1024) continue;                                               // (a module kernel keeps the default LDS limit)
+                je_ = c;
+            }
+            if (je_ && (!geom_given || cfg->threads_per_workgroup == 0 || cfg->threads_per_workgroup == 256)) {
+                rw_jit::Shape sh{};
+                sh.R = R; sh.H = H; sh.W = W; sh.N = N; sh.Q = Q; sh.S = S; sh.E = je_; sh.T = 256; sh.M = eng->msg_bits;
+                sh.wide = eng->wide ? 1 : 0;
+                sh.obs = eng->image ? rw::OBS_IMAGE : eng->msg_bits > 0 ? rw::OBS_FLATTENED_MSG : rw::OBS_FLATTENED;
+                sh.NL = eng->image ? n_layers : 0;
+                sh.directional = eng->image ? (cfg->image_directional ? 1 : 0) : -1;
+                for (int l = 0; l < n_layers && l < 8 && eng->image; ++l) sh.layers |= (uint32_t)layers[l] << (4 * l);
+                sh.nt = nt_rule(je_) ? 1 : 0;
+                rw_jit::Result res;
+                const bool built = rw_jit::compile(sh, eng->prop.gcnArchName, &res);
+                eng->jit_log = res.log;
+                eng->jit_state = -1;
+                if (built) {
+                    hipError_t me = hipModuleLoadData(&eng->jit_module, res.code.data());
+                    if (me == hipSuccess) me = hipModuleGetFunction(&eng->jit_step, eng->jit_module, res.step_name.c_str());
+                    if (me == hipSuccess) me = hipModuleGetFunction(&eng->jit_rollout, eng->jit_module, res.rollout_name.c_str());
+                    if (me == hipSuccess) {
+                        E = je_;
+                        T = 256;
+                        eng->specialised = true;
+                        eng->q_runtime = false;
+                        eng->build_kind = 1;
+                        eng->jit_state = res.from_cache ? 2 : 1;
+                        eng->kernel_nt = nullptr;
+                        eng->jit_nt = sh.nt;
+                    } else {
+                        eng->jit_log += std::string(" | loading the code object failed: ") + hipGetErrorString(me);
+                        eng->jit_step = eng->jit_rollout = nullptr;
+                        if (eng->jit_module) { (void)hipModuleUnload(eng->jit_module); eng->jit_module = nullptr; }
+                        (void)hipGetLastError();
+                    }
+                }
+            } else {
+                eng->jit_log = "no workgroup geometry of an exact-shape build fits this batch / shape";
+                eng->jit_state = -1;
+            }
+        }
+    }
+#endif
     eng->E = E;
     eng->T = T;
     eng->n_wg = (B + E - 1) / E;
@@ -513,21 +625,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.normalised = cfg->normalised_coordinates ? 1 : 0;
     p.envs_per_wg = E;
     {
-        // Observation stores: non-temporal (stream) or cached.  Measured rule (round 3, same-box A/Bs, profiles/EXPERIMENTS.md):
-        // the hint wins wherever a workgroup's observation chunk is small (every registered task except the 16-agent ones —
-        // small-4ag B = 16384 7.13 -> 6.17 us, medium-6ag-hard 7.25 -> 6.26, large-8ag 12.25 -> 11.1) and wherever a step's
-        // observations outgrow the Infinity Cache (large-16ag r=2 B = 32768 88.7 -> 81.6); it loses for large observation
-        // chunks below that size (large-16ag r=2 B = 16384 36.2 -> 43.1).
-        // (measured by chunk size: 4544 floats small-4ag, 9088 large-8ag at 16 envs: the hint wins; 18176 large-16ag r=1,
-        //  23424 large-16ag r=2 at 8 envs: it loses below the cache size; 13632 small-12ag: 18.65 vs 19.02 us, it still wins)
-        const long long chunk = (long long)E * N * eng->L;                    // floats of one workgroup's observations
-        const double obs_mb = (double)B * N * eng->L * 4 / 1e6;
-        bool nt = chunk <= 14336 || obs_mb > 240.0;
-        const char *pref = getenv("RWARE_OBS_STORES");  // (A/B hook: moves the default only — an explicit flag of the caller wins)
-        if (pref && !strcmp(pref, "cached")) nt = false;
-        if (pref && !strcmp(pref, "stream")) nt = true;
-        if (cfg->stream_flags & RW_OBS_STORES_CACHED) nt = false;
-        if (cfg->stream_flags & RW_OBS_STORES_STREAM) nt = true;
+        const bool nt = eng->jit_step ? eng->jit_nt != 0 : nt_rule(E);
         p.nt_obs = nt ? 1 : 0;
         if (nt && eng->kernel_nt) eng->kernel = eng->kernel_nt;  // (exact builds: the choice is a kernel, not a branch)
     }
@@ -589,6 +687,7 @@ int rw_destroy(rw_engine *eng) {
     if (!eng) return RW_OK;
     (void)hipSetDevice(eng->cfg.device_id);
     if (eng->stream) (void)hipStreamSynchronize(eng->stream);
+    if (eng->jit_module) (void)hipModuleUnload(eng->jit_module);
     if (eng->slab) (void)hipFree(eng->slab);
     if (eng->d_highway_bits) (void)hipFree(eng->d_highway_bits);
     if (eng->d_shelf_init) (void)hipFree(eng->d_shelf_init);
@@ -846,6 +945,27 @@ int rw_sync(rw_engine *eng) {
     return RW_OK;
 }
 
+const char *rw_jit_log(const rw_engine *eng) { return eng ? eng->jit_log.c_str() : ""; }
+
+int64_t rw_jit_probe(const int32_t shape[15], const char *arch, char *log, size_t log_len) {
+    // Compiles (or finds in the disk cache) the exact-shape build of `shape` for `arch` WITHOUT a device: the compile half of
+    // what rw_create does for a shape with no ahead-of-time build.  Returns the size of the code object, or -1.
+    if (!shape || !arch) return -1;
+#ifndef RW_NO_JIT
+    rw_jit::Shape sh{};
+    sh.R = shape[0]; sh.H = shape[1]; sh.W = shape[2]; sh.N = shape[3]; sh.Q = shape[4]; sh.S = shape[5]; sh.E = shape[6]; sh.T = shape[7];
+    sh.M = shape[8]; sh.wide = shape[9]; sh.obs = shape[10]; sh.NL = shape[11]; sh.layers = (uint32_t)shape[12]; sh.directional = shape[13];
+    sh.nt = shape[14];
+    rw_jit::Result res;
+    const bool ok = rw_jit::compile(sh, arch, &res);
+    if (log && log_len) snprintf(log, log_len, "%s", res.log.c_str());
+    return ok ? (int64_t)res.code.size() : -1;
+#else
+    if (log && log_len) snprintf(log, log_len, "built without run-time specialisation");
+    return -1;
+#endif
+}
+
 int rw_mark_views_stale(rw_engine *eng) {
     if (!eng) return RW_ERR_INVALID_ARG;
     eng->grid_stale = eng->agents_stale = true;
@@ -968,6 +1088,7 @@ int rw_get_info(const rw_engine *eng, rw_info *out) {
     out->state_layout = 0;  // (the per-shelf position layout of round 2/3 is gone: with non-temporal observation stores the shadow wins at every batch size)
     out->build_kind = eng->build_kind;
     out->obs_stores_stream = p.nt_obs;
+    out->jit = eng->jit_state;
     // A = 8HW + 4N + 40N + 4Q + 16 + 4NL + 4N + 4
     out->algorithmic_bytes_per_env_step =
         8LL * p.HW + 4LL * p.N + 40LL * p.N + 4LL * p.Q + 16 + 4LL * p.N * eng->L + 4LL * p.N + 4;

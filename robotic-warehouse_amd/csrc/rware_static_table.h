@@ -100,9 +100,27 @@ namespace {
 //  register budget of 8 wavefronts (amdgpu_waves_per_eu) was measured: small-8ag B = 16384 12.73 -> 11.14 us, but +0.1 .. +0.4 us
 //  wherever the batch fits anyway — the spilled scalars cost more than they buy.)
 #define RW_QRT_58(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 8, 256, ((N) >= 7 ? 14336 : 8192)), RW_STATIC(H, W, N, -1, S, 1, 16, 256, 0)
-// 9 .. 19 agents (rware/__init__.py:16 registers every count up to 19): 8 envs per workgroup (72 .. 152 agents: two or three
-// agent wavefronts), 4 envs for batches that are no multiple of 8 and as an explicit geometry
-#define RW_QRT_WIDE(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 8, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 4, 256, 0)
+// 9 .. 19 agents (rware/__init__.py:16 registers every count up to 19).  Measured, round 4, B = 16384, same box (us per step,
+// E = 8 vs 16; 8-env builds of 9 .. 13 agents with the register budget of 8 wavefronts per SIMD, rw::want_occ8):
+//   small-9ag 13.35 vs 13.05 | 10ag 13.80 vs 14.23 | 12ag 15.67 vs 16.52 | 13ag 18.48 vs 18.45 | 14ag 20.75 vs 19.79 | 16ag 22.81 vs 21.60
+//   large-16ag 22.38 vs 21.18 (E = 4: 20.8) | B = 8192 small-10ag 10.60 vs 10.05 | B = 32768 23.5 vs 24.0
+// -> 9 .. 13 agents: 8 envs per workgroup; 14 .. 16: 16 envs (no register budget to force: 4 workgroups per CU hold the batch);
+//    17 .. 19: 8 envs (three agents' envs per wavefront: 12 envs at most).  4 envs: batches that are no multiple of 8.
+#define RW_QRT_WIDE(H, W, S, N) RW_QRT_WIDE_##N(H, W, S, N)
+#define RW_QRT_WIDE_LO(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 8, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 16, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 4, 256, 0)
+#define RW_QRT_WIDE_MID(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 16, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 8, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 4, 256, 0)
+#define RW_QRT_WIDE_HI(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 8, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 4, 256, 0)
+#define RW_QRT_WIDE_9 RW_QRT_WIDE_LO
+#define RW_QRT_WIDE_10 RW_QRT_WIDE_LO
+#define RW_QRT_WIDE_11 RW_QRT_WIDE_LO
+#define RW_QRT_WIDE_12 RW_QRT_WIDE_LO
+#define RW_QRT_WIDE_13 RW_QRT_WIDE_LO
+#define RW_QRT_WIDE_14 RW_QRT_WIDE_MID
+#define RW_QRT_WIDE_15 RW_QRT_WIDE_MID
+#define RW_QRT_WIDE_16 RW_QRT_WIDE_MID
+#define RW_QRT_WIDE_17 RW_QRT_WIDE_HI
+#define RW_QRT_WIDE_18 RW_QRT_WIDE_HI
+#define RW_QRT_WIDE_19 RW_QRT_WIDE_HI
 #define RW_QRT_WIDE_A(H, W, S) RW_QRT_WIDE(H, W, S, 9), RW_QRT_WIDE(H, W, S, 10), RW_QRT_WIDE(H, W, S, 11), RW_QRT_WIDE(H, W, S, 12), \
                                RW_QRT_WIDE(H, W, S, 13), RW_QRT_WIDE(H, W, S, 14)
 #define RW_QRT_WIDE_B(H, W, S) RW_QRT_WIDE(H, W, S, 15), RW_QRT_WIDE(H, W, S, 16), RW_QRT_WIDE(H, W, S, 17), RW_QRT_WIDE(H, W, S, 18), \

@@ -137,7 +137,7 @@ class WarehouseVecEnv(_VectorEnvBase):
                  normalised_coordinates: bool = False, render_mode=None, *,
                  autoreset_mode: str = "next_step", devices=None, output: str = "numpy",
                  envs_per_workgroup: int = 0, threads_per_workgroup: int = 0, library: str | None = None,
-                 obs_stores: str | None = None):
+                 obs_stores: str | None = None, jit=None):
         if not 0 <= int(msg_bits) <= 16:
             raise ValueError("msg_bits must be in 0..16")
         self.msg_bits = int(msg_bits)
@@ -213,7 +213,10 @@ class WarehouseVecEnv(_VectorEnvBase):
                 image_directional=image_observation_directional, msg_bits=self.msg_bits,
                 # None / "auto": the engine's measured rule; "cached": observation lines stay in the cache hierarchy for a
                 # learner that reads them right behind the step; "stream": non-temporal stores (rw_stream_flags)
-                obs_stores=obs_stores))
+                obs_stores=obs_stores,
+                # None / "auto": shapes without an ahead-of-time exact-shape kernel are specialised at construction (hipRTC, disk
+                # cache) when the batch has >= 4096 envs; False / "off": never; True / "force": always
+                jit=jit))
         self._bounds = [b for b in self._bounds if b[1] > b[0]]
         self.shard_bounds = list(self._bounds)  # env range [lo, hi) of every engine / device, in order
         self.devices = devices[: len(self.engines)]

@@ -111,5 +111,42 @@ def test_kernel_isa_has_no_operand_order_sensitive_dpp_folds(tmp_path):
     assert ops <= allowed, f"operand-order-sensitive DPP folds in the kernel ISA: {sorted(ops - allowed)}"
     # second audit on the same listing: no kernel keeps anything in scratch memory (a register array indexed by a run-time
     # value ends up there — the chain walk of the first register version of the agent phases did: 2.3 us per step)
-    scratch = [int(v) for v in re.findall(r"^; ScratchSize: (\d+)", out.read_text(), flags=re.M)]
-    assert scratch and all(v == 0 for v in scratch), f"kernels with scratch memory: {scratch}"
+    # The builds that ask for the register budget of 8 wavefronts per SIMD (amdgpu_waves_per_eu) may spill a few dwords INSIDE
+    # the rare delivery / reset path (the 128-bit PCG64 multiply needs more registers than the rest of the kernel has left):
+    # every scratch instruction of such a kernel has to sit next to the PCG multiplier constant, and the frame stays tiny.
+    lines = out.read_text().splitlines()
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN2rw17rware_step_kernel.*:\s", l)]
+    assert starts
+    n_scratch_kernels = 0
+    for a, b in zip(starts, starts[1:] + [len(lines)]):
+        body = lines[a:b]
+        size = [int(m.group(1)) for l in body for m in [re.match(r"^; ScratchSize: (\d+)", l)] if m]
+        if not size or size[0] == 0:
+            continue
+        n_scratch_kernels += 1
+        assert size[0] <= 64, f"{lines[a][:120]}: {size[0]} bytes of scratch per lane"
+        pcg = [i for i, l in enumerate(body) if "0x4385df64" in l]   # low word of the PCG64 multiplier: only the RNG draw has it
+        spills = [i for i, l in enumerate(body) if re.match(r"^\s*scratch_(load|store)", l)]
+        assert pcg and spills and all(min(abs(i - j) for j in pcg) < 400 for i in spills), \
+            f"{lines[a][:120]}: scratch traffic outside the rare RNG path"
+    assert n_scratch_kernels <= 8, n_scratch_kernels
+
+
+def test_runtime_specialisation_compiles_without_a_device(tmp_path, monkeypatch):
+    """rw_jit_probe: the compile half of what rw_create does for a shape with no ahead-of-time exact-shape kernel — the device
+    headers embedded in the library, hipRTC, the disk cache — needs no GPU.  The shapes of three golden fixtures that run the
+    generic kernel otherwise (a `layout=` string, column_height 5 with sensor_range 5, sensor_range 3) compile; the second
+    request is a cache hit; an impossible shape fails with hipRTC's message, not a crash."""
+    if not any(os.path.exists(p) for p in ("/opt/rocm/lib/libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7")):
+        pytest.skip("no hipRTC on this box")
+    monkeypatch.setenv("RWARE_JIT_CACHE", str(tmp_path))
+    shapes = [dict(sensor_range=1, H=7, W=7, N=3, Q=3, S=20, E=16), dict(sensor_range=5, H=14, W=10, N=12, Q=12, S=60, E=8, nt=0),
+              dict(sensor_range=3, H=20, W=10, N=3, Q=3, S=80, E=16)]
+    for sh in shapes:
+        n, log = _capi.jit_probe(**sh)
+        assert n > 10000 and "compiled in" in log, log
+        n2, log2 = _capi.jit_probe(**sh)
+        assert n2 == n and log2.startswith("loaded "), log2
+    assert len(list(tmp_path.glob("*.hsaco"))) == len(shapes)
+    n, log = _capi.jit_probe(sensor_range=1, H=11, W=10, N=9, Q=9, S=32, E=4)       # a 4-env shelf chunk of 440 bytes: no whole DMA pieces
+    assert n == -1 and "16-byte granular" in log, log

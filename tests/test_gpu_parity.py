@@ -983,3 +983,62 @@ def test_capture_loop_replays_policy_and_step_from_one_graph():
     with pytest.raises(ValueError):
         rware_amd.WarehouseVecEnv(64, output="torch", **kw).capture_loop(policy)   # default stream: cannot capture
     genv.close(); eenv.close()
+
+
+@pytest.mark.parametrize("name,tile", [("layoutstr-3ag", 4), ("sr5-12ag-colheight5-twostage", 4), ("small-3ag-normcoord-sr3", 8),
+                                        ("img-tiny-3ag-northup-sr2", 8), ("msg3-tiny-3ag-sr2", 8), ("small-19ag", 4)])
+def test_runtime_specialised_builds_replay_reference_golden(name, tile, tmp_path, monkeypatch):
+    """Run-time specialisation (hipRTC, rware_jit.cpp): shapes without an ahead-of-time exact-shape kernel — a `layout=` string,
+    column_height 5 with sensor_range 5, normalised coordinates with sensor_range 3, an IMAGE / a message variant with
+    sensor_range 2 — are compiled by rw_create as rw::StaticCfg builds (`build_kind == 1`) and replay the unmodified reference's
+    golden traces in full; a second engine of the same shape takes the code object from the disk cache."""
+    monkeypatch.setenv("RWARE_JIT_CACHE", str(tmp_path))
+    meta, z = gu.load_fixture(name)
+    be = EngineBackend(meta["E"], tile=tile, jit="force", **gu.ctor_kwargs(meta))
+    info = be.env.engines[0].info
+    assert info.jit == 1 and info.build_kind == 1 and info.specialised == 1, be.env.engines[0].jit_log()
+    assert gu.replay(be, meta, z) == meta["T"]
+    be.env.close()
+    again = EngineBackend(meta["E"], tile=tile, jit="force", **gu.ctor_kwargs(meta))
+    assert again.env.engines[0].info.jit == 2, again.env.engines[0].jit_log()     # from the cache
+    again.env.close()
+
+
+def test_runtime_specialisation_policy(tmp_path, monkeypatch):
+    """Default policy: a shape without an exact / agent-count-static build is specialised at construction when the batch has at
+    least 4096 envs; small batches, registered shapes and jit=False keep the ahead-of-time kernels.  The specialised build
+    gives the generic kernel's results (both against the oracle)."""
+    monkeypatch.setenv("RWARE_JIT_CACHE", str(tmp_path))
+    kw = dict(rware_amd.env_kwargs("rware-small-4ag-v1"), column_height=5, sensor_range=2, max_steps=40)
+    small = rware_amd.WarehouseVecEnv(256, **kw)
+    assert small.engines[0].info.jit == 0 and small.engines[0].info.build_kind == 0        # generic: the batch is small
+    small.close()
+    reg = rware_amd.WarehouseVecEnv(4096, **rware_amd.env_kwargs("rware-small-4ag-v1"))
+    assert reg.engines[0].info.jit == 0 and reg.engines[0].info.build_kind == 1            # ahead-of-time exact build
+    reg.close()
+    off = rware_amd.WarehouseVecEnv(4096, jit=False, **kw)
+    assert off.engines[0].info.jit == 0 and off.engines[0].info.build_kind == 0
+    B, N = 4096, kw["n_agents"]
+    env = rware_amd.WarehouseVecEnv(B, **kw)
+    assert env.engines[0].info.jit == 1 and env.engines[0].info.build_kind == 1, env.engines[0].jit_log()
+    okw = dict(kw, reward_type=rware_amd.enums.enum_value(kw["reward_type"]))
+    orc = OracleVecEnv(B, **okw)
+    assert np.array_equal(env.reset(seed=12)[0], orc.reset(seed=12))
+    off.reset(seed=12)
+    rng = np.random.default_rng(13)
+    for t in range(90):
+        a = rng.choice(5, size=(B, N), p=[.1, .5, .1, .1, .2]).astype(np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        ob2, rw2, tm2, _, _ = off.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+        assert np.array_equal(ob2, o2) and np.array_equal(rw2, r2), t
+    acts = rng.choice(5, size=(20, B, N), p=[.1, .5, .1, .1, .2]).astype(np.int32)
+    obs, rew, term = env.rollout(acts)                       # the specialised fused-rollout kernel
+    for k in range(20):
+        o2, r2, d2 = orc.step_autoreset(acts[k], "next_step")
+        assert np.array_equal(obs[k], o2) and np.array_equal(rew[k], r2) and np.array_equal(term[k], d2.astype(bool)), k
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    env.close(); off.close()
