@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RW_ABI_VERSION 2
+#define RW_ABI_VERSION 3
 
 typedef struct rw_engine rw_engine;
 
@@ -69,7 +69,9 @@ enum rw_autoreset {
     RW_AUTORESET_DISABLED = 0,
     RW_AUTORESET_NEXT_STEP = 1, /* the step after `terminated` performs reset(): action ignored,
                                    reward 0, terminated 0 (Gymnasium >= 1.0 default)              */
-    RW_AUTORESET_SAME_STEP = 2  /* the terminating step returns the reset observation             */
+    RW_AUTORESET_SAME_STEP = 2  /* the terminating step returns the reset observation; the terminal
+                                   observation is kept in RW_BUF_FINAL_OBS (Gymnasium's
+                                   info["final_obs"])                                             */
 };
 
 /* How `rw_config.stream` is read.  A hipStream_t of NULL is also the handle of the device's default
@@ -132,7 +134,12 @@ enum rw_buffer_kind {
     RW_BUF_FEATURES = 16,    /* float32 [B][N][6]  IMAGE_DICT features: one-hot direction, on_highway,
                                                    carrying (:727-742); unused otherwise          */
     RW_BUF_AGENT_MSG = 17,   /* int32   [B][N]     bit k == message[k] of the agent (msg_bits > 0, :89)   */
-    RW_BUF_KIND_COUNT = 18
+    RW_BUF_FINAL_OBS = 18,   /* float32 [B][N][L]  SAME_STEP autoreset, FLATTENED observations: the observation of the terminating
+                                                   step itself — what Warehouse.step returns with done = True (:929-946) —
+                                                   written for the envs whose `terminated` flag that step set (rows of other
+                                                   envs keep older contents); the reset observation goes to RW_BUF_OBS.  Empty
+                                                   in the other modes and for IMAGE observations                          */
+    RW_BUF_KIND_COUNT = 19
 };
 
 /* Mirrors the constructor of rware.warehouse.Warehouse (rware/warehouse.py:146-170).  The
@@ -214,6 +221,16 @@ int rw_step_tape_device_timed(rw_engine *eng, const int32_t *tape_dev, int32_t t
  * outputs ([T][B][N][L] f32, [T][B][N] f32, [T][B] u8); otherwise only the last step's remain. */
 int rw_step_many_device(rw_engine *eng, const int32_t *actions_dev, int32_t n_steps,
                         float *obs_tape, float *reward_tape, uint8_t *terminated_tape);
+
+/* One call that enqueues a step on SEVERAL engines — the shards of a single-process multi-device env (one engine per GPU): every
+ * engine but the first is launched by a thread of its own that rw_multi_create starts (bound to that engine's device, spinning
+ * briefly between rounds, asleep otherwise); rw_multi_step_device(actions_dev[k] = engine k's device action array) returns when
+ * all launches are enqueued — the host pays about one launch, not n.  Results as for rw_step_device; the engines stay usable
+ * on their own between rounds (never concurrently with a round).  Destroy the rw_multi before its engines. */
+typedef struct rw_multi rw_multi;
+int rw_multi_create(rw_engine **engines, int32_t n, rw_multi **out);
+int rw_multi_step_device(rw_multi *m, const int32_t *const *actions_dev);
+int rw_multi_destroy(rw_multi *m);
 
 /* raw device memory for action / output tapes (callers without a GPU array library) */
 int rw_device_malloc(rw_engine *eng, size_t bytes, void **dev_ptr);

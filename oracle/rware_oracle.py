@@ -214,7 +214,11 @@ class OracleVecEnv:
         if mode == "same_step":
             rew, done = self.step(actions)
             if done.any():
+                # what Warehouse.step itself returned with done = True (rware/warehouse.py:929-946): Gymnasium's info["final_obs"]
+                self.final_obs, self.final_mask = self.obs(), done.astype(bool)
                 self.reset(mask=done)
+            else:
+                self.final_obs, self.final_mask = None, done.astype(bool)
             return self.obs(), rew, done
         rew, done = self.step(actions)
         return self.obs(), rew, done

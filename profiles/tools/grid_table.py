@@ -13,8 +13,11 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 KIND = {0: "generic", 1: "exact", 2: "agent-count-static", 3: "size-static"}
 grid = [f"rware-{s}-{n}ag{d}-v1" for s in ("tiny", "small", "medium") for n in (2, 4, 6, 8) for d in ("-easy", "", "-hard")]
 extra = ["rware-small-1ag-v1", "rware-small-3ag-v1", "rware-small-5ag-v1", "rware-small-7ag-v1", "rware-tiny-3ag-hard-v1", "rware-medium-5ag-easy-v1",
-         "rware-large-2ag-v1", "rware-large-4ag-v1", "rware-large-6ag-v1", "rware-large-8ag-v1", "rware-small-10ag-v1", "rware-small-12ag-v1",
-         "rware-large-16ag-v1", "rware-small-19ag-v1"]
+         "rware-large-2ag-v1", "rware-large-4ag-v1", "rware-large-6ag-v1", "rware-large-8ag-v1",
+         # 9 .. 19 agents: agent-count-static builds, agent phases in registers (round 4)
+         "rware-small-9ag-v1", "rware-small-10ag-v1", "rware-tiny-11ag-v1", "rware-small-12ag-v1", "rware-medium-13ag-v1", "rware-small-14ag-v1",
+         "rware-medium-15ag-hard-v1", "rware-small-16ag-v1", "rware-large-16ag-v1", "rware-small-17ag-v1", "rware-large-18ag-easy-v1",
+         "rware-small-19ag-v1"]
 print(f"B = {B} envs per GPU; us per step of the whole batch; G agent-steps/s")
 print(f"{'task':30s} {'build':20s} {'E':>3s} {'obs stores':>12s} {'us/step':>9s} {'G a-s/s':>9s}")
 for env_id in grid + extra:

@@ -1,6 +1,7 @@
 """us per step of explicit (task, batch, geometry, observation-store) combinations, un-profiled, HIP events on the launches.
-    python profiles/tools/measure.py <env_id>:<B>[:<E>[:<stores>[:<sensor_range>]]] ...
-E = 0: the engine's own geometry; stores = auto | cached | stream.  Per-step launches from a device action tape
+    python profiles/tools/measure.py <env_id>:<B>[:<E>[:<stores>[:<sensor_range>[:<jit>]]]] ...
+E = 0: the engine's own geometry; stores = auto | cached | stream; jit = auto | off | force (run-time specialisation).
+<env_id> may also be one of the unregistered shapes below (constructor arguments, not ids).  Per-step launches from a device action tape
 (rw_step_tape_device_timed), uniform random actions, next_step autoreset.  One line per spec."""
 import sys
 
@@ -11,18 +12,26 @@ sys.path.insert(0, ".")
 import rware_amd  # noqa: E402
 
 KIND = {0: "generic", 1: "exact", 2: "agent-count-static", 3: "size-static"}
+CUSTOM = {
+    # the layout string of the reference's README / tests (rware/warehouse.py:328-350), 3 agents
+    "layoutstr-3ag": dict(layout="\n".join(["X.....X", "X.....X", "X.xxx.X", "X.xxx.X", "X.....X", "X.....X", "..g.g.."]), n_agents=3, request_queue_size=3),
+    "small-4ag-colheight5": dict(rware_amd.env_kwargs("rware-small-4ag-v1"), column_height=5),
+    "sr5-12ag-colheight5": dict(shelf_columns=3, shelf_rows=2, column_height=5, n_agents=12, request_queue_size=12, sensor_range=5),
+    "small-24ag": dict(rware_amd.env_kwargs("rware-small-4ag-v1"), n_agents=24, request_queue_size=24),
+}
 for spec in sys.argv[1:]:
     f = spec.split(":")
     env_id, B = f[0], int(f[1])
     E = int(f[2]) if len(f) > 2 else 0
     stores = f[3] if len(f) > 3 and f[3] != "auto" else None
-    sr = int(f[4]) if len(f) > 4 else 0
-    kw = rware_amd.env_kwargs(env_id)
+    sr = int(f[4]) if len(f) > 4 and f[4] else 0
+    jit = {"auto": None, "off": False, "force": True}[f[5]] if len(f) > 5 else None
+    kw = dict(CUSTOM[env_id]) if env_id in CUSTOM else rware_amd.env_kwargs(env_id)
     if sr:
         kw["sensor_range"] = sr
     N = kw["n_agents"]
     try:
-        env = rware_amd.WarehouseVecEnv(B, envs_per_workgroup=E, threads_per_workgroup=256 if E else 0, obs_stores=stores, **kw)
+        env = rware_amd.WarehouseVecEnv(B, envs_per_workgroup=E, threads_per_workgroup=256 if E else 0, obs_stores=stores, jit=jit, **kw)
     except Exception as exc:  # noqa: BLE001
         print(f"{spec:44s} FAILED {exc}")
         continue
@@ -42,6 +51,6 @@ for spec in sys.argv[1:]:
     eng.sync()
     i = eng.info
     eb = int(i.engine_bytes_per_env_step) * B
-    print(f"{spec:44s} {KIND[int(i.build_kind)]:18s} E {int(i.envs_per_workgroup):2d} {'nt' if int(i.obs_stores_stream) else 'cached':6s} "
+    print(f"{spec:44s} {KIND[int(i.build_kind)] + (' (jit)' if int(i.jit) > 0 else ''):18s} E {int(i.envs_per_workgroup):2d} {'nt' if int(i.obs_stores_stream) else 'cached':6s} "
           f"{best:8.3f} us/step {B * N / best / 1e3:7.2f} G a-s/s  engine {eb / 1e6:7.1f} MB -> {eb / best / 1e6:5.2f} TB/s = {eb / best / 8e6:4.2f} of peak", flush=True)
     env.close()

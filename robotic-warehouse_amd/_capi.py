@@ -13,17 +13,17 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "librware_hip.so")
 
-RW_ABI_VERSION = 2
+RW_ABI_VERSION = 3
 RW_OK, RW_ERR_INVALID_ARG, RW_ERR_INVALID_ACTION, RW_ERR_HIP, RW_ERR_UNSUPPORTED, RW_ERR_NO_DEVICE, RW_ERR_INDEX = 0, -1, -2, -3, -4, -5, -6
 
 BUF = {
     "obs": 0, "rewards": 1, "terminated": 2, "truncated": 3, "grid": 4, "agent_x": 5, "agent_y": 6,
     "agent_dir": 7, "agent_carry": 8, "agent_delivered": 9, "queue": 10, "steps": 11, "inactive": 12,
-    "rng": 13, "need_reset": 14, "actions": 15, "features": 16, "agent_msg": 17,
+    "rng": 13, "need_reset": 14, "actions": 15, "features": 16, "agent_msg": 17, "final_obs": 18,
 }
 BUF_DTYPE = {
     "obs": np.float32, "rewards": np.float32, "terminated": np.uint8, "truncated": np.uint8,
-    "rng": np.uint64, "need_reset": np.uint8, "features": np.float32,
+    "rng": np.uint64, "need_reset": np.uint8, "features": np.float32, "final_obs": np.float32,
 }
 
 RW_STREAM_USE_GIVEN = 1  # rw_stream_flags: `stream` is taken literally, NULL == the device's default stream
@@ -55,7 +55,7 @@ class RwInfo(C.Structure):
 
 EXPORTS = (
     "rw_create", "rw_destroy", "rw_last_error", "rw_reset", "rw_step", "rw_step_device",
-    "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_mark_views_stale", "rw_jit_log", "rw_jit_probe", "rw_sync", "rw_get_buffer", "rw_read", "rw_read_outputs", "rw_write",
+    "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_mark_views_stale", "rw_jit_log", "rw_jit_probe", "rw_multi_create", "rw_multi_step_device", "rw_multi_destroy", "rw_sync", "rw_get_buffer", "rw_read", "rw_read_outputs", "rw_write",
     "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
     "rw_abi_version", "rw_debug_timeline", "rw_device_malloc", "rw_device_free", "rw_copy_to_device",
     "rw_copy_to_host", "rw_snapshot_create", "rw_snapshot_save", "rw_snapshot_restore", "rw_snapshot_destroy",
@@ -115,6 +115,9 @@ def load(path: str | None = None):
     lib.rw_jit_log.restype = C.c_char_p
     lib.rw_jit_probe.argtypes = [C.POINTER(C.c_int32), C.c_char_p, C.c_char_p, C.c_size_t]
     lib.rw_jit_probe.restype = C.c_int64
+    lib.rw_multi_create.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
+    lib.rw_multi_step_device.argtypes = [vp, C.POINTER(vp)]
+    lib.rw_multi_destroy.argtypes = [vp]
     lib.rw_sync.argtypes = [vp]
     lib.rw_get_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.rw_read.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -198,7 +201,7 @@ class Engine:
         obs_shape = (self.B, self.N, self.L) if int(observation_type) == 1 else (self.B, self.N, self.L // (win * win), win, win)
         self.shapes = {
             "features": (self.B, self.N, 6),
-            "obs": obs_shape, "rewards": (self.B, self.N), "terminated": (self.B,),
+            "obs": obs_shape, "final_obs": obs_shape, "rewards": (self.B, self.N), "terminated": (self.B,),
             "truncated": (self.B,), "grid": (self.B, 2, self.H, self.W), "agent_x": (self.B, self.N),
             "agent_y": (self.B, self.N), "agent_dir": (self.B, self.N), "agent_carry": (self.B, self.N),
             "agent_delivered": (self.B, self.N), "queue": (self.B, self.Q), "steps": (self.B,),
@@ -372,6 +375,40 @@ class Engine:
         ms = C.c_float()
         self._check(self.lib.rw_event_elapsed_ms(self._h, a, b, C.byref(ms)))
         return float(ms.value)
+
+
+class MultiEngine:
+    """rw_multi: one C call per step for all the engines of a single-process multi-device env (launcher thread per engine)."""
+
+    def __init__(self, engines):
+        self.engines, self.lib = list(engines), engines[0].lib
+        n = len(self.engines)
+        hs = (C.c_void_p * n)(*[e._h for e in self.engines])
+        self._h = C.c_void_p()
+        rc = self.lib.rw_multi_create(hs, n, C.byref(self._h))
+        if rc != RW_OK:
+            raise EngineError(rc, "rw_multi_create failed")
+        self._ptrs = (C.c_void_p * n)()
+
+    def step_device(self, dev_ptrs):
+        p = self._ptrs
+        for k, v in enumerate(dev_ptrs):
+            p[k] = v
+        rc = self.lib.rw_multi_step_device(self._h, p)
+        if rc != RW_OK:
+            msgs = [(e.lib.rw_last_error(e._h) or b"").decode() for e in self.engines]
+            raise EngineError(rc, next((m for m in msgs if m), "rw_multi_step_device failed"))
+
+    def close(self):
+        if self._h:
+            self.lib.rw_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def seed_state(seed: int, library=None) -> np.ndarray:

@@ -7,12 +7,16 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -217,7 +221,7 @@ int pack_agents(rw_engine *eng) {
 
 size_t elem_size(int kind) {
     switch (kind) {
-        case RW_BUF_OBS: case RW_BUF_REWARDS: case RW_BUF_FEATURES: return 4;
+        case RW_BUF_OBS: case RW_BUF_REWARDS: case RW_BUF_FEATURES: case RW_BUF_FINAL_OBS: return 4;
         case RW_BUF_TERMINATED: case RW_BUF_TRUNCATED: case RW_BUF_NEED_RESET: return 1;
         case RW_BUF_RNG: return 8;
         default: return 4;
@@ -568,13 +572,16 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     n_elems[RW_BUF_ACTIONS] = szB * N * AM;
     n_elems[RW_BUF_FEATURES] = szB * N * 6;
     n_elems[RW_BUF_AGENT_MSG] = szB * N;
+    // the terminal observation of SAME_STEP autoreset (FLATTENED): allocated only where the kernel writes it
+    const bool want_final = cfg->autoreset_mode == RW_AUTORESET_SAME_STEP && !eng->image;
+    n_elems[RW_BUF_FINAL_OBS] = want_final ? szB * N * eng->L : 0;
     // One slab for every buffer: the per-step working set (agent SoA, queue, counters, flags, rewards,
     // shelf shadow) sits in a few contiguous MiB, so a workgroup's ~15 streams share TLB entries
     // instead of touching 15 separate allocations.  Order = hot and small first.
     static const int order[RW_BUF_KIND_COUNT] = {
         RW_BUF_AGENT_X, RW_BUF_AGENT_Y, RW_BUF_AGENT_DIR, RW_BUF_AGENT_CARRY, RW_BUF_AGENT_DELIVERED, RW_BUF_QUEUE,
         RW_BUF_AGENT_MSG, RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_NEED_RESET, RW_BUF_REWARDS, RW_BUF_TERMINATED, RW_BUF_TRUNCATED,
-        RW_BUF_ACTIONS, RW_BUF_RNG, RW_BUF_FEATURES, RW_BUF_OBS, RW_BUF_GRID};
+        RW_BUF_ACTIONS, RW_BUF_RNG, RW_BUF_FEATURES, RW_BUF_OBS, RW_BUF_FINAL_OBS, RW_BUF_GRID};
     auto up = [](size_t x) { return (x + 4095) & ~(size_t)4095; };
     size_t slab_bytes = 0, off[RW_BUF_KIND_COUNT];
     eng->rec_off = 0;  // the packed agent records lead the hot set
@@ -661,6 +668,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.features = obs_type == RW_OBS_IMAGE_DICT ? (float *)eng->buf[RW_BUF_FEATURES].ptr : nullptr;
     p.msg_bits = cfg->msg_bits;
     p.amsg = (int32_t *)eng->buf[RW_BUF_AGENT_MSG].ptr;
+    p.final_obs = want_final ? (float *)eng->buf[RW_BUF_FINAL_OBS].ptr : nullptr;
     rw::LaunchArgs &la = eng->la;
     la.actions = (const int32_t *)eng->buf[RW_BUF_ACTIONS].ptr;
     la.reset_mask = eng->d_mask;
@@ -1117,6 +1125,110 @@ int rw_event_elapsed_ms(rw_engine *eng, int32_t a, int32_t b, float *ms) {
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
     RW_HIP(eng, hipEventSynchronize(eng->events[b]));
     RW_HIP(eng, hipEventElapsedTime(ms, eng->events[a], eng->events[b]));
+    return RW_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// rw_multi: ONE call that enqueues a step on every engine of a single-process multi-device env ("use one
+// thread per device or a single C call that fans out").  Every engine but the first has a launcher thread of its own, bound to
+// that engine's device; rw_multi_step_device hands the action pointers over, launches engine 0 itself and returns when every
+// launch has been enqueued (nothing waits for the GPUs).  A launcher spins on the round counter for a few tens of microseconds
+// after each round — a training loop calls every ~10 us, so it stays hot — and sleeps on a condition variable otherwise.
+struct rw_multi {
+    std::vector<rw_engine *> engs;
+    std::vector<const int32_t *> actions;
+    std::vector<int> rc;
+    std::vector<std::thread> threads;
+    std::atomic<uint64_t> round{0};
+    std::atomic<int> pending{0};
+    std::atomic<bool> stop{false};
+    std::atomic<int> sleepers{0};
+    std::mutex mu;
+    std::condition_variable cv;
+};
+
+namespace {
+void multi_worker(rw_multi *m, int k) {
+    (void)hipSetDevice(m->engs[(size_t)k]->cfg.device_id);
+    uint64_t seen = 0;
+    for (;;) {
+        int spins = 0;
+        while (m->round.load(std::memory_order_acquire) == seen && !m->stop.load(std::memory_order_acquire)) {
+            if (++spins < 20000) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+                continue;
+            }
+            std::unique_lock<std::mutex> lk(m->mu);
+            m->sleepers.fetch_add(1);
+            m->cv.wait(lk, [&] { return m->round.load(std::memory_order_acquire) != seen || m->stop.load(); });
+            m->sleepers.fetch_sub(1);
+        }
+        if (m->stop.load(std::memory_order_acquire)) return;
+        seen = m->round.load(std::memory_order_acquire);
+        rw_engine *eng = m->engs[(size_t)k];
+        rw::LaunchArgs la = eng->la;
+        la.actions = m->actions[(size_t)k];
+        m->rc[(size_t)k] = la.actions ? launch(eng, la, rw::OP_STEP) : RW_ERR_INVALID_ARG;
+        m->pending.fetch_sub(1, std::memory_order_acq_rel);
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int rw_multi_create(rw_engine **engines, int32_t n, rw_multi **out) {
+    if (!engines || n < 1 || !out) return RW_ERR_INVALID_ARG;
+    for (int k = 0; k < n; ++k)
+        if (!engines[k]) return RW_ERR_INVALID_ARG;
+    rw_multi *m = new (std::nothrow) rw_multi();
+    if (!m) return RW_ERR_HIP;
+    m->engs.assign(engines, engines + n);
+    m->actions.assign((size_t)n, nullptr);
+    m->rc.assign((size_t)n, RW_OK);
+    for (int k = 1; k < n; ++k) m->threads.emplace_back(multi_worker, m, k);
+    *out = m;
+    return RW_OK;
+}
+
+int rw_multi_step_device(rw_multi *m, const int32_t *const *actions_dev) {
+    if (!m || !actions_dev) return RW_ERR_INVALID_ARG;
+    const int n = (int)m->engs.size();
+    for (int k = 0; k < n; ++k) m->actions[(size_t)k] = actions_dev[k];
+    m->pending.store(n - 1, std::memory_order_release);
+    m->round.fetch_add(1, std::memory_order_acq_rel);
+    if (m->sleepers.load(std::memory_order_acquire) > 0) {
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->cv.notify_all();
+    }
+    rw_engine *e0 = m->engs[0];
+    int rc = RW_ERR_INVALID_ARG;
+    if (actions_dev[0] && hipSetDevice(e0->cfg.device_id) == hipSuccess) {
+        rw::LaunchArgs la = e0->la;
+        la.actions = actions_dev[0];
+        rc = launch(e0, la, rw::OP_STEP);
+    }
+    while (m->pending.load(std::memory_order_acquire) > 0) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    for (int k = 1; k < n && rc == RW_OK; ++k) rc = m->rc[(size_t)k];
+    return rc;
+}
+
+int rw_multi_destroy(rw_multi *m) {
+    if (!m) return RW_OK;
+    m->stop.store(true, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->cv.notify_all();
+    }
+    for (auto &t : m->threads) t.join();
+    delete m;
     return RW_OK;
 }
 

@@ -127,6 +127,9 @@ struct Params {
     // communication bits (rware/warehouse.py:255-259, 660-667, 810-812); only the OBS_FLATTENED_MSG kernels
     int32_t msg_bits;     // M: an action is [Action, bit_0 .. bit_{M-1}] per agent, L = 8 + (7 + M)(2r+1)^2
     int32_t *amsg;        // [B][N] bit k == message[k]
+    // SAME_STEP autoreset, FLATTENED observations: where the terminal observation of an env goes when the step that ends its
+    // episode also resets it (RW_BUF_FINAL_OBS, [B][N][L]); nullptr otherwise
+    float *final_obs;
 };
 
 // What changes from launch to launch.  The kernel-argument segment is rewritten by the host for every
@@ -1203,6 +1206,43 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
 
     // ---------------------------------------------------------------- RS: reset flagged envs (:757-802)
     if (RW_RARE(s_misc[0] != 0)) {  // workgroup-uniform; rare
+        if constexpr (!kImage) {
+            // SAME_STEP autoreset: the observation of the terminating step itself — what Warehouse.step returns together with
+            // done = True (rware/warehouse.py:929-946, _make_obs :722-744) — goes to RW_BUF_FINAL_OBS before the env is reset
+            // (Gymnasium's info["final_obs"]).  Rare (every max_steps steps), so it is written straight from the definition
+            // (:598-674), one thread per float, no bit string: compact code off the common path.
+            float *fin = p.final_obs;
+            if (op == OP_STEP && k_autoreset == AR_SAME_STEP && fin != nullptr) {
+                for (int g = tid; g < nea * L; g += T) {
+                    const int i = g / L, k = g - i * L, e = rw_div18(i, mN);
+                    if (!s_envi[e * ENVI_W + ENVI_DONE]) continue;  // (only envs this step terminated: ENVI_RESET may also be a mask)
+                    const int ax = s_ax[i], ay = s_ay[i];
+                    float v;
+                    if (k < 8) {  // self part (:643-647)
+                        v = k == 0 ? coordf(0, ax) : k == 1 ? coordf(1, ay) : k == 2 ? (s_carry[i] ? 1.0f : 0.0f)
+                          : k < 7 ? (s_dir[i] == k - 3 ? 1.0f : 0.0f) : (on_highway(ay * W + ax) ? 1.0f : 0.0f);
+                    } else {      // window cell c, row-major, dy outer (:628-629), CW values per cell (:655-673)
+                        const int c = (k - 8) / CW, b = (k - 8) - c * CW;
+                        const int x = ax + c % WIN - R, y = ay + c / WIN - R;
+                        const bool ok = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
+                        const int cell = e * HW + (ok ? y * W + x : 0);
+                        const int ida = ok ? (s_ga[cell] & 0x7f) : 0, ids = ok ? (int)s_gs[cell] : 0;
+                        const int j = e * N + (ida ? ida - 1 : 0);
+                        if (b == 0) v = ida ? 1.0f : 0.0f;
+                        else if (b < 5) v = (ida ? s_dir[j] : 0) == b - 1 ? 1.0f : 0.0f;  // empty / off-map: [1, 0, 0, 0] (:659)
+                        else if (b < 5 + M) v = (ida && ((s_msg[j] >> (b - 5)) & 1)) ? 1.0f : 0.0f;
+                        else if (b == 5 + M) v = ids ? 1.0f : 0.0f;
+                        else {  // requested: straight from the queue (the bitmap of an env that resets in this launch is not built
+                            int rq = 0;  // by every agent-phase implementation — RS rebuilds it after the reset)
+                            for (int q = 0; q < Q; ++q) rq |= (s_queue[e * Q + q] == ids) ? 1 : 0;
+                            v = (ids && rq) ? 1.0f : 0.0f;
+                        }
+                    }
+                    as_global(fin)[((size_t)e0 * N) * L + g] = v;
+                }
+                lds_barrier();  // (the reset below overwrites the arrays this read)
+            }
+        }
         for (int c = tid; c < ne * HW; c += T) {
             const int e = c / HW;
             if (!s_envi[e * ENVI_W + ENVI_RESET]) continue;

@@ -225,6 +225,12 @@ class WarehouseVecEnv(_VectorEnvBase):
         self._tviews = {}
         self._live_actions = None
         self._pool = None
+        self._multi = None
+        # step()'s fast path: (tensor type, dtype, shape, device, bound C function, engine handle, cached result tuple); only for
+        # output="torch" envs whose results are the same zero-copy views every step and whose observation needs no host-side check
+        self._has_final_obs = autoreset_mode == "same_step" and not image
+        self._fast = None
+        self._fast_ok = output == "torch" and not self._dict_obs and len(devices) == 1
 
     # ------------------------------------------------------------------------------- spaces
     def _make_spaces(self):
@@ -279,8 +285,24 @@ class WarehouseVecEnv(_VectorEnvBase):
         With output="torch" all four results are zero-copy views of engine memory — the SAME tensor objects every call,
         overwritten in place by the next step (obs, rewards, terminated; truncated stays False).  A loop that keeps them
         across steps (`dones.append(terminated)`) must `.clone()` them; output="numpy" returns fresh host arrays."""
+        fast = self._fast
+        if fast is not None and type(actions) is fast[0] and actions.dtype is fast[1] and actions.is_contiguous() \
+                and actions.shape == fast[2] and actions.device == fast[3]:
+            # the closed loop's hot call: a contiguous int32 CUDA tensor of the right shape on the env's device, single engine —
+            # one pre-bound C call and the cached result tuple (the checks of step_async / step_wait, done once)
+            self._live_actions = actions
+            rc = fast[4](fast[5], actions.data_ptr())
+            if rc:
+                self.engines[0]._check(rc)
+            return fast[6]
         self.step_async(actions)
-        return self.step_wait()
+        out = self.step_wait()
+        if fast is None and self._fast_ok and self._torch is not None and isinstance(actions, self._torch.Tensor) and actions.is_cuda \
+                and actions.dtype == self._torch.int32 and actions.is_contiguous() and len(self.engines) == 1 \
+                and tuple(actions.shape) in ((self.num_envs, self.n_agents), (self.num_envs, self.n_agents, 1 + self.msg_bits)):
+            eng = self.engines[0]
+            self._fast = (type(actions), actions.dtype, actions.shape, actions.device, eng.lib.rw_step_device, eng._h, out)
+        return out
 
     def step_async(self, actions):
         t = self._torch
@@ -288,11 +310,13 @@ class WarehouseVecEnv(_VectorEnvBase):
             # one CUDA tensor per device (the shards of a multi-device env): every launch is enqueued before anything waits
             if len(actions) != len(self.engines):
                 raise ValueError(f"expected {len(self.engines)} per-device action tensors, got {len(actions)}")
-            live = []
-            for d, (eng, a) in enumerate(zip(self.engines, actions)):
-                a = self._device_actions(a, eng.B, d)
-                live.append(a)
-                eng.step_device(a.data_ptr())
+            live = [self._device_actions(a, eng.B, d) for d, (eng, a) in enumerate(zip(self.engines, actions))]
+            if len(live) > 1:  # ONE C call: every engine but the first has a launcher thread of its own (rw_multi)
+                if self._multi is None:
+                    self._multi = _capi.MultiEngine(self.engines)
+                self._multi.step_device([a.data_ptr() for a in live])
+            else:
+                self.engines[0].step_device(live[0].data_ptr())
             self._live_actions = live
             return
         if t is not None and isinstance(actions, t.Tensor) and actions.is_cuda:
@@ -340,12 +364,14 @@ class WarehouseVecEnv(_VectorEnvBase):
         if self.output == "torch":
             if len(self.engines) > 1:  # one tuple entry per device, in shard order; nothing waited for
                 vs = [self._torch_views(d) for d in range(len(self.engines))]
+                fin = [self._final_info(v, d) for d, v in enumerate(vs)]
+                info = {k: tuple(f[k] for f in fin) for k in fin[0]}  # (one entry per device, like the results)
                 return (tuple(self._obs_of(v) for v in vs), tuple(v["rewards"] for v in vs),
-                        tuple(v["terminated_bool"] for v in vs), tuple(v["truncated_bool"] for v in vs), {})
+                        tuple(v["terminated_bool"] for v in vs), tuple(v["truncated_bool"] for v in vs), info)
             v = self._torch_views()
             # the flag buffers are uint8 0/1: reinterpreted as bool, not cast (a cast is a torch kernel per flag per step
             # around a ~7 us step kernel)
-            return self._observations(), v["rewards"], v["terminated_bool"], v["truncated_bool"], {}
+            return self._observations(), v["rewards"], v["terminated_bool"], v["truncated_bool"], self._final_info(v)
         # host arrays: the whole return tuple in one round trip per device (`truncated` is always False, :942 — nothing to read)
         if self._index_layers:
             self.sync()  # IndexError where the reference's _make_img_obs raises it
@@ -360,11 +386,16 @@ class WarehouseVecEnv(_VectorEnvBase):
             feat = np.concatenate([p[3] for p in parts], axis=0) if want_f else None
         else:
             obs, rew, term, feat = self.engines[0].read_outputs(want_f)
+        info = {}
+        if self._has_final_obs and term.any():  # (rare: the extra copy is made only on a step that ended an episode)
+            info = {"final_obs": self._gather("final_obs"), "_final_obs": term.view(np.bool_).copy()}
+            if self._dict_obs:
+                info["final_obs"] = self.dict_from_flat(info["final_obs"])
         if self._dict_obs:
             obs = self.dict_from_flat(obs)
         elif want_f:
             obs = {"image": obs, "features": feat}
-        return obs, rew, term.view(np.bool_), np.zeros(self.num_envs, np.bool_), {}
+        return obs, rew, term.view(np.bool_), np.zeros(self.num_envs, np.bool_), info
 
     def rollout(self, actions, want_obs=True):
         """Open-loop rollout: `actions` (T, B, N) -> (obs (T,B,N,L), rewards (T,B,N), terminated (T,B)).
@@ -543,6 +574,17 @@ class WarehouseVecEnv(_VectorEnvBase):
             }
         return tuple(agent(i) for i in range(n))
 
+    def _final_info(self, v, d=0):
+        """SAME_STEP autoreset: the step that ends an episode returns the RESET observation; what the reference's step() returned
+        with done = True (rware/warehouse.py:929-946) is kept as info["final_obs"], valid in the rows where info["_final_obs"]
+        (== terminated) is set — Gymnasium >= 1.0's vector-env convention.  Zero-copy views (torch output)."""
+        if not self._has_final_obs:
+            return {}
+        if "final_obs" not in v:
+            t, eng = self._torch, self.engines[d]
+            v["final_obs"] = t.as_tensor(eng.device_array("final_obs"), device=v["obs"].device)
+        return {"final_obs": v["final_obs"], "_final_obs": v["terminated_bool"]}
+
     def _obs_of(self, v):
         return {"image": v["obs"], "features": v["features"]} if self.observation_type == ObservationType.IMAGE_DICT else v["obs"]
 
@@ -638,6 +680,9 @@ class WarehouseVecEnv(_VectorEnvBase):
         return self.global_image
 
     def close(self, **kwargs):
+        if self._multi is not None:
+            self._multi.close()
+            self._multi = None
         for eng in self.engines:
             eng.close()
         self.engines = []

@@ -96,11 +96,21 @@ inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+// (module API: the run-time specialised builds do not exist in this build — RW_NO_JIT — the names only have to compile)
+typedef struct emu_module *hipModule_t;
+typedef struct emu_function *hipFunction_t;
+inline hipError_t hipModuleUnload(hipModule_t) { return hipSuccess; }
+inline hipError_t hipModuleLaunchKernel(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, hipStream_t, void **, void **) { return 1; }
+inline hipError_t hipExtModuleLaunchKernel(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, size_t, hipStream_t, void **, void **,
+                                           hipEvent_t, hipEvent_t, unsigned) { return 1; }
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
 
+#include <mutex>
+extern std::mutex emu_launch_mutex;  // one "device": launches from several host threads (rw_multi) run one after the other
 template <typename... KArgs, typename... Args>
 void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds_bytes, hipStream_t, Args... args) {
     (void)lds_bytes;
+    std::lock_guard<std::mutex> emu_launch_lock(emu_launch_mutex);
     for (unsigned b = 0; b < grid.x; ++b) {
         pthread_barrier_t bar;
         pthread_barrier_init(&bar, nullptr, block.x);

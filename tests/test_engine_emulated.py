@@ -78,10 +78,18 @@ def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
         a = rng.choice(5, size=(B, kw["n_agents"]), p=[0.1, 0.55, 0.1, 0.1, 0.15]).astype(np.int32)
         if M:
             a = np.concatenate([a[..., None], rng.integers(0, 2, size=(B, kw["n_agents"], M), dtype=np.int32)], axis=-1)
-        obs, rew, term, trunc, _ = env.step(a)
+        obs, rew, term, trunc, info = env.step(a)
         o2, r2, d2 = orc.step_autoreset(a, mode)
         assert np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
         assert np.array_equal(obs, o2), t
+        if mode == "same_step" and kw.get("observation_type", 1) == 1:
+            # the terminal observation of the step that ended (and reset) an episode: info["final_obs"], as Gymnasium >= 1.0 has it
+            assert ("final_obs" in info) == bool(d2.any()), t
+            if d2.any():
+                assert np.array_equal(info["_final_obs"], orc.final_mask)
+                assert np.array_equal(info["final_obs"][orc.final_mask], orc.final_obs[orc.final_mask]), t
+        else:
+            assert info == {}
         st, so = env.get_state(), orc.get_state()
         for k in so:
             assert np.array_equal(st[k], so[k]), (k, t)
@@ -858,3 +866,33 @@ def test_crowded_warehouses_resolve_long_chains_in_registers(env_id, p_forward):
     for k in so:
         assert np.array_equal(st[k], so[k]), k
     env.close()
+
+
+def test_rw_multi_enqueues_every_engine_from_one_call():
+    """rw_multi ("a single C call that fans out"): four engines — the shards of a single-process multi-device
+    env — stepped through ONE rw_multi_step_device call per round (launcher thread per engine), against the same four shards
+    stepped one rw_step_device call each: identical state, and the engines stay usable on their own afterwards."""
+    from rware_amd import _capi
+    kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
+    mk = lambda: rware_amd.WarehouseVecEnv(32, library=LIB, devices=[0, 0, 0, 0], max_steps=12, **{k: v for k, v in kw.items() if k != "max_steps"})
+    a, b = mk(), mk()
+    assert len(a.engines) == 4
+    a.reset(seed=5); b.reset(seed=5)
+    multi = _capi.MultiEngine(a.engines)
+    rng = np.random.default_rng(1)
+    bufs = [np.zeros((8, 2), np.int32) for _ in range(4)]     # (the emulation build's "device" memory is host memory)
+    for t in range(30):
+        acts = rng.integers(0, 5, size=(32, 2), dtype=np.int32)
+        for k in range(4):
+            bufs[k][:] = acts[8 * k:8 * k + 8]
+        multi.step_device([x.ctypes.data for x in bufs])
+        for k, eng in enumerate(b.engines):
+            eng.step_device(bufs[k].ctypes.data)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(a.observations(), b.observations()) and sa["steps"].max() <= 12
+    a.engines[2].step_device(bufs[2].ctypes.data)             # still an ordinary engine
+    with pytest.raises(_capi.EngineError):
+        multi.step_device([bufs[0].ctypes.data, 0, bufs[2].ctypes.data, bufs[3].ctypes.data])   # a NULL action pointer
+    multi.close(); a.close(); b.close()

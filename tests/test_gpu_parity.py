@@ -97,11 +97,16 @@ def test_engine_matches_oracle_large_batch(env_id, extra, B, T, geom, mode):
     for t in range(T):
         p = [0.2] * 5 if (t // 50) % 2 == 0 else [0.1, 0.6, 0.1, 0.1, 0.1]
         a = rng.choice(5, size=(B, N), p=p).astype(np.int32)
-        obs, rew, term, trunc, _ = env.step(a)
+        obs, rew, term, trunc, info = env.step(a)
         o2, r2, d2 = orc.step_autoreset(a, mode)
         assert np.array_equal(rew, r2), f"rewards t={t}"
         assert np.array_equal(term, d2.astype(bool)), f"done t={t}"
         assert np.array_equal(obs, o2), f"obs t={t}"
+        if mode == "same_step":   # the pre-reset observation of the terminating step (rware/warehouse.py:929-946): info["final_obs"]
+            assert ("final_obs" in info) == bool(d2.any()), t
+            if d2.any():
+                assert np.array_equal(info["_final_obs"], orc.final_mask)
+                assert np.array_equal(info["final_obs"][orc.final_mask], orc.final_obs[orc.final_mask]), f"final_obs t={t}"
         if t % 25 == 0 or t == T - 1:
             st, so = env.get_state(), orc.get_state()
             for k in so:
@@ -1042,3 +1047,48 @@ def test_runtime_specialisation_policy(tmp_path, monkeypatch):
     for k in so:
         assert np.array_equal(st[k], so[k]), k
     env.close(); off.close()
+
+
+def test_rw_multi_one_call_steps_eight_engines():
+    """rw_multi ("a single C call that fans out"): 8 engines — here all on this box's one GPU, one per device
+    on a node — stepped by ONE C call per round, launcher thread per engine.  Same results as stepping them one call each; and
+    the host pays about one launch per round, not eight: at most 2x a single rw_step_device call (a generous bound on a busy
+    test box: the launches run in parallel on 8 threads)."""
+    import time
+    import torch
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    n, Bs = 8, 1024
+    mk = lambda: rware_amd.WarehouseVecEnv(n * Bs, devices=[0] * n, output="torch", **kw)
+    a, b = mk(), mk()
+    a.reset(seed=9); b.reset(seed=9)
+    acts = torch.randint(0, 5, (64, n, Bs, 4), dtype=torch.int32, device="cuda")
+    rounds = 300
+    for t in range(rounds):
+        a.step([acts[t % 64, k] for k in range(n)])                # -> rw_multi_step_device
+        for k, eng in enumerate(b.engines):
+            eng.step_device(acts[t % 64, k].data_ptr())            # one C call per engine
+    torch.cuda.synchronize()
+    a.sync(); b.sync()
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    # host time per round: the multi call vs ONE single-engine call (pre-built pointer lists: the C calls themselves)
+    ptrs = [[acts[t, k].data_ptr() for k in range(n)] for t in range(64)]
+    multi, e0 = a._multi, b.engines[0]
+    def per_round(fn, reps=2000):
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for t in range(reps):
+                fn(t % 64)
+            best = min(best, (time.perf_counter() - t0) / reps * 1e6)
+            torch.cuda.synchronize()
+        return best
+    us_multi = per_round(lambda t: multi.step_device(ptrs[t]))
+    us_single = per_round(lambda t: e0.step_device(ptrs[t][0]))
+    us_loop = per_round(lambda t: [eng.step_device(p) for eng, p in zip(b.engines, ptrs[t])], reps=500)
+    print(f"host us per round: rw_multi x8 {us_multi:.2f}, one rw_step_device {us_single:.2f}, eight calls in a loop {us_loop:.2f}")
+    assert us_multi < us_loop
+    assert us_multi <= 2.0 * us_single + 2.0, (us_multi, us_single, us_loop)
+    a.close(); b.close()
