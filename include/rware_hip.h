@@ -222,10 +222,11 @@ int rw_step_tape_device_timed(rw_engine *eng, const int32_t *tape_dev, int32_t t
 int rw_step_many_device(rw_engine *eng, const int32_t *actions_dev, int32_t n_steps,
                         float *obs_tape, float *reward_tape, uint8_t *terminated_tape);
 
-/* One call that enqueues a step on SEVERAL engines — the shards of a single-process multi-device env (one engine per GPU): every
- * engine but the first is launched by a thread of its own that rw_multi_create starts (bound to that engine's device, spinning
- * briefly between rounds, asleep otherwise); rw_multi_step_device(actions_dev[k] = engine k's device action array) returns when
- * all launches are enqueued — the host pays about one launch, not n.  Results as for rw_step_device; the engines stay usable
+/* One call that enqueues a step on SEVERAL engines — the shards of a single-process multi-device env (one engine per GPU).  When
+ * every engine sits on a device of its own, every engine but the first is launched by a thread that rw_multi_create starts
+ * (bound to that engine's device, spinning briefly between rounds, asleep otherwise), so the launches are issued side by
+ * side; engines that share a device are looped over by the calling thread (their launches serialise on the device's queue
+ * anyway).  rw_multi_step_device(actions_dev[k] = engine k's device action array) returns when all launches are enqueued.  Results as for rw_step_device; the engines stay usable
  * on their own between rounds (never concurrently with a round).  Destroy the rw_multi before its engines. */
 typedef struct rw_multi rw_multi;
 int rw_multi_create(rw_engine **engines, int32_t n, rw_multi **out);
@@ -242,6 +243,10 @@ int rw_copy_to_host(rw_engine *eng, void *host_dst, const void *dev_src, size_t 
  * far (three small kernels on the engine's stream; a no-op when nothing ran since the last refresh).  For callers that
  * hold a borrowed pointer / a zero-copy tensor of one of them. */
 int rw_refresh_grid(rw_engine *eng);
+/* Move the engine to another stream (a hipStream_t; NULL = the device's default stream): later calls enqueue there.  Work
+ * already enqueued stays where it is — ordering the two streams is the caller's business (events).  An engine-owned stream is
+ * drained and destroyed.  For callers that set up stream capture after the engine exists (WarehouseVecEnv.capture_loop). */
+int rw_set_stream(rw_engine *eng, void *stream);
 /* Tell the engine that steps ran which its host side did not see — a HIP graph holding rw_step_device launches was replayed
  * (replays run without host code) — so that the next rw_read / rw_get_buffer / rw_write of a derived view rebuilds it.  The
  * engine also notices by itself when one of its launches is being captured (hipStreamIsCapturing) and from then on rebuilds

@@ -55,7 +55,7 @@ class RwInfo(C.Structure):
 
 EXPORTS = (
     "rw_create", "rw_destroy", "rw_last_error", "rw_reset", "rw_step", "rw_step_device",
-    "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_mark_views_stale", "rw_jit_log", "rw_jit_probe", "rw_multi_create", "rw_multi_step_device", "rw_multi_destroy", "rw_sync", "rw_get_buffer", "rw_read", "rw_read_outputs", "rw_write",
+    "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_mark_views_stale", "rw_set_stream", "rw_jit_log", "rw_jit_probe", "rw_multi_create", "rw_multi_step_device", "rw_multi_destroy", "rw_sync", "rw_get_buffer", "rw_read", "rw_read_outputs", "rw_write",
     "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
     "rw_abi_version", "rw_debug_timeline", "rw_device_malloc", "rw_device_free", "rw_copy_to_device",
     "rw_copy_to_host", "rw_snapshot_create", "rw_snapshot_save", "rw_snapshot_restore", "rw_snapshot_destroy",
@@ -111,6 +111,7 @@ def load(path: str | None = None):
     lib.rw_refresh_obs.argtypes = [vp]
     lib.rw_refresh_grid.argtypes = [vp]
     lib.rw_mark_views_stale.argtypes = [vp]
+    lib.rw_set_stream.argtypes = [vp, vp]
     lib.rw_jit_log.argtypes = [vp]
     lib.rw_jit_log.restype = C.c_char_p
     lib.rw_jit_probe.argtypes = [C.POINTER(C.c_int32), C.c_char_p, C.c_char_p, C.c_size_t]
@@ -317,6 +318,10 @@ class Engine:
 
     def jit_log(self) -> str:
         return (self.lib.rw_jit_log(self._h) or b"").decode()
+
+    def set_stream(self, stream_handle):
+        """Later launches go to `stream_handle` (a hipStream_t as int; 0 = the default stream)."""
+        self._check(self.lib.rw_set_stream(self._h, C.c_void_p(int(stream_handle or 0))))
 
     def mark_views_stale(self):
         """Steps ran that the host side did not see (a replayed HIP graph): the derived views are rebuilt when next asked for."""

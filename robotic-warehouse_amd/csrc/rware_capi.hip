@@ -974,6 +974,19 @@ int64_t rw_jit_probe(const int32_t shape[15], const char *arch, char *log, size_
 #endif
 }
 
+int rw_set_stream(rw_engine *eng, void *stream) {
+    // everything enqueued so far stays ordered on the old stream; the caller orders the two streams (events) if it has to
+    if (!eng) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    if (eng->own_stream && eng->stream) {
+        RW_HIP(eng, hipStreamSynchronize(eng->stream));
+        RW_HIP(eng, hipStreamDestroy(eng->stream));
+        eng->own_stream = false;
+    }
+    eng->stream = (hipStream_t)stream;
+    return RW_OK;
+}
+
 int rw_mark_views_stale(rw_engine *eng) {
     if (!eng) return RW_ERR_INVALID_ARG;
     eng->grid_stale = eng->agents_stale = true;
@@ -1189,7 +1202,17 @@ int rw_multi_create(rw_engine **engines, int32_t n, rw_multi **out) {
     m->engs.assign(engines, engines + n);
     m->actions.assign((size_t)n, nullptr);
     m->rc.assign((size_t)n, RW_OK);
-    for (int k = 1; k < n; ++k) m->threads.emplace_back(multi_worker, m, k);
+    // Launcher threads only pay when every engine has a device (and therefore a submission queue) of its own; engines that
+    // share a device serialise on its queue anyway and the hand-off costs more than it hides (measured, 8 engines on one
+    // MI355X: 44.6 us per round with threads, 30.9 us for eight Python calls) — those are looped over by the caller's thread.
+    bool distinct = true;
+    for (int a = 0; a < n && distinct; ++a)
+        for (int b = a + 1; b < n; ++b)
+            if (engines[a]->cfg.device_id == engines[b]->cfg.device_id) { distinct = false; break; }
+    const char *force = getenv("RWARE_MULTI_THREADS");  // (1 / 0: force either mode — tests)
+    if (force && (force[0] == '0' || force[0] == '1')) distinct = force[0] == '1';
+    if (distinct)
+        for (int k = 1; k < n; ++k) m->threads.emplace_back(multi_worker, m, k);
     *out = m;
     return RW_OK;
 }
@@ -1197,6 +1220,18 @@ int rw_multi_create(rw_engine **engines, int32_t n, rw_multi **out) {
 int rw_multi_step_device(rw_multi *m, const int32_t *const *actions_dev) {
     if (!m || !actions_dev) return RW_ERR_INVALID_ARG;
     const int n = (int)m->engs.size();
+    if (m->threads.empty()) {  // engines that share devices: one loop, this thread
+        for (int k = 0; k < n; ++k) {
+            rw_engine *e = m->engs[(size_t)k];
+            if (!actions_dev[k]) return fail(e, RW_ERR_INVALID_ARG, "rw_multi_step_device: no action array for engine %d", k);
+            RW_HIP(e, hipSetDevice(e->cfg.device_id));
+            rw::LaunchArgs la = e->la;
+            la.actions = actions_dev[k];
+            const int rc1 = launch(e, la, rw::OP_STEP);
+            if (rc1 != RW_OK) return rc1;
+        }
+        return RW_OK;
+    }
     for (int k = 0; k < n; ++k) m->actions[(size_t)k] = actions_dev[k];
     m->pending.store(n - 1, std::memory_order_release);
     m->round.fetch_add(1, std::memory_order_acq_rel);

@@ -365,7 +365,7 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
 // Which per-step builds ask for the register budget of 8 wavefronts per SIMD (amdgpu_waves_per_eu): 8-env workgroups hold a
 // 16384-env batch in ONE round only if 8 of them fit a CU, i.e. 8 wavefronts per SIMD —
 //   exact builds, 7 / 8 agents   (one of them — 8 agents, 16 queue slots — came out at 66 VGPRs, 7 per CU: 11.7 instead of ~9.6 us)
-//   agent-count-static builds, 9 .. 13 agents   (104 scalar registers otherwise — the run-time queue length and what hangs on
+//   9 .. 13 agents, agent-count-static and (run-time compiled) exact builds alike   (104 scalar registers otherwise — the run-time queue length and what hangs on
 //       it — so 7 per CU; with the budget: 53 .. 63 VGPRs, no scratch.  Round 4, B = 16384: small-10ag 16.0 -> 13.8 us,
 //       small-12ag 18.3 -> 15.8.  From 14 agents on the budget costs spills (8 .. 44 bytes per lane): not asked for.)
 template <typename Cfg, bool kRollout>
@@ -373,7 +373,7 @@ constexpr bool want_occ8() {
     if (kRollout || RW_AB_OCC8 < 0) return false;
     if (RW_AB_OCC8 > 0) return true;
     if (Cfg::kE != 8) return false;
-    return (!Cfg::kQrt && (Cfg::kN == 7 || Cfg::kN == 8)) || (Cfg::kQrt && Cfg::kN >= 9 && Cfg::kN <= 13);
+    return (!Cfg::kQrt && (Cfg::kN == 7 || Cfg::kN == 8)) || (Cfg::kN >= 9 && Cfg::kN <= 13);
 }
 template <int R, typename CellT, typename Cfg, bool kRollout, int kObs = OBS_FLATTENED>
 __global__ void __launch_bounds__(256)

@@ -446,15 +446,25 @@ class WarehouseVecEnv(_VectorEnvBase):
         per round issued eagerly, 32 us replayed from a graph — profiles/r03_learner_probe.txt).  Replaying policy + step
         from a graph removes the host's share of that.  `policy` gets the env's zero-copy output tensors (the same objects every round: they are overwritten in
         place by the step) and returns an integer CUDA tensor of (B, N) actions; it must be capturable (no host syncs, no
-        data-dependent shapes).  The env has to sit on a non-default stream — construct it under `with torch.cuda.stream(s)` —
-        because a HIP graph cannot be captured on the legacy default stream.  `policy` is called `warmup` times eagerly first
-        (outputs discarded, the env does not step) so that lazy library initialisation happens outside the capture.
-        Returns an object with `.replay()` (enqueue the captured rounds once more on the env's stream) and `.graph`."""
+        data-dependent shapes).  A HIP graph cannot be captured on the legacy default stream: an env that was built there
+        (the usual case) is moved to a stream of its own for good (rw_set_stream) — replay() then orders that stream behind the
+        caller's current stream and the caller's next ops behind the replay (two event waits per replay, no host sync), and
+        eager env.step() calls keep working (they enqueue on the env's new stream: order them with `loop.stream` yourself).
+        `policy` is called `warmup` times eagerly first (outputs discarded, the env does not step) so that lazy library
+        initialisation happens outside the capture.
+        Returns an object with `.replay()` (enqueue the captured rounds once more), `.graph` and `.stream`."""
         t = self._torch
         if t is None or len(self.engines) != 1:
             raise ValueError('capture_loop needs output="torch" and a single device')
+        bridge = False
         if not self._stream_handles or not self._stream_handles[0]:
-            raise ValueError("the env enqueues on the default stream: construct it under `with torch.cuda.stream(s)` to capture")
+            own = t.cuda.Stream(device=self.devices[0])
+            own.wait_stream(t.cuda.current_stream(self.devices[0]))     # everything enqueued so far comes first
+            self.engines[0].set_stream(own.cuda_stream)
+            self._stream_handles = [int(own.cuda_stream)]
+            self._own_stream = own                                      # (keeps the stream alive as long as the env)
+            self._fast = None
+            bridge = True
         dev = self.devices[0]
         s = t.cuda.ExternalStream(self._stream_handles[0], device=f"cuda:{dev}")
         v = self._torch_views()
@@ -470,7 +480,7 @@ class WarehouseVecEnv(_VectorEnvBase):
                     a = self._device_actions(policy(obs, v["rewards"], v["terminated_bool"]), self.num_envs, 0)
                     keep.append(a)  # (allocated from the graph's private pool: alive as long as the graph is)
                     self.engines[0].step_device(a.data_ptr())
-        return _CapturedLoop(g, s, keep, int(steps), self.engines[0])
+        return _CapturedLoop(g, s, keep, int(steps), self.engines[0], bridge)
 
     def snapshot(self):
         """Checkpoint the batched state on the device (grid, agents, queue, counters, RNG streams).

@@ -746,7 +746,8 @@ def test_agent_count_static_builds_read_the_queue_length_at_run_time(env_id, ext
     B, N = 32, kw["n_agents"]
     env = rware_amd.WarehouseVecEnv(B, library=LIB, **kw)
     assert env.engines[0].info.specialised == 1
-    assert env.engines[0].info.build_kind == 2 and env.engines[0].info.envs_per_workgroup == (8 if N >= 5 else 16)
+    # (geometry by the measured rules of rware_static_table.h: 16 envs up to 4 agents, 8 from 5 on, 16 again for 14 .. 16 agents)
+    assert env.engines[0].info.build_kind == 2 and env.engines[0].info.envs_per_workgroup == (16 if N <= 4 or (14 <= N <= 16 and "tiny" not in env_id) else 8)
     orc = OracleVecEnv(B, **kw)
     assert np.array_equal(env.reset(seed=14)[0], orc.reset(seed=14))
     rng = np.random.default_rng(16)
@@ -852,7 +853,7 @@ def test_crowded_warehouses_resolve_long_chains_in_registers(env_id, p_forward):
     kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
     B, N = 16, kw["n_agents"]
     env = rware_amd.WarehouseVecEnv(B, library=LIB, **kw)
-    assert env.engines[0].info.build_kind == 2 and env.engines[0].info.envs_per_workgroup == 8
+    assert env.engines[0].info.build_kind == 2 and env.engines[0].info.envs_per_workgroup == 8    # (the tiny warehouse: 8-env builds only)
     orc = OracleVecEnv(B, **kw)
     assert np.array_equal(env.reset(seed=31)[0], orc.reset(seed=31))
     rng = np.random.default_rng(33)
@@ -868,11 +869,13 @@ def test_crowded_warehouses_resolve_long_chains_in_registers(env_id, p_forward):
     env.close()
 
 
-def test_rw_multi_enqueues_every_engine_from_one_call():
+@pytest.mark.parametrize("threads", ["1", "0"])
+def test_rw_multi_enqueues_every_engine_from_one_call(threads, monkeypatch):
     """rw_multi ("a single C call that fans out"): four engines — the shards of a single-process multi-device
     env — stepped through ONE rw_multi_step_device call per round (launcher thread per engine), against the same four shards
     stepped one rw_step_device call each: identical state, and the engines stay usable on their own afterwards."""
     from rware_amd import _capi
+    monkeypatch.setenv("RWARE_MULTI_THREADS", threads)   # both modes: a launcher thread per engine / one loop in the caller's thread
     kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
     mk = lambda: rware_amd.WarehouseVecEnv(32, library=LIB, devices=[0, 0, 0, 0], max_steps=12, **{k: v for k, v in kw.items() if k != "max_steps"})
     a, b = mk(), mk()
