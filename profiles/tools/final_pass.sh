@@ -21,6 +21,20 @@ TL_OBS_TYPE=2 python profiles/tools/timeline_probe.py 2>&1 | grep -v amdgpu.ids 
 python profiles/tools/timeline_probe.py rware-medium-6ag-hard-v1 8192 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_medium6.txt
 TL_SENSOR_RANGE=2 python profiles/tools/timeline_probe.py rware-large-16ag-v1 16384 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_large16_r2.txt
 python profiles/tools/timeline_probe.py rware-small-8ag-v1 16384 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_small8.txt
+python profiles/tools/timeline_probe.py rware-small-10ag-v1 16384 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_small10.txt
+python profiles/tools/timeline_probe.py rware-tiny-2ag-v1 4096 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_timeline_tiny2.txt
+python profiles/tools/grid_table.py 16384 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_grid_table_B16384.txt
+# run-time specialised builds (hipRTC) against the generic kernel on unregistered shapes
+python profiles/tools/measure.py layoutstr-3ag:16384:0:auto::off layoutstr-3ag:16384:0:auto::force small-4ag-colheight5:16384:0:auto::off \
+  small-4ag-colheight5:16384:0:auto::force sr5-12ag-colheight5:8192:0:auto::off sr5-12ag-colheight5:8192:0:auto::force \
+  rware-small-4ag-v1:16384:0:auto:2:off rware-small-4ag-v1:16384:0:auto:2:force rware-small-4ag-v1:16384:0:auto:3:off \
+  rware-small-4ag-v1:16384:0:auto:3:force small-24ag:16384:0:auto::off small-24ag:16384:0:auto::force 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_jit_vs_generic.txt
+# instruction mix and instruction-cache traffic of the headline kernel and two wide ones (separate PMC passes)
+I1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES"
+I2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+I3="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQC_DCACHE_REQ SQC_DCACHE_MISSES"
+for c in "$I1" "$I2" "$I3"; do bash profiles/tools/pmc_pass.sh ${TAG}_headline "$c"; done
+for c in "$I1" "$I2"; do bash profiles/tools/pmc_pass.sh ${TAG}_small10 "$c" --env-id rware-small-10ag-v1; bash profiles/tools/pmc_pass.sh ${TAG}_cfg5 "$c" --env-id rware-large-16ag-v1 --sensor-range 2; done
 python profiles/tools/k20_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_k20_probe.txt
 python profiles/tools/api_rates.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_api_rates.txt
 bash profiles/tools/unprofiled.sh $TAG > gpurun_out/${TAG}_unprofiled.txt

@@ -27,6 +27,8 @@ CONFIGS=(
   "image_tiny2_B4096|256|6000|--env-id rware-tiny-2ag-v1 --batch 4096 --observation-type 2"
   "msg2_small4_B16384|256|6000|--msg-bits 2"
   "small8_B16384|256|6000|--env-id rware-small-8ag-v1"
+  "small10_B16384|256|3000|--env-id rware-small-10ag-v1"
+  "large16_B16384|64|1500|--env-id rware-large-16ag-v1"
   "fused64_small4_B16384|256|1024|--many 64"
 )
 cd /tmp
@@ -54,5 +56,8 @@ for entry in "${CONFIGS[@]}"; do
 done
 cd "$ROOT"
 python profiles/tools/sweep_collect.py "$OUT" "$TAG"
+# the per-config summaries that get committed under profiles/ (before the large databases are dropped)
+for d in "$OUT"/*/; do n=$(basename "$d"); [ "$n" = calib ] && continue; python profiles/tools/summarize_rocpd.py "$d" > "gpurun_out/${TAG}_${n}_kernels.txt" 2>/dev/null; done
+python profiles/tools/summarize_rocpd.py "$OUT/calib" > "gpurun_out/${TAG}_calibration_kernels.txt" 2>/dev/null
 # keep only what is worth carrying back (the databases can be large)
 find "$OUT" -name '*.db' -size +4M -delete

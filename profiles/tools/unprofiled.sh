@@ -17,6 +17,8 @@ run image_small4_B16384 256 --observation-type 2 --steps 6000 --warmup 200
 run image_tiny2_B4096 256 --env-id rware-tiny-2ag-v1 --batch 4096 --observation-type 2 --steps 6000 --warmup 200
 run msg2_small4_B16384 256 --msg-bits 2 --steps 6000 --warmup 200
 run small8_B16384 256 --env-id rware-small-8ag-v1 --steps 6000 --warmup 200
+run small10_B16384 256 --env-id rware-small-10ag-v1 --steps 3000 --warmup 200
+run large16_B16384 64 --env-id rware-large-16ag-v1 --steps 1500 --warmup 100
 RWARE_BENCH_TAPE_STEPS=256 python bench.py --no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-sustained --many 64 --steps 4096 --warmup 64 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d['sweep_config']='fused64_small4_B16384'; print(json.dumps(d))" >> $OUT
 python - <<PY
 import json

@@ -147,9 +147,11 @@ const StaticEntry kEntries[] = {
     //  a multiple of 8 but not of 16, or an explicit geometry)
     RW_STATIC(20, 10, 4, 4, 80, 1, 8, 256, 0),
     RW_STATIC(20, 16, 6, 3, 144, 1, 16, 256, 0),   // rware-medium-6ag-hard
-    // (large-16ag r=2, round 3, same box: E = 8 36.2 us at B = 16384 vs 38.4 with E = 4 and 37.1 with E = 16; B = 4096: 14.6 vs 13.8 with E = 4)
-    RW_STATIC(29, 16, 16, 16, 224, 2, 8, 256, 0),  // rware-large-16ag, sensor_range = 2
-    RW_STATIC(29, 16, 16, 16, 224, 2, 4, 256, 0),  // (batches that are no multiple of 8; explicit geometry)
+    // (large-16ag r=2.  Round 3, same box: E = 8 36.2 us at B = 16384 vs 38.4 with E = 4 and 37.1 with E = 16; B = 4096: 14.6 vs 13.8
+    //  with E = 4.  Round 4, agents in registers, same box: B = 16384 37.27 (E = 8) vs 37.29 (E = 4), both cached; B = 32768, past
+    //  the Infinity Cache, non-temporal: 79.0 vs 75.3 -> 4 envs per workgroup in front)
+    RW_STATIC(29, 16, 16, 16, 224, 2, 4, 256, 0),  // rware-large-16ag, sensor_range = 2
+    RW_STATIC(29, 16, 16, 16, 224, 2, 8, 256, 0),  // (explicit geometry)
 #elif RW_STATIC_GROUP == 1
     // ---- the "next" observation kinds callers hit first: IMAGE / IMAGE_DICT (any layer list, directional
     // or not) and FLATTENED with 1 or 2 communication bits, on the two smallest BASELINE tasks
