@@ -9,7 +9,7 @@
 set -u
 TAG=${1:-rNN}
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee gpurun_out/${TAG}_gpu_suite.txt
+python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -60 > gpurun_out/${TAG}_gpu_suite_full.txt; tail -3 gpurun_out/${TAG}_gpu_suite_full.txt | tee gpurun_out/${TAG}_gpu_suite.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 bash profiles/tools/sweep.sh $TAG 2>&1 | tail -15
 cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json

@@ -61,6 +61,9 @@ struct rw_engine {
     bool specialised = false;
     bool grid_stale = false;   // steps / resets have run since RW_BUF_GRID was last rebuilt (refresh_grid)
     bool agents_stale = false; // ... since RW_BUF_AGENT_X .. _DELIVERED were last unpacked from the records (refresh_agents)
+    bool counters_stale = false; // ... since RW_BUF_STEPS / _INACTIVE / _NEED_RESET were last unpacked from the counter records
+    int32_t *d_cnt = nullptr;  // [B][2] counter records {steps | need_reset << 31, inactive}: what the step kernels read and write
+    size_t cnt_off = 0;
     // run-time specialised build (rware_jit.cpp): the code object's module and its two kernels; launched instead of `kernel` /
     // `kernel_rollout` when present
     hipModule_t jit_module = nullptr;
@@ -127,7 +130,7 @@ namespace {
 
 int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     la.op = op | (la.timeline ? rw::OP_FLAG_TIMELINE : 0);
-    if (op != rw::OP_OBS) eng->grid_stale = eng->agents_stale = true;  // the kernels keep the shadow and the packed agent records current, not the int32 views
+    if (op != rw::OP_OBS) eng->grid_stale = eng->agents_stale = eng->counters_stale = true;  // the kernels keep the shadow and the packed agent records current, not the int32 views
     if (!eng->own_stream && !eng->captured) {  // (a stream of the caller's may be capturing; the engine's own stream never is)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(eng->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) eng->captured = true;
@@ -216,6 +219,27 @@ int pack_agents(rw_engine *eng) {
                        (const int32_t *)eng->buf[RW_BUF_AGENT_DELIVERED].ptr, n, eng->prm.W);
     RW_HIP(eng, hipGetLastError());
     eng->agents_stale = false;
+    return RW_OK;
+}
+
+// RW_BUF_STEPS / RW_BUF_INACTIVE / RW_BUF_NEED_RESET are derived views of the per-env counter records
+bool is_counter_view(int kind) { return kind == RW_BUF_STEPS || kind == RW_BUF_INACTIVE || kind == RW_BUF_NEED_RESET; }
+int refresh_counters(rw_engine *eng) {
+    if (!eng->counters_stale && !eng->captured) return RW_OK;
+    const size_t n = (size_t)eng->prm.B;
+    hipLaunchKernelGGL((rw::rware_unpack_counters_kernel<>), dim3(agent_blocks(n)), dim3(256), 0, eng->stream, (const int32_t *)eng->d_cnt,
+                       (int32_t *)eng->buf[RW_BUF_STEPS].ptr, (int32_t *)eng->buf[RW_BUF_INACTIVE].ptr, (uint8_t *)eng->buf[RW_BUF_NEED_RESET].ptr, n);
+    RW_HIP(eng, hipGetLastError());
+    eng->counters_stale = false;
+    return RW_OK;
+}
+int pack_counters(rw_engine *eng) {
+    const size_t n = (size_t)eng->prm.B;
+    hipLaunchKernelGGL((rw::rware_pack_counters_kernel<>), dim3(agent_blocks(n)), dim3(256), 0, eng->stream, eng->d_cnt,
+                       (const int32_t *)eng->buf[RW_BUF_STEPS].ptr, (const int32_t *)eng->buf[RW_BUF_INACTIVE].ptr,
+                       (const uint8_t *)eng->buf[RW_BUF_NEED_RESET].ptr, n);
+    RW_HIP(eng, hipGetLastError());
+    eng->counters_stale = false;
     return RW_OK;
 }
 
@@ -584,8 +608,10 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         RW_BUF_ACTIONS, RW_BUF_RNG, RW_BUF_FEATURES, RW_BUF_OBS, RW_BUF_FINAL_OBS, RW_BUF_GRID};
     auto up = [](size_t x) { return (x + 4095) & ~(size_t)4095; };
     size_t slab_bytes = 0, off[RW_BUF_KIND_COUNT];
-    eng->rec_off = 0;  // the packed agent records lead the hot set
+    eng->rec_off = 0;  // the packed agent records lead the hot set, the counter records follow
     slab_bytes += up(szB * N * sizeof(uint32_t));
+    eng->cnt_off = slab_bytes;
+    slab_bytes += up(szB * 2 * sizeof(int32_t) + 64);  // (+ the rounding pieces of the stage-in DMA)
     for (int k : order) {
         eng->buf[k].bytes = n_elems[k] * elem_size(k);
         off[k] = slab_bytes;
@@ -600,6 +626,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     for (int k = 0; k < RW_BUF_KIND_COUNT; ++k) eng->buf[k].ptr = (char *)eng->slab + off[k];
     eng->d_shadow = (char *)eng->slab + eng->shadow_off;
     eng->d_rec = (uint32_t *)((char *)eng->slab + eng->rec_off);
+    eng->d_cnt = (int32_t *)((char *)eng->slab + eng->cnt_off);
     const int HWW = (HW + 31) / 32;
     // the static kernels stage the bitmap in whole 16-byte pieces: allocate (and zero) the rounded-up size
     const size_t hw_bytes = sizeof(uint32_t) * (size_t)rw::rw_up4(HWW);
@@ -651,6 +678,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.acarry = (int32_t *)eng->buf[RW_BUF_AGENT_CARRY].ptr;
     p.adeliv = (int32_t *)eng->buf[RW_BUF_AGENT_DELIVERED].ptr;
     p.queue = (int32_t *)eng->buf[RW_BUF_QUEUE].ptr;
+    p.counters = eng->d_cnt;
     p.steps = (int32_t *)eng->buf[RW_BUF_STEPS].ptr;
     p.inactive = (int32_t *)eng->buf[RW_BUF_INACTIVE].ptr;
     p.shelf_shadow = eng->d_shadow;
@@ -871,9 +899,10 @@ struct rw_snapshot {
 namespace {
 // the state that reset()/step() evolve: (device pointer, size) pieces in a fixed order
 std::vector<std::pair<void *, size_t>> state_pieces(rw_engine *eng) {
-    static const int kinds[] = {RW_BUF_QUEUE, RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_RNG, RW_BUF_NEED_RESET, RW_BUF_AGENT_MSG};
+    static const int kinds[] = {RW_BUF_QUEUE, RW_BUF_RNG, RW_BUF_AGENT_MSG};
     std::vector<std::pair<void *, size_t>> v;
     v.emplace_back(eng->d_rec, (size_t)eng->prm.B * eng->prm.N * sizeof(uint32_t));  // the agents: their packed records
+    v.emplace_back(eng->d_cnt, (size_t)eng->prm.B * 2 * sizeof(int32_t));            // steps, inactive, pending resets: the counter records
     for (int k : kinds) v.emplace_back(eng->buf[k].ptr, eng->buf[k].bytes);
     v.emplace_back(eng->d_shadow, (size_t)eng->prm.B * eng->prm.HW * (eng->wide ? 2 : 1));
     return v;
@@ -915,7 +944,7 @@ int rw_snapshot_restore(rw_engine *eng, const rw_snapshot *snap) {
         if (pc.second) RW_HIP(eng, hipMemcpyAsync(pc.first, (const char *)snap->mem + off, pc.second, hipMemcpyDeviceToDevice, eng->stream));
         off += (pc.second + 255) & ~(size_t)255;
     }
-    eng->grid_stale = eng->agents_stale = true;  // (the int32 views are not part of a snapshot: they are derived from what is)
+    eng->grid_stale = eng->agents_stale = eng->counters_stale = true;  // (the views are not part of a snapshot: they are derived from what is)
     return launch(eng, eng->la, rw::OP_OBS);
 }
 
@@ -996,15 +1025,16 @@ int rw_mark_views_stale(rw_engine *eng) {
 int rw_refresh_grid(rw_engine *eng) {
     if (!eng) return RW_ERR_INVALID_ARG;
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
-    const int rc = refresh_agents(eng);  // (all derived views: the five agent arrays as well)
+    int rc = refresh_agents(eng);  // (all derived views: the five agent arrays and the counter views as well)
+    if (rc == RW_OK) rc = refresh_counters(eng);
     return rc != RW_OK ? rc : refresh_grid(eng);
 }
 
 int rw_get_buffer(rw_engine *eng, int kind, void **dev_ptr, size_t *bytes) {
     if (!eng || kind < 0 || kind >= RW_BUF_KIND_COUNT) return RW_ERR_INVALID_ARG;
-    if (kind == RW_BUF_GRID || is_agent_view(kind)) {
+    if (kind == RW_BUF_GRID || is_agent_view(kind) || is_counter_view(kind)) {
         RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
-        const int rc = kind == RW_BUF_GRID ? refresh_grid(eng) : refresh_agents(eng);
+        const int rc = kind == RW_BUF_GRID ? refresh_grid(eng) : is_agent_view(kind) ? refresh_agents(eng) : refresh_counters(eng);
         if (rc != RW_OK) return rc;
     }
     if (dev_ptr) *dev_ptr = eng->buf[kind].ptr;
@@ -1017,8 +1047,8 @@ int rw_read(rw_engine *eng, int kind, void *host_dst, size_t bytes) {
     if (bytes != eng->buf[kind].bytes)
         return fail(eng, RW_ERR_INVALID_ARG, "rw_read kind %d: %zu bytes given, buffer holds %zu", kind, bytes, eng->buf[kind].bytes);
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
-    if (kind == RW_BUF_GRID || is_agent_view(kind)) {
-        const int rc = kind == RW_BUF_GRID ? refresh_grid(eng) : refresh_agents(eng);
+    if (kind == RW_BUF_GRID || is_agent_view(kind) || is_counter_view(kind)) {
+        const int rc = kind == RW_BUF_GRID ? refresh_grid(eng) : is_agent_view(kind) ? refresh_agents(eng) : refresh_counters(eng);
         if (rc != RW_OK) return rc;
     }
     if (bytes) RW_HIP(eng, hipMemcpyAsync(host_dst, eng->buf[kind].ptr, bytes, hipMemcpyDeviceToHost, eng->stream));
@@ -1049,13 +1079,13 @@ int rw_write(rw_engine *eng, int kind, const void *host_src, size_t bytes) {
     if (kind == RW_BUF_TRUNCATED)
         return fail(eng, RW_ERR_INVALID_ARG, "rw_write: RW_BUF_TRUNCATED is read-only (the reference never truncates, rware/warehouse.py:942)");
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
-    if (is_agent_view(kind)) {  // the other four views have to be current before the five are packed again
-        const int rc = refresh_agents(eng);
+    if (is_agent_view(kind) || is_counter_view(kind)) {  // the sibling views have to be current before they are all packed again
+        const int rc = is_agent_view(kind) ? refresh_agents(eng) : refresh_counters(eng);
         if (rc != RW_OK) return rc;
     }
     if (bytes) RW_HIP(eng, hipMemcpyAsync(eng->buf[kind].ptr, host_src, bytes, hipMemcpyHostToDevice, eng->stream));
-    if (is_agent_view(kind)) {
-        const int rc = pack_agents(eng);
+    if (is_agent_view(kind) || is_counter_view(kind)) {
+        const int rc = is_agent_view(kind) ? pack_agents(eng) : pack_counters(eng);
         if (rc != RW_OK) return rc;
     }
     if (kind == RW_BUF_GRID) {
@@ -1114,12 +1144,12 @@ int rw_get_info(const rw_engine *eng, rw_info *out) {
     out->algorithmic_bytes_per_env_step =
         8LL * p.HW + 4LL * p.N + 40LL * p.N + 4LL * p.Q + 16 + 4LL * p.N * eng->L + 4LL * p.N + 4;
     // What THIS layout has to move per env-step: the shelf shadow (read), the packed agent records (read +
-    // write), the actions, the request queue (read; written only on a delivery), steps + inactive (read + write) and the
-    // pending-reset flag (read), the observation, the rewards, `terminated`; with communication bits the stored messages
+    // write), the actions, the request queue (read; written only on a delivery), the counter record — steps, inactive, the
+    // pending-reset bit: 8 bytes (read + write) —, the observation, the rewards, `terminated`; with communication bits the stored messages
     // (read + write); IMAGE_DICT: the feature vectors.  The physical (PMC) traffic of a step is checked against this figure
     // (profiles/tools/sweep_collect.py), and bench.py's `frac_engine` is priced on it: a fraction of a bandwidth, never above 1.
     out->engine_bytes_per_env_step =
-        (int64_t)p.HW * (eng->wide ? 2 : 1) + 8LL * p.N + 4LL * p.N * (1 + eng->msg_bits) + 4LL * p.Q + 17 + 4LL * p.N * eng->L +
+        (int64_t)p.HW * (eng->wide ? 2 : 1) + 8LL * p.N + 4LL * p.N * (1 + eng->msg_bits) + 4LL * p.Q + 16 + 4LL * p.N * eng->L +
         4LL * p.N + 1 + (eng->msg_bits ? 8LL * p.N : 0) + (p.features ? 24LL * p.N : 0);
     snprintf(out->device_name, sizeof out->device_name, "%s", eng->prop.name);
     snprintf(out->arch_name, sizeof out->arch_name, "%s", eng->prop.gcnArchName);

@@ -99,7 +99,11 @@ struct Params {
     uint32_t *arec;                // [B][N] packed agent records (rec_pack below): the agents' state as the kernels keep it
     int32_t *queue;
     const uint32_t *highway_bits;  // [HWW] bit c == highways[c]                  (static per config)
-    int32_t *steps, *inactive;
+    int32_t *counters;             // [B][2] the per-env counter record the kernels keep: {steps | need_reset << 31, inactive} — ONE
+                                   // 8-byte load and ONE 8-byte store per env-step (a whole 128-byte line per 16-env workgroup)
+                                   // where three arrays were read and two or three written; RW_BUF_STEPS / _INACTIVE / _NEED_RESET
+                                   // are derived views (rware_unpack_counters_kernel), like the agent arrays
+    int32_t *steps, *inactive;     // the exported views (host paths only)
     uint8_t *need_reset;           // [B]
     uint64_t *rng;                 // [6][B]
     // config
@@ -174,8 +178,8 @@ enum : int { TL_START = 0, TL_ZEROED, TL_DMA_ISSUED, TL_ENV_LOADED, TL_LOADED, T
 struct LdsLayout {
     // DMA destinations, contiguous in exactly this order (the static builds fill them with ONE linear
     // LDS-DMA stream): shelf layer, agent arrays (the packed records land in `ax` and are unpacked in place; in the
-    // kDirect builds the agent lanes publish them), actions, queue, highway bitmap, per-env counters/flags
-    int gs, ax, ay, dir, carry, deliv, act, queue, hw, dsteps, dinact, dflag, dma_end;
+    // kDirect builds the agent lanes publish them), actions, queue, highway bitmap, per-env counter records, reset mask
+    int gs, ax, ay, dir, carry, deliv, act, queue, hw, dcnt, dflag, dma_end;
     int ga, zero_end;  // cleared every launch
     int tgt, nxt, depth, win, rew, mv, msg, fx, fy, req, obits, envi, misc, total;
 };
@@ -201,9 +205,8 @@ RW_HD LdsLayout make_lds_layout(int E, int N, int Q, int HW, int SW, int OW, int
     l.act = o;    o += rw_up4(E * N * act_words);  // [Action, message bits...] per agent
     l.queue = o;  o += rw_up4(E * Q);
     l.hw = o;     o += rw_up4((HW + 31) / 32);
-    l.dsteps = o; o += rw_up4(E);
-    l.dinact = o; o += rw_up4(E);
-    l.dflag = o;  o += rw_up4((E + 3) / 4);                    // bytes
+    l.dcnt = o;   o += rw_up4(2 * E);                          // counter records {steps | need_reset << 31, inactive}
+    l.dflag = o;  o += rw_up4((E + 3) / 4);                    // bytes: the reset mask (OP_RESET only)
     l.dma_end = o;
     l.ga = o;     o += rw_up4((E * HW + 3) / 4);               // agent layer, 1 byte per cell: id | 0x80 if loaded
     l.zero_end = o;
@@ -329,6 +332,22 @@ __global__ void rware_pack_agents_kernel(uint32_t *rec, const int32_t *ax, const
         rec[i] = rec_pack((ay[i] * W + ax[i]) & 0x3fff, adir[i] & 3, adeliv[i], acarry[i] & 0x3fff);
 }
 
+// exported counter views <-> records (host paths: rw_read / rw_get_buffer of RW_BUF_STEPS / _INACTIVE / _NEED_RESET; after rw_write)
+template <typename Dummy = void>
+__global__ void rware_unpack_counters_kernel(const int32_t *cnt, int32_t *steps, int32_t *inactive, uint8_t *need_reset, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int32_t x = cnt[2 * i];
+        steps[i] = x & 0x7fffffff; inactive[i] = cnt[2 * i + 1]; need_reset[i] = (uint8_t)((uint32_t)x >> 31);
+    }
+}
+template <typename Dummy = void>
+__global__ void rware_pack_counters_kernel(int32_t *cnt, const int32_t *steps, const int32_t *inactive, const uint8_t *need_reset, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        cnt[2 * i] = (steps[i] & 0x7fffffff) | (need_reset[i] ? (int32_t)0x80000000 : 0);
+        cnt[2 * i + 1] = inactive[i];
+    }
+}
+
 // Rebuilds the exported int32 grid [B][2][H][W] (rware/warehouse.py:749-755, _recalc_grid) from the state the kernels keep:
 // layer 1 = the shelf shadow, layer 0 = agent ids at the agent coordinates.  Two launches: cells, then agents.
 template <typename CellT>
@@ -422,13 +441,18 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     // (as_global: these pointers were loaded from memory — hipcc would address them with flat_* instructions, see rware_cdna4.h)
     RW_GLOBAL CellT *const g_shadow = as_global(reinterpret_cast<CellT *>(p.shelf_shadow));
     RW_GLOBAL uint32_t *const q_rec = as_global(p.arec);
-    RW_GLOBAL int32_t *const q_queue = as_global(p.queue), *const q_steps = as_global(p.steps), *const q_inact = as_global(p.inactive);
+    RW_GLOBAL int32_t *const q_queue = as_global(p.queue);
+    // (the record as one 64-bit word — low half steps | pending-reset bit, high half inactive: scalar types load and store
+    //  through address-space pointers, class types like int2 do not)
+    RW_GLOBAL uint64_t *const q_cnt = as_global(reinterpret_cast<uint64_t *>(p.counters));
+    struct Cnt { int x, y; };
+    auto cnt_load = [&](int ge_) -> Cnt { const uint64_t v = q_cnt[ge_]; return Cnt{(int)(uint32_t)v, (int)(uint32_t)(v >> 32)}; };
+    auto cnt_store = [&](int ge_, int x, int y) { q_cnt[ge_] = (uint64_t)(uint32_t)x | ((uint64_t)(uint32_t)y << 32); };
     const RW_GLOBAL uint32_t *const q_hw = as_global(p.highway_bits);
-    RW_GLOBAL uint8_t *const q_need = as_global(p.need_reset);
     const int k_reward_type = p.reward_type, k_max_inactivity = p.max_inactivity, k_max_steps = p.max_steps;
     const int k_autoreset = p.autoreset, k_n_goals = p.n_goals, k_normalised = p.normalised, k_nt = p.nt_obs;
     const int k_goal0 = p.goal_cells[0], k_goal1 = p.goal_cells[1];
-    keep_sgpr_ptr(g_shadow, q_rec, q_queue, q_steps, q_inact, q_hw, q_need);
+    keep_sgpr_ptr(g_shadow, q_rec, q_queue, q_cnt, q_hw);
     keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised, k_nt);
     if constexpr (Cfg::kQrt) keep_sgpr(Q);  // (the stage-in of the queue needs it)
     // IMAGE kernels: the layer list and its switches belong to the same batch — the image gather used to fetch them where
@@ -516,12 +540,17 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     // first thing in the kernel: the loads fly beside the clear and the stage-in DMA, are complete at the barrier that
     // drains the DMA, and the agent phases start without an LDS read.  The LDS copies the later phases read (window
     // gather, write-back) are written by the agent lanes together with their results.
-    const RW_GLOBAL uint8_t *flag_src = (op == OP_RESET) ? as_global(la.reset_mask) : q_need;  // OP_RESET: all-ones when no mask was given
+    // which envs reset in this launch: OP_RESET — the caller's mask (all-ones when none was given); OP_STEP — the pending-reset
+    // bit of the counter record (NEXT_STEP autoreset); OP_OBS — none
+    const RW_GLOBAL uint8_t *const q_mask = as_global(la.reset_mask);
+    auto flag_of = [&](int cnt_x, int mask_byte) -> int { return op == OP_OBS ? 0 : op == OP_RESET ? mask_byte : (int)((uint32_t)cnt_x >> 31); };
     int r_x = 0, r_y = 0, r_d = 0, r_carry = 0, r_deliv = 0, r_act = ACT_NOOP, r_flag = 0, r_steps = 0, r_inact = 0;
+    int r_cx = 0, r_mask = 0;  // (the counter record's first word and the reset-mask byte as loaded: decoded in unpack_own)
     uint32_t r_rec = 0;
     auto unpack_own = [&]() {  // (W is a compile-time constant in the builds that use this)
         r_y = rec_cell(r_rec) / W; r_x = rec_cell(r_rec) - r_y * W;
         r_d = rec_dir(r_rec); r_carry = rec_carry(r_rec); r_deliv = rec_deliv(r_rec);
+        r_flag = flag_of(r_cx, r_mask); r_steps = r_cx & 0x7fffffff;
     };
     constexpr int KMW = (kMsg && Cfg::kM) ? Cfg::kM : 1;
     int r_mw[KMW] = {};   // the action's message words (_MSG builds), r_msg: the agent's stored message
@@ -542,9 +571,10 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
 #pragma unroll
                     for (int k = 0; k < KMW; ++k) r_mw[k] = la.actions[gi * AM + 1 + k];
             }
-            r_flag = (op == OP_OBS) ? 0 : (int)flag_src[ge];
-            r_steps = q_steps[ge];
-            r_inact = q_inact[ge];
+            const Cnt c = cnt_load(ge);  // ONE 8-byte load: steps, pending-reset bit, inactive — decoded where the record is
+            r_cx = c.x;                  // (unpack_own), so that nothing up here waits for it
+            r_inact = c.y;
+            if (op == OP_RESET) r_mask = (int)q_mask[ge];
         }
     }
     // P1 of the agent phases as two pieces, so that the exact-shape per-step kernels can run them BEFORE the stage-in barrier
@@ -606,10 +636,10 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             as_bytes(q_rec + (size_t)e0 * N), nullptr, nullptr, nullptr, nullptr,
             op == OP_STEP ? as_bytes(as_global(la.actions) + (size_t)e0 * N * AM) : as_bytes(q_rec + (size_t)e0 * N),
             as_bytes(q_queue + (size_t)e0 * Q), as_bytes(q_hw),
-            as_bytes(q_steps + e0), as_bytes(q_inact + e0),
-            as_bytes(flag_src + e0)};
+            as_bytes(q_cnt + e0), nullptr,   // (entry 10: the old second counter array — the record is one stream)
+            as_bytes(q_mask + e0)};
         const int seg[13] = {lo.gs, lo.ax, lo.ay, lo.dir, lo.carry, lo.deliv, lo.act, lo.queue, lo.hw,
-                             lo.dsteps, lo.dinact, lo.dflag, lo.dma_end};  // dword offsets, all multiples of 4
+                             lo.dcnt, lo.dflag, lo.dflag, lo.dma_end};  // dword offsets, all multiples of 4 (entry 10 is empty)
         if constexpr (Cfg::kN != 0) {
             // One DMA instruction moves up to 64 pieces of ONE segment (LDS base + lane * 16), so the source
             // pick is scalar; the (compile-time) list of such instructions is dealt round-robin to the waves.
@@ -617,14 +647,17 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             // (kEarly: dealt to wavefronts 1.. only — wavefront 0 must not have a DMA of its own to wait for)
             const int wave_s = uniform(wave) - (kEarly ? 1 : 0), dma_w = nw - (kEarly ? 1 : 0);
             int job = 0;
-            for (int k = 0; k < 12; ++k) {  // (fully unrolled when the shapes are compile-time constants)
-                if (k >= 2 && k <= 5) continue;  // (filled by unpack_records, not by DMA)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {  // (fully unrolled: the shapes are compile-time constants — keep every `continue` a compile-time one)
+                if ((k >= 2 && k <= 5) || k == 10) continue;  // (filled by unpack_records, not by DMA; no source)
                 if (kDirect && ((k >= 1 && k <= 6) || k >= 9)) continue;  // agent records, actions, counters, flags: in registers
                 const int pieces = (seg[k + 1] - seg[k]) >> 2;
                 // (run-time queue length: the slot holds 2 N entries per env, the chunk in HBM is [E][Q] — contiguous, E * Q / 4 pieces)
                 const int have = (Cfg::kQrt && k == 7) ? (E * Q) >> 2 : pieces;
+                const bool wanted = k != 11 || op == OP_RESET;  // (scalar: the reset mask only matters to OP_RESET)
+#pragma unroll
                 for (int c = 0; c < pieces; c += 64, ++job)
-                    if (job % dma_w == wave_s && c + lane < have)
+                    if (job % dma_w == wave_s && c + lane < have && wanted)
                         lds_dma_b128(src[k] + (size_t)(c + lane) * 16, smem + seg[k] + 4 * c);
             }
             if constexpr (kMsg && !kDirect) {  // the agents' stored messages: a 13th array, outside the contiguous block
@@ -653,12 +686,13 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
 #pragma unroll
                 for (int k = 1; k < 12; ++k)
                     if (t >= ((seg[k] - seg[0]) >> 2)) g = src[k] + (size_t)(t - ((seg[k] - seg[0]) >> 2)) * 16;
-                const bool no_src = t >= ((seg[2] - seg[0]) >> 2) && t < ((seg[6] - seg[0]) >> 2);  // ay .. deliv slots: unpack_records
+                const bool no_src = (t >= ((seg[2] - seg[0]) >> 2) && t < ((seg[6] - seg[0]) >> 2)) ||   // ay .. deliv slots: unpack_records
+                                    (t >= ((seg[11] - seg[0]) >> 2) && op != OP_RESET);                  // the reset mask: OP_RESET only
                 if (t < pieces && !no_src) lds_dma_b128(g, smem + lo.gs + 4 * b);
             }
         }
-        // (rounding pieces at the tail of hw / dflag read a few bytes past the logical end of their source:
-        //  the bitmap is allocated rounded up to 16 bytes, the flags sit in the padded slab / the +64 mask buffer)
+        // (rounding pieces at the tail of hw / dcnt / dflag read a few bytes past the logical end of their source:
+        //  the bitmap is allocated rounded up to 16 bytes, the records sit in the padded slab, the mask buffer has +64 bytes)
         RW_MARK(TL_DMA_ISSUED);
         RW_MARK(TL_ENV_LOADED);
         if constexpr (kDmaFirst) lds_wait();  // (the blind clear: hipcc does not count those stores)
@@ -667,9 +701,10 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             const uint8_t *s_dflag = reinterpret_cast<const uint8_t *>(smem + lo.dflag);
             for (int e = tid; e < ne; e += T) {
                 int32_t *ev = s_envi + e * ENVI_W;
-                const int rs = (op == OP_OBS) ? 0 : (int)s_dflag[e];
-                ev[ENVI_STEPS] = smem[lo.dsteps + e];
-                ev[ENVI_INACTIVE] = smem[lo.dinact + e];
+                const int cx = smem[lo.dcnt + 2 * e];
+                const int rs = flag_of(cx, op == OP_RESET ? (int)s_dflag[e] : 0);
+                ev[ENVI_STEPS] = cx & 0x7fffffff;
+                ev[ENVI_INACTIVE] = smem[lo.dcnt + 2 * e + 1];
                 ev[ENVI_RESET] = rs;
                 ev[ENVI_SKIP] = rs;
                 ev[ENVI_DONE] = 0; ev[ENVI_QDIRTY] = 0;
@@ -689,9 +724,10 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         lds_barrier();  // orders the s_misc clear above before the flag writes below
         for (int e = tid; e < ne; e += T) {
             int32_t *ev = s_envi + e * ENVI_W;
-            const int rs = (op == OP_OBS) ? 0 : (int)flag_src[e0 + e];
-            ev[ENVI_STEPS] = q_steps[e0 + e];
-            ev[ENVI_INACTIVE] = q_inact[e0 + e];
+            const Cnt c = cnt_load(e0 + e);
+            const int rs = flag_of(c.x, op == OP_RESET ? (int)q_mask[e0 + e] : 0);
+            ev[ENVI_STEPS] = c.x & 0x7fffffff;
+            ev[ENVI_INACTIVE] = c.y;
             ev[ENVI_RESET] = rs;
             ev[ENVI_SKIP] = rs;  // an env that resets in this call does not step
             ev[ENVI_DONE] = 0; ev[ENVI_QDIRTY] = 0;
@@ -1314,11 +1350,9 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             const int32_t *ev = s_envi + e * ENVI_W;
             if (!ev[ENVI_RESET]) continue;
             for (int k = 0; k < Q; ++k) q_queue[(size_t)(e0 + e) * Q + k] = s_queue[e * Q + k];
-            q_steps[e0 + e] = 0;
-            q_inact[e0 + e] = 0;
+            cnt_store(e0 + e, 0, 0);  // steps 0, nothing pending, inactive 0
             term_t[e0 + e] = (uint8_t)ev[ENVI_DONE];
             as_global(p.truncated)[e0 + e] = 0;
-            q_need[e0 + e] = 0;
         }
         // fused rollout: a later step's write-back (another wavefront) may store need_reset = 1 for the same env — this
         // path's stores are made visible first (vmcnt drained before the barrier; the path is rare, the wait is free)
@@ -1346,16 +1380,14 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                     const int32_t *ev = s_envi + e * ENVI_W;
                     if (ev[ENVI_RESET]) continue;
                     const int ge = e0 + e;
-                    q_steps[ge] = ev[ENVI_STEPS];
-                    q_inact[ge] = ev[ENVI_INACTIVE];
+                    // (fused rollout: only the launch's last step stores the pending-reset bit — the reset at the top of the
+                    //  following step consumes it from LDS)
+                    const int pend = (ev[ENVI_DONE] && k_autoreset == AR_NEXT_STEP && (!kRollout || t + 1 == n_steps)) ? (int)0x80000000 : 0;
+                    cnt_store(ge, ev[ENVI_STEPS] | pend, ev[ENVI_INACTIVE]);  // ONE 8-byte store: the env's counter record
                     term_t[ge] = (uint8_t)ev[ENVI_DONE];
                     // Only what changed: RW_BUF_TRUNCATED is zero for the engine's lifetime (the reference never truncates,
-                    // :942); need_reset was 0 (the env stepped) and becomes 1 only on termination; the queue changes only
-                    // on a delivery.  Every store stream a step does not issue is ~0.1 us of it (DESIGN.md ablations).
-                    // (fused rollout: only the launch's last step stores the flag — the reset at the top of the following
-                    //  step consumes it from LDS, and a store of 1 here would race the RS store of 0 there, which comes from
-                    //  another wavefront)
-                    if (ev[ENVI_DONE] && k_autoreset == AR_NEXT_STEP && (!kRollout || t + 1 == n_steps)) q_need[ge] = 1;
+                    // :942); the queue changes only on a delivery.  Every store stream a step does not issue is ~0.1 us of it
+                    // (DESIGN.md ablations).
                     if (ev[ENVI_QDIRTY])
                         for (int k = 0; k < Q; ++k) q_queue[(size_t)ge * Q + k] = s_queue[e * Q + k];
                 }

@@ -34,6 +34,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(8) int2 { int x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;

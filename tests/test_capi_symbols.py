@@ -130,6 +130,11 @@ def test_kernel_isa_has_no_operand_order_sensitive_dpp_folds(tmp_path):
         assert pcg and spills and all(min(abs(i - j) for j in pcg) < 400 for i in spills), \
             f"{lines[a][:120]}: scratch traffic outside the rare RNG path"
     assert n_scratch_kernels <= 8, n_scratch_kernels
+    # third audit: no register array indexed at run time (s_set_gpr_idx_on / v_movrel*) — that is what a table-driven loop turns
+    # into when it stops being fully unrolled (round 4: one run-time `continue` in the stage-in's DMA job loop made the
+    # headline step 6.1 -> 9.0 us; the compiler said nothing)
+    dyn = re.findall(r"^\s*(s_set_gpr_idx_on|v_movrel[sd]*_b32)\b", out.read_text(), flags=re.M)
+    assert not dyn, f"{len(dyn)} run-time-indexed register accesses in the exact-shape kernels"
 
 
 def test_runtime_specialisation_compiles_without_a_device(tmp_path, monkeypatch):
