@@ -114,14 +114,23 @@ class _Space:
 class _CapturedLoop:
     """What WarehouseVecEnv.capture_loop returns: `steps` (policy, step) rounds in one HIP graph."""
 
-    def __init__(self, graph, stream, keep, steps, engine=None):
-        self.graph, self.stream, self._keep, self.steps, self._engine = graph, stream, keep, steps, engine
+    def __init__(self, graph, stream, keep, steps, engine=None, bridge=False):
+        self.graph, self.stream, self._keep, self.steps, self._engine, self._bridge = graph, stream, keep, steps, engine, bridge
 
     def replay(self):
         import torch
 
-        with torch.cuda.stream(self.stream):
-            self.graph.replay()
+        if self._bridge:
+            # the env was built on the default stream and moved to a capture stream of its own: order the replay behind what the
+            # caller enqueued so far (a learner still reading the last observations) and the caller's next ops behind the replay
+            cur = torch.cuda.current_stream(self.stream.device)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                self.graph.replay()
+            cur.wait_stream(self.stream)
+        else:
+            with torch.cuda.stream(self.stream):
+                self.graph.replay()
         if self._engine is not None:  # the replayed steps ran without host code: get_state() / set_state() must not trust
             self._engine.mark_views_stale()  # the engine's "views are current" flags (grid, agent_* arrays)
 
