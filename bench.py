@@ -512,6 +512,11 @@ def main():
                 # `traffic` / `frac_physical`: PMC bytes of a recorded rocprofv3 pass (profiles/pmc_traffic.json), beside it.
                 "bound": "hbm", "achieved": achieved, "achieved_algorithmic": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
+                "note": "achieved / frac are priced on SURVEY.md §8(d)'s ALGORITHMIC bytes (the contract's figure: two int32 grid layers "
+                        "and five int32 agent fields per env), which this engine does not move — it reads a 1-byte shelf layer and one "
+                        "dword per agent — so they are a work rate in A's unit and may exceed the peak; the bandwidth figures are "
+                        "achieved_engine / frac_engine (bytes the layout must move, measured by this run, <= 1 by construction) and "
+                        "traffic / frac_physical (rocprofv3 PMC bytes of the same kernel sources)",
                 "engine_bytes_per_launch": e_launch, "achieved_engine": achieved_engine, "frac_engine": achieved_engine / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_over_engine_bytes": (traffic / e_launch) if traffic else None,
                 "peak_measured": HBM_MEASURED_GBPS, "frac_of_measured_peak": achieved / HBM_MEASURED_GBPS,
