@@ -36,6 +36,11 @@ __device__ __forceinline__ void lds_zero_b128_blind(void *lds_ptr) {
     const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_ptr;
     asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(z));
 }
+// dma_wait(): every LDS-DMA (and every other vector-memory load) this wavefront has issued is complete.  The stage-in barrier
+// used to rely on __syncthreads() for this; hipRTC's runtime header defines __syncthreads() with a fence that does NOT make the
+// compiler wait for vmcnt there, so a run-time compiled build left the DMA in flight across the barrier (round 4: wrong
+// `requested` bits under load — the queue segment is the last DMA issued).  The wait is explicit now, whatever the header says.
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -133,6 +138,12 @@ __device__ __forceinline__ int env_or(int v, int lane_base) {
         for (int k = 0; k < N; ++k) r |= g[k];
         return r;
     }
+}
+// env_any<N>(v, lane_base): true in every lane of an env iff v holds in one of its N lanes (one ballot, one 64-bit shift)
+template <int N>
+__device__ __forceinline__ bool env_any(bool v, int lane_base) {
+    const uint64_t b = __builtin_amdgcn_ballot_w64(v);
+    return ((b >> lane_base) & ((1ull << N) - 1ull)) != 0ull;
 }
 __device__ __forceinline__ void wave_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

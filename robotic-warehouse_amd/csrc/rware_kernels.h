@@ -384,20 +384,23 @@ __global__ void rware_shadow_kernel(const int32_t *grid, CellT *shadow, int B, i
 // Which per-step builds ask for the register budget of 8 wavefronts per SIMD (amdgpu_waves_per_eu): 8-env workgroups hold a
 // 16384-env batch in ONE round only if 8 of them fit a CU, i.e. 8 wavefronts per SIMD —
 //   exact builds, 7 / 8 agents   (one of them — 8 agents, 16 queue slots — came out at 66 VGPRs, 7 per CU: 11.7 instead of ~9.6 us)
-//   9 .. 13 agents, agent-count-static and (run-time compiled) exact builds alike   (104 scalar registers otherwise — the run-time queue length and what hangs on
-//       it — so 7 per CU; with the budget: 53 .. 63 VGPRs, no scratch.  Round 4, B = 16384: small-10ag 16.0 -> 13.8 us,
-//       small-12ag 18.3 -> 15.8.  From 14 agents on the budget costs spills (8 .. 44 bytes per lane): not asked for.)
-template <typename Cfg, bool kRollout>
+//   9 .. 19 agents, agent-count-static and (run-time compiled) exact builds alike   (104 scalar registers otherwise — the
+//       run-time queue length and what hangs on it — so 7 per CU; with the budget: 54 .. 62 VGPRs, no scratch.  Round 4,
+//       B = 16384: small-10ag 16.0 -> 13.8 us, small-12ag 18.3 -> 15.8.  With the all-gather agent phases the budget cost spills
+//       from 14 agents on — 8 .. 44 bytes per lane; the per-cell exchange, kCell, needs no register arrays of N entries.)
+template <int R, typename Cfg, bool kRollout>
 constexpr bool want_occ8() {
     if (kRollout || RW_AB_OCC8 < 0) return false;
     if (RW_AB_OCC8 > 0) return true;
     if (Cfg::kE != 8) return false;
-    return (!Cfg::kQrt && (Cfg::kN == 7 || Cfg::kN == 8)) || (Cfg::kN >= 9 && Cfg::kN <= 13);
+    // (sensor_range >= 2: the window gather and the expansion hold more rows in registers — the budget would spill on the
+    //  common path, e.g. 8 bytes per lane for large-16ag r = 2)
+    return (!Cfg::kQrt && (Cfg::kN == 7 || Cfg::kN == 8)) || (R == 1 && Cfg::kN >= 9 && Cfg::kN <= 19);
 }
 template <int R, typename CellT, typename Cfg, bool kRollout, int kObs = OBS_FLATTENED>
 __global__ void __launch_bounds__(256)
 #if defined(__HIPCC__)
-__attribute__((amdgpu_waves_per_eu(want_occ8<Cfg, kRollout>() ? 8 : 1, 8)))
+__attribute__((amdgpu_waves_per_eu(want_occ8<R, Cfg, kRollout>() ? 8 : 1, 8)))
 #endif
 rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L0 = 8 + 7 * CELLS, OW0 = (L0 + 31) / 32;
@@ -434,6 +437,15 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     //  5 bits x 12 in 64, 6 bits x 19 in 128)
     constexpr bool kRegAG = Cfg::kN >= 1 && Cfg::kN <= 19;
     constexpr bool kDirect = kRegAG && Cfg::kE != 0 && (!kMsg || (Cfg::kM >= 1 && Cfg::kM <= 4));  // (message words: one register each)
+#ifndef RW_AB_CELL_AG
+#define RW_AB_CELL_AG 1  // A/B hook (profiles/tools/ab.sh): 0 = all-gather exchange for every agent count
+#endif
+    // 9 .. 19 agents, per-step builds (kCell): the exchange goes through the per-cell agent layer in LDS instead of all-gathers — who
+    // stands on my target cell is ONE byte read, who competes for it is a look at its four neighbours, follower depth and the
+    // chain walk chase pointers — O(1) per agent where the gathers are O(N) moves + O(N) compares per agent.  These kernels are
+    // bound by instruction issue: at 16 agents the gathers were most of the agent phases' ~800 instructions per
+    // wavefront.  (Up to 8 agents the gathers are DPP moves or a handful of ds_bpermute and stay.)
+    constexpr bool kCell = RW_AB_CELL_AG != 0 && kDirect && !kRollout && Cfg::kN >= 9;
     // ONE scalar batch, first thing in the kernel, for every field of the parameter block that the stage-in and the agent
     // phases read: left to itself hipcc fetches each field where it is first used — three dependent scalar-cache round
     // trips in the prologue (every launch starts with cold caches) and more inside the agent phases, which run on one
@@ -674,7 +686,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                     const bool mine = (g < KG) && (wave * KG + g < Cfg::kE);
                     unpack_own();
                     early = intent_of((op == OP_STEP) && mine && !r_flag, r_act, r_x, r_y, r_d);
-                    early.occ_w = occupant_of(early, r_carry, a_idx, (g < KG ? g : KG - 1) * KN);
+                    if constexpr (!kCell) early.occ_w = occupant_of(early, r_carry, a_idx, (g < KG ? g : KG - 1) * KN);
                     keep_vgpr(early.tg0, early.occ_w);  // (materialised here, not sunk below the barrier)
                 }
             }
@@ -696,7 +708,8 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         RW_MARK(TL_DMA_ISSUED);
         RW_MARK(TL_ENV_LOADED);
         if constexpr (kDmaFirst) lds_wait();  // (the blind clear: hipcc does not count those stores)
-        __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
+        dma_wait();       // the stage-in DMA this wavefront issued has landed (explicit: see rware_cdna4.h) ...
+        __syncthreads();  // ... and everybody else's: the one full barrier
         if constexpr (!kDirect) {  // (kDirect: the leader lane of each env publishes these from its registers, in AG)
             const uint8_t *s_dflag = reinterpret_cast<const uint8_t *>(smem + lo.dflag);
             for (int e = tid; e < ne; e += T) {
@@ -734,7 +747,8 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             if (rs) atomicOr(&s_misc[0], 1);
         }
         RW_MARK(TL_ENV_LOADED);
-        __syncthreads();  // the one full barrier: drains the DMA (vmcnt) as well
+        dma_wait();
+        __syncthreads();  // the one full barrier (the DMA has been waited for)
         unpack_records();
         lds_barrier();
     }
@@ -896,6 +910,10 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         a = in.a;
         const int st = in.st, tg0 = in.tg0, tx0 = in.tx0, ty0 = in.ty0;
         RW_AG_MARK(TL_AG_RECORD, st, a);
+        if constexpr (kCell) {  // the start-of-step agent layer (id | 0x80 if loaded; zeroed by the clear): where everybody stands
+            if (mine && !ev_reset) gA[st] = (uint8_t)((a_idx + 1) | (carry ? 0x80 : 0));
+            wave_sync();
+        }
         // ---- LDS read batch 2 (the only one of the common kDirect step): the shelf layer at the target, under the agent and
         // on the first two goal cells (start-of-step values), the highway word of the agent's cell
         const int sh_tg = gS[tg0], shelf_here = gS[st], sh_g0 = gS[k_goal0], sh_g1 = gS[k_goal1];
@@ -907,7 +925,13 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             if (Cfg::kQrt && q * KN >= KQ) { qv[q] = 0; continue; }  // (scalar test: a slot group beyond the run-time queue length)
             qv[q] = s_queue[eq + (Cfg::kQrt ? max(min(a_idx + q * KN, KQ - 1), 0) : min(a_idx + q * KN, KQ - 1))];
         }
-        const int occ_w = kEarly ? in.occ_w : occupant_of(in, carry, a_idx, lane_base);  // (issued beside the LDS reads above)
+        int occ_w;
+        if constexpr (kCell) {  // (one byte of the agent layer, read in the same batch)
+            const int ag_tg = gA[tg0];
+            occ_w = (ag_tg & 0x7f) ? ((((ag_tg & 0x7f) - 1) << 20) | ((ag_tg & 0x80) << 9)) : -1;
+        } else {
+            occ_w = kEarly ? in.occ_w : occupant_of(in, carry, a_idx, lane_base);  // (issued beside the LDS reads above)
+        }
         if (kDirect && t == 0 && mine && a_idx == 0) {  // the env's leader lane publishes the flags and counters the other
             // phases read (from its registers; LDS stores issued while the reads above are in flight)
             ev[ENVI_STEPS] = r_steps; ev[ENVI_INACTIVE] = r_inact; ev[ENVI_RESET] = r_flag; ev[ENVI_SKIP] = r_flag;
@@ -926,88 +950,153 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         // Chains (an agent stepping onto a cell another agent stands on) are rare; when the wavefront has none, every
         // follower depth is 0 and a mover commits iff it wins its cell.
         const bool chains = wave_any(nxt >= 0);  // wave-uniform
-        // ------------------------------------------------------------ P2a: follower depth (longest chain of movers behind me)
-        int depth = 0;
-        int nxv[KN];
-        if (chains) {
-            env_gather<KN>(nxt, lane_base, nxv);
-            for (int it = 1; it < KN; ++it) {  // relaxation; a chain of movers has at most N - 1 links
-                int dv[KN];
-                env_gather<KN>(depth, lane_base, dv);
-                int nd = 0;
-#pragma unroll
-                for (int k = 0; k < KN; ++k) nd = max(nd, (nxv[k] == a_idx) ? dv[k] + 1 : 0);
-                nd = (nxt != -2) ? nd : 0;  // only movers carry a depth
-                const bool changed = nd != depth;
-                depth = nd;
-                if (!wave_any(changed)) break;  // wave-uniform (agents on a cycle never settle: their depth is not used)
+        int depth = 0, lose = 0, commit = 0;
+        if constexpr (kCell) {
+            // ---- through LDS, O(1) per agent: chain links and contested-cell keys are published, follower depth by walking the
+            // links with atomicMax (a chain of movers is short), the winner test looks at the four neighbours of the target
+            // cell — whoever else wants that cell stands on one of them —, the chain walk chases pointers.
+            if (mine) { s_nxt[i] = nxt; s_tgt[i] = (nxt != -2) ? tg : -1; }  // (s_depth was zeroed by the clear)
+            wave_sync();
+            if (chains) {
+                if (nxt >= 0) {
+                    int j = nxt, dd = 1;
+                    while (j >= 0 && j != a_idx && dd <= KN && s_nxt[base + j] != -2) {
+                        atomicMax(&s_depth[base + j], dd);
+                        j = s_nxt[base + j];
+                        ++dd;
+                    }
+                }
+                wave_sync();
+                depth = s_depth[i];
             }
-        }
-        // ------------------------------------------------------------ P2b: winner per contested cell
-        // larger follower depth wins, then the LOWER agent id; only movers compete.  One word per agent, target cell above
-        // the priority (depth << IB | 2^IB - 1 - index; IB = 4 bits up to 16 agents, 5 beyond): agent k beats me iff the cell
-        // fields agree and its word is the larger one.  A stationary agent announces a cell nobody can target (0x1fff00 | index)
-        // and so neither beats nor is beaten.
-        constexpr int IB = KN <= 16 ? 4 : 5, PW = 2 * IB;  // (a depth is at most N - 1: the same width)
-        const uint32_t vme = (nxt != -2) ? ((uint32_t)tg << PW) | ((uint32_t)depth << IB) | (uint32_t)((1 << IB) - 1 - a_idx)
-                                         : (0x1fff00u | (uint32_t)a_idx) << PW;
-        int kv[KN];
-        env_gather<KN>((int)vme, lane_base, kv);
-        // (A subtract-and-running-minimum form of this test — one compare at the end — passed the host emulation and failed a
-        //  golden trace on the GPU: hipcc folds the DPP move into `v_subrev_u32_dpp` and the result came out with the
-        //  operands swapped; profiles/tools/dpp_subrev_probe.hip.  Keep the exchange results in registers of their own.)
-        int lose = 0;
-#pragma unroll
-        for (int k = 0; k < KN; ++k)  // (bitwise on purpose: no short-circuit branches)
-            lose |= ((((uint32_t)kv[k] ^ vme) < (1u << PW)) & ((uint32_t)kv[k] > vme)) ? 1 : 0;
-        // ------------------------------------------------------------ P2c: commit (:871-876)
-        int commit = (nxt == -1) ? (lose ^ 1) : ((nxt == -2) ? 1 : 0);
-        if (chains) {  // walk the chain ahead: i -> nxt(i) -> ... on the gathered links
-            // every agent's (nxt + 2 | win << LB) as one field of a word every lane of the env holds: following a link is
-            // a shift and a mask (a register array indexed by a run-time agent index would live in scratch memory).
-            // N <= 6: 3 + 1 bits per agent in 32 bits; 7 <= N <= 12: 4 + 1 bits per agent in 64 bits (two OR-reductions);
-            // 13 <= N <= 19: 5 + 1 bits per agent in 128 bits — ONE gather of every agent's field (N cross-lane moves), the word
-            // assembled in each lane with compile-time shifts (four OR-reductions would be 4 N moves).
-            constexpr int LB = KN <= 6 ? 3 : KN <= 12 ? 4 : 5, FW = LB + 1;
-            constexpr uint32_t LM = (1u << LB) - 1u;
-            using links_t = typename pick_type<KN <= 6, uint32_t, typename pick_type<KN <= 12, uint64_t, u128>::type>::type;
-            links_t links;
+            // winner of a contested cell: larger follower depth, then the LOWER agent id; only movers compete.  The start-of-step
+            // agent layer says who stands on the four neighbours of my target; their published keys say whether they want it.
             {
-                const uint32_t own_field = (uint32_t)((nxt + 2) | ((lose ^ 1) << LB));
-                if constexpr (KN <= 6) {
-                    links = (links_t)(uint32_t)env_or<KN>((int)(own_field << (FW * a_idx)), lane_base);
-                } else if constexpr (KN <= 12) {
-                    const uint64_t own = (uint64_t)own_field << (FW * a_idx);
-                    const uint32_t lo = (uint32_t)env_or<KN>((int)(uint32_t)own, lane_base);
-                    const uint32_t hi = (uint32_t)env_or<KN>((int)(uint32_t)(own >> 32), lane_base);
-                    links = (links_t)(((uint64_t)hi << 32) | lo);
-                } else {
-                    int fv[KN];
-                    env_gather<KN>((int)own_field, lane_base, fv);
-                    links = 0;
+                const bool okn[4] = {ty > 0, ty < H - 1, tx > 0, tx < W - 1};
+                const int nbc[4] = {tg - W, tg + W, tg - 1, tg + 1};
+                int kk[4];
+                bool val[4];
 #pragma unroll
-                    for (int k = 0; k < KN; ++k) links |= (links_t)(uint32_t)fv[k] << (FW * k);
+                for (int q = 0; q < 4; ++q) {  // (read batch 1: an off-grid neighbour reads my own cell and is masked)
+                    const int ida = gA[okn[q] ? nbc[q] : st] & 0x7f;
+                    kk[q] = ida - 1;
+                    val[q] = okn[q] & (ida != 0) & (kk[q] != a_idx);
+                }
+                int tk[4], dk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {  // (read batch 2)
+                    const int jq = base + (val[q] ? kk[q] : 0);
+                    tk[q] = s_tgt[jq];
+                    dk[q] = s_depth[jq];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    lose |= (val[q] & (tk[q] == tg) & ((dk[q] > depth) | ((dk[q] == depth) & (kk[q] < a_idx)))) ? 1 : 0;
+                lose = (nxt != -2) ? lose : 0;
+            }
+            // ---- commit (:871-876)
+            commit = (nxt == -1) ? (lose ^ 1) : ((nxt == -2) ? 1 : 0);
+            if (chains) {  // walk the chain ahead: i -> nxt(i) -> ...
+                if (mine) s_win[i] = lose ^ 1;
+                wave_sync();
+                if (nxt >= 0) {
+                    int j = a_idx, hops = 0, ok = 1, cm = 0;
+                    for (;;) {
+                        ok &= s_win[base + j];
+                        const int nj = s_nxt[base + j];
+                        ++hops;
+                        if (nj == -1) { cm = ok; break; }                  // drains into an empty cell
+                        if (nj == a_idx) { cm = (hops >= 3) ? 1 : 0; break; }  // a cycle through me; the 2-swap is refused
+                        if (s_nxt[base + nj] == -2) break;                 // blocked by a stationary agent
+                        if (hops >= KN) break;                             // feeds a cycle it is not part of
+                        j = nj;
+                    }
+                    commit = cm;
                 }
             }
-            int j = a_idx, hops = 0, ok = 1, cm = 0;
-            bool done = nxt < 0;
+            wave_lds_order();  // every lane's reads of the start-of-step agent layer come before the first lane's update of it (P3)
+        } else {
+            // ------------------------------------------------------------ P2a: follower depth (longest chain of movers behind me)
+            int nxv[KN];
+            if (chains) {
+                env_gather<KN>(nxt, lane_base, nxv);
+                for (int it = 1; it < KN; ++it) {  // relaxation; a chain of movers has at most N - 1 links
+                    int dv[KN];
+                    env_gather<KN>(depth, lane_base, dv);
+                    int nd = 0;
 #pragma unroll
-            for (int h = 0; h < KN; ++h) {
-                const uint32_t ent = (uint32_t)(links >> (FW * j)) & ((1u << FW) - 1u);
-                const int nj = (int)(ent & LM) - 2;
-                ok &= (int)(ent >> LB);
-                ++hops;
-                const int nnj = (int)((uint32_t)(links >> (FW * (nj & (KN <= 6 ? 7 : (nj < 0 ? 0 : 31))))) & LM) - 2;  // nxt of the successor (not used when nj < 0)
-                const bool to_empty = nj == -1;                     // drains into an empty cell
-                const bool back = nj == a_idx;                      // a cycle through me; the 2-swap is refused
-                const bool stuck = (nj >= 0) & (nnj == -2);         // blocked by a stationary agent
-                cm = (!done & to_empty) ? ok : cm;
-                cm = (!done & !to_empty & back) ? ((hops >= 3) ? 1 : 0) : cm;
-                done = done | to_empty | back | stuck | (hops >= KN);  // hops == N: feeds a cycle it is not part of
-                j = (nj >= 0) ? nj : j;
-                if (h + 1 < KN && !wave_any(!done)) break;  // wave-uniform: the usual chain is one or two links long
+                    for (int k = 0; k < KN; ++k) nd = max(nd, (nxv[k] == a_idx) ? dv[k] + 1 : 0);
+                    nd = (nxt != -2) ? nd : 0;  // only movers carry a depth
+                    const bool changed = nd != depth;
+                    depth = nd;
+                    if (!wave_any(changed)) break;  // wave-uniform (agents on a cycle never settle: their depth is not used)
+                }
             }
-            commit = (nxt >= 0) ? cm : commit;
+            // ------------------------------------------------------------ P2b: winner per contested cell
+            // larger follower depth wins, then the LOWER agent id; only movers compete.  One word per agent, target cell above
+            // the priority (depth << IB | 2^IB - 1 - index; IB = 4 bits up to 16 agents, 5 beyond): agent k beats me iff the cell
+            // fields agree and its word is the larger one.  A stationary agent announces a cell nobody can target (0x1fff00 | index)
+            // and so neither beats nor is beaten.
+            constexpr int IB = KN <= 16 ? 4 : 5, PW = 2 * IB;  // (a depth is at most N - 1: the same width)
+            const uint32_t vme = (nxt != -2) ? ((uint32_t)tg << PW) | ((uint32_t)depth << IB) | (uint32_t)((1 << IB) - 1 - a_idx)
+                                             : (0x1fff00u | (uint32_t)a_idx) << PW;
+            int kv[KN];
+            env_gather<KN>((int)vme, lane_base, kv);
+            // (A subtract-and-running-minimum form of this test — one compare at the end — passed the host emulation and failed a
+            //  golden trace on the GPU: hipcc folds the DPP move into `v_subrev_u32_dpp` and the result came out with the
+            //  operands swapped; profiles/tools/dpp_subrev_probe.hip.  Keep the exchange results in registers of their own.)
+#pragma unroll
+            for (int k = 0; k < KN; ++k)  // (bitwise on purpose: no short-circuit branches)
+                lose |= ((((uint32_t)kv[k] ^ vme) < (1u << PW)) & ((uint32_t)kv[k] > vme)) ? 1 : 0;
+            // ------------------------------------------------------------ P2c: commit (:871-876)
+            commit = (nxt == -1) ? (lose ^ 1) : ((nxt == -2) ? 1 : 0);
+            if (chains) {  // walk the chain ahead: i -> nxt(i) -> ... on the gathered links
+                // every agent's (nxt + 2 | win << LB) as one field of a word every lane of the env holds: following a link is
+                // a shift and a mask (a register array indexed by a run-time agent index would live in scratch memory).
+                // N <= 6: 3 + 1 bits per agent in 32 bits; 7 <= N <= 12: 4 + 1 bits per agent in 64 bits (two OR-reductions);
+                // 13 <= N <= 19: 5 + 1 bits per agent in 128 bits — ONE gather of every agent's field (N cross-lane moves), the word
+                // assembled in each lane with compile-time shifts (four OR-reductions would be 4 N moves).
+                constexpr int LB = KN <= 6 ? 3 : KN <= 12 ? 4 : 5, FW = LB + 1;
+                constexpr uint32_t LM = (1u << LB) - 1u;
+                using links_t = typename pick_type<KN <= 6, uint32_t, typename pick_type<KN <= 12, uint64_t, u128>::type>::type;
+                links_t links;
+                {
+                    const uint32_t own_field = (uint32_t)((nxt + 2) | ((lose ^ 1) << LB));
+                    if constexpr (KN <= 6) {
+                        links = (links_t)(uint32_t)env_or<KN>((int)(own_field << (FW * a_idx)), lane_base);
+                    } else if constexpr (KN <= 12) {
+                        const uint64_t own = (uint64_t)own_field << (FW * a_idx);
+                        const uint32_t lo = (uint32_t)env_or<KN>((int)(uint32_t)own, lane_base);
+                        const uint32_t hi = (uint32_t)env_or<KN>((int)(uint32_t)(own >> 32), lane_base);
+                        links = (links_t)(((uint64_t)hi << 32) | lo);
+                    } else {
+                        int fv[KN];
+                        env_gather<KN>((int)own_field, lane_base, fv);
+                        links = 0;
+#pragma unroll
+                        for (int k = 0; k < KN; ++k) links |= (links_t)(uint32_t)fv[k] << (FW * k);
+                    }
+                }
+                int j = a_idx, hops = 0, ok = 1, cm = 0;
+                bool done = nxt < 0;
+#pragma unroll
+                for (int h = 0; h < KN; ++h) {
+                    const uint32_t ent = (uint32_t)(links >> (FW * j)) & ((1u << FW) - 1u);
+                    const int nj = (int)(ent & LM) - 2;
+                    ok &= (int)(ent >> LB);
+                    ++hops;
+                    const int nnj = (int)((uint32_t)(links >> (FW * (nj & (KN <= 6 ? 7 : (nj < 0 ? 0 : 31))))) & LM) - 2;  // nxt of the successor (not used when nj < 0)
+                    const bool to_empty = nj == -1;                     // drains into an empty cell
+                    const bool back = nj == a_idx;                      // a cycle through me; the 2-swap is refused
+                    const bool stuck = (nj >= 0) & (nnj == -2);         // blocked by a stationary agent
+                    cm = (!done & to_empty) ? ok : cm;
+                    cm = (!done & !to_empty & back) ? ((hops >= 3) ? 1 : 0) : cm;
+                    done = done | to_empty | back | stuck | (hops >= KN);  // hops == N: feeds a cycle it is not part of
+                    j = (nj >= 0) ? nj : j;
+                    if (h + 1 < KN && !wave_any(!done)) break;  // wave-uniform: the usual chain is one or two links long
+                }
+                commit = (nxt >= 0) ? cm : commit;
+            }
         }
         // ------------------------------------------------------------ P3: apply (:878-899)
         RW_AG_MARK(TL_AG_WINNERS, commit, lose);
@@ -1032,6 +1121,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         if (mine) s_rew[i] = rew;  // every agent of the chunk gets its reward slot
         if (mine) s_mv[i] = moved ? (st | (tg << 16)) : -1;  // which two cells changed (write-back hand-off)
         if (mcar) gS[st] = 0;  // incremental _recalc_grid (:749-755): clear phase ...
+        if constexpr (kCell) { if (moved) gA[st] = 0; }  // (kCell: the layer holds the start-of-step marks — a mover's goes first)
         wave_lds_order();
         if (mcar) gS[tg] = (CellT)carry;  // ... then set phase, for the whole wavefront in this order
         // the agent layer was zeroed at the start of the step: final position only (id | 0x80 if loaded)
@@ -1039,8 +1129,14 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         // ------------------------------------------------------------ P5: goals, rewards, termination (:903-942)
         // Is there a shelf on a goal cell after the moves?  From registers: a loaded mover that arrived there, or the
         // start-of-step shelf unless a loaded mover took it away.  (More than two goal cells: always take the LDS path.)
-        const int gflags = env_or<KN>(mcar ? ((tg == k_goal0 ? 1 : 0) | (tg == k_goal1 ? 2 : 0) | (st == k_goal0 ? 4 : 0) |
-                                               (st == k_goal1 ? 8 : 0)) : 0, lane_base);
+        int gflags;
+        if constexpr (kCell) {  // (four ballots instead of N cross-lane moves)
+            gflags = (env_any<KN>(mcar & (tg == k_goal0), lane_base) ? 1 : 0) | (env_any<KN>(mcar & (tg == k_goal1), lane_base) ? 2 : 0) |
+                     (env_any<KN>(mcar & (st == k_goal0), lane_base) ? 4 : 0) | (env_any<KN>(mcar & (st == k_goal1), lane_base) ? 8 : 0);
+        } else {
+            gflags = env_or<KN>(mcar ? ((tg == k_goal0 ? 1 : 0) | (tg == k_goal1 ? 2 : 0) | (st == k_goal0 ? 4 : 0) |
+                                         (st == k_goal1 ? 8 : 0)) : 0, lane_base);
+        }
         // bit g of `on_goal`: a shelf stands on goal g after the moves — a loaded mover arrived (gflags bits 0, 1), or the
         // start-of-step shelf is still there (bits 2, 3 say a loaded mover took it away).  Integer arithmetic on purpose.
         const int had = min(sh_g0, 1) | (min(sh_g1, 1) << 1);
@@ -1356,7 +1452,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         }
         // fused rollout: a later step's write-back (another wavefront) may store need_reset = 1 for the same env — this
         // path's stores are made visible first (vmcnt drained before the barrier; the path is rare, the wait is free)
-        if (kRollout) __syncthreads(); else lds_barrier();
+        if (kRollout) { dma_wait(); __syncthreads(); } else lds_barrier();
     }
     RW_MARK(TL_RESET);
 
@@ -1789,6 +1885,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         if (k_transposed & 1) {
             // AGENT_DIRECTION (:547-552): the marked cells hold dir + 1, not 1.  Patched after every 0/1 store of
             // the workgroup has completed (full barrier: vmcnt), one thread per (agent, image row) as in P7.
+            dma_wait();
             __syncthreads();
             if (worker)
             for (int w = tid; w < nea * WIN; w += TW) {

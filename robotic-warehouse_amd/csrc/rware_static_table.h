@@ -100,24 +100,25 @@ namespace {
 //  register budget of 8 wavefronts (amdgpu_waves_per_eu) was measured: small-8ag B = 16384 12.73 -> 11.14 us, but +0.1 .. +0.4 us
 //  wherever the batch fits anyway — the spilled scalars cost more than they buy.)
 #define RW_QRT_58(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 8, 256, ((N) >= 7 ? 14336 : 8192)), RW_STATIC(H, W, N, -1, S, 1, 16, 256, 0)
-// 9 .. 19 agents (rware/__init__.py:16 registers every count up to 19).  Measured, round 4, B = 16384, same box (us per step,
-// E = 8 vs 16; 8-env builds of 9 .. 13 agents with the register budget of 8 wavefronts per SIMD, rw::want_occ8):
-//   small-9ag 13.35 vs 13.05 | 10ag 13.80 vs 14.23 | 12ag 15.67 vs 16.52 | 13ag 18.48 vs 18.45 | 14ag 20.75 vs 19.79 | 16ag 22.81 vs 21.60
-//   large-16ag 22.38 vs 21.18 (E = 4: 20.8) | B = 8192 small-10ag 10.60 vs 10.05 | B = 32768 23.5 vs 24.0
-// -> 9 .. 13 agents: 8 envs per workgroup; 14 .. 16: 16 envs (no register budget to force: 4 workgroups per CU hold the batch);
-//    17 .. 19: 8 envs (three agents' envs per wavefront: 12 envs at most).  4 envs: batches that are no multiple of 8.
+// 9 .. 19 agents (rware/__init__.py:16 registers every count up to 19): 8 envs per workgroup, with the register budget of 8
+// wavefronts per SIMD (rw::want_occ8) and the per-cell agent phases (kCell).  Measured, round 4, B = 16384, same box, us per step:
+//   all-gather agent phases, E = 8 vs 16:  small-9ag 13.35 / 13.05 | 10ag 13.80 / 14.23 | 12ag 15.67 / 16.52 | 13ag 18.48 / 18.45 |
+//       14ag 20.75 / 19.79 | 16ag 22.81 / 21.60 | large-16ag 22.38 / 21.18 (E = 4: 20.8)   (from 14 agents on the budget spilled)
+//   per-cell agent phases (54 .. 62 VGPRs at every agent count), E = 8 vs 16:  10ag 13.0 / 13.9 | 14ag 16.9 / 17.5 | 16ag 18.0 / 18.8 |
+//       large-16ag 18.0 / 19.0 (E = 4: 17.4) | 17ag 19.6 | 19ag 21.3
+// -> 8 envs per workgroup for every count; 16 (up to 16 agents: three agents' envs of 17 .. 19 fit a wavefront, 12 envs at most per
+//    4-wavefront workgroup) and 4 as explicit geometries and for batches that are no multiple of 8.
 #define RW_QRT_WIDE(H, W, S, N) RW_QRT_WIDE_##N(H, W, S, N)
 #define RW_QRT_WIDE_LO(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 8, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 16, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 4, 256, 0)
-#define RW_QRT_WIDE_MID(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 16, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 8, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 4, 256, 0)
 #define RW_QRT_WIDE_HI(H, W, S, N) RW_STATIC(H, W, N, -1, S, 1, 8, 256, 0), RW_STATIC(H, W, N, -1, S, 1, 4, 256, 0)
 #define RW_QRT_WIDE_9 RW_QRT_WIDE_LO
 #define RW_QRT_WIDE_10 RW_QRT_WIDE_LO
 #define RW_QRT_WIDE_11 RW_QRT_WIDE_LO
 #define RW_QRT_WIDE_12 RW_QRT_WIDE_LO
 #define RW_QRT_WIDE_13 RW_QRT_WIDE_LO
-#define RW_QRT_WIDE_14 RW_QRT_WIDE_MID
-#define RW_QRT_WIDE_15 RW_QRT_WIDE_MID
-#define RW_QRT_WIDE_16 RW_QRT_WIDE_MID
+#define RW_QRT_WIDE_14 RW_QRT_WIDE_LO
+#define RW_QRT_WIDE_15 RW_QRT_WIDE_LO
+#define RW_QRT_WIDE_16 RW_QRT_WIDE_LO
 #define RW_QRT_WIDE_17 RW_QRT_WIDE_HI
 #define RW_QRT_WIDE_18 RW_QRT_WIDE_HI
 #define RW_QRT_WIDE_19 RW_QRT_WIDE_HI

@@ -34,6 +34,7 @@ inline void store_f4_nt(float4 *dst, float4 v) { *dst = v; }  // (the hint has n
 inline int uniform(int x) { return x; }
 inline void lds_zero_b128_blind(void *lds_ptr) { memset(lds_ptr, 0, 16); }
 inline void lds_wait() {}
+inline void dma_wait() {}
 inline void lds_barrier() { pthread_barrier_wait(emu_barrier); }
 inline void wave_sync() { pthread_barrier_wait(emu_wave_barrier); }
 inline void wave_lds_order() { pthread_barrier_wait(emu_wave_barrier); }  // threads are not in lockstep here: a real barrier
@@ -47,6 +48,8 @@ inline int env_or(int v, int lane_base) {
     for (int k = 0; k < N; ++k) r |= g[k];
     return r;
 }
+template <int N>
+inline bool env_any(bool v, int lane_base) { return env_or<N>(v ? 1 : 0, lane_base) != 0; }
 template <int N>
 inline void env_gather(int v, int lane_base, int (&out)[N]) {  // every thread of the wave calls this
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63u;

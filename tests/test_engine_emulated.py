@@ -746,8 +746,8 @@ def test_agent_count_static_builds_read_the_queue_length_at_run_time(env_id, ext
     B, N = 32, kw["n_agents"]
     env = rware_amd.WarehouseVecEnv(B, library=LIB, **kw)
     assert env.engines[0].info.specialised == 1
-    # (geometry by the measured rules of rware_static_table.h: 16 envs up to 4 agents, 8 from 5 on, 16 again for 14 .. 16 agents)
-    assert env.engines[0].info.build_kind == 2 and env.engines[0].info.envs_per_workgroup == (16 if N <= 4 or (14 <= N <= 16 and "tiny" not in env_id) else 8)
+    # (geometry by the measured rules of rware_static_table.h: 16 envs up to 4 agents, 8 from 5 on)
+    assert env.engines[0].info.build_kind == 2 and env.engines[0].info.envs_per_workgroup == (16 if N <= 4 else 8)
     orc = OracleVecEnv(B, **kw)
     assert np.array_equal(env.reset(seed=14)[0], orc.reset(seed=14))
     rng = np.random.default_rng(16)
@@ -844,10 +844,12 @@ def test_generic_kernel_matches_oracle_on_random_shapes(case):
     ("rware-tiny-13ag-v1", 0.75), ("rware-tiny-16ag-v1", 0.75), ("rware-tiny-17ag-hard-v1", 0.7), ("rware-tiny-19ag-v1", 0.8),
     ("rware-tiny-10ag-v1", 0.8), ("rware-tiny-12ag-easy-v1", 0.75),
 ])
-def test_crowded_warehouses_resolve_long_chains_in_registers(env_id, p_forward):
+def test_crowded_warehouses_resolve_long_chains(env_id, p_forward):
     """9 .. 19 agents on the 110 cells of the tiny warehouse under a forward-heavy policy: long follower chains, contested
-    cells with unequal depths, blocked tails and cycles on nearly every step — the register-exchange agent phases (wide
-    priority words, 128-bit chain links) against the oracle's literal networkx restatement."""
+    cells with unequal depths, blocked tails and cycles on nearly every step — the per-cell agent phases of the per-step kernel
+    (occupant from the agent layer, winners among the target's four neighbours, pointer-chased depth and chain walk) and the
+    register-exchange ones of the fused rollout (wide priority words, 128-bit chain links) against the oracle's literal networkx
+    restatement."""
     kw = rware_amd.env_kwargs(env_id)
     kw["max_steps"] = 40
     kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
@@ -863,6 +865,11 @@ def test_crowded_warehouses_resolve_long_chains_in_registers(env_id, p_forward):
         obs, rew, term, _, _ = env.step(a)
         o2, r2, d2 = orc.step_autoreset(a, "next_step")
         assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+    acts = rng.choice(5, size=(25, B, N), p=[rest, p_forward, rest, rest, rest]).astype(np.int32)
+    obs, rew, term = env.rollout(acts)                      # the fused rollout keeps the all-gather (register) agent phases
+    for k in range(25):
+        o2, r2, d2 = orc.step_autoreset(acts[k], "next_step")
+        assert np.array_equal(obs[k], o2) and np.array_equal(rew[k], r2) and np.array_equal(term[k], d2.astype(bool)), k
     st, so = env.get_state(), orc.get_state()
     for k in so:
         assert np.array_equal(st[k], so[k]), k

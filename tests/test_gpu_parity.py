@@ -830,11 +830,11 @@ def test_agent_count_static_builds_match_oracle(env_id):
     ("rware-tiny-16ag-v1", 0.75, (0, 0)), ("rware-tiny-17ag-hard-v1", 0.7, (0, 0)), ("rware-tiny-19ag-v1", 0.8, (0, 0)),
     ("rware-small-16ag-v1", 0.8, (4, 256)), ("rware-small-19ag-v1", 0.8, (4, 256)),
 ])
-def test_crowded_warehouses_resolve_long_chains_in_registers(env_id, p_forward, geom):
+def test_crowded_warehouses_resolve_long_chains(env_id, p_forward, geom):
     """9 .. 19 agents on the 110 cells of the tiny warehouse (and the 4-env geometry on the small one) under a forward-heavy
     policy: long follower chains, contested cells with unequal depths, blocked tails and cycles on nearly every step — the
-    register-exchange agent phases (wide priority words, 64- / 128-bit chain links) against the oracle's literal networkx
-    restatement, every env, every step."""
+    per-cell agent phases of the per-step kernels and the register-exchange ones of the fused rollout (wide priority words,
+    64- / 128-bit chain links) against the oracle's literal networkx restatement, every env, every step."""
     kw = rware_amd.env_kwargs(env_id)
     kw["max_steps"] = 60
     kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
@@ -850,6 +850,11 @@ def test_crowded_warehouses_resolve_long_chains_in_registers(env_id, p_forward, 
         obs, rew, term, _, _ = env.step(a)
         o2, r2, d2 = orc.step_autoreset(a, "next_step")
         assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+    acts = rng.choice(5, size=(25, B, N), p=[rest, p_forward, rest, rest, rest]).astype(np.int32)
+    obs, rew, term = env.rollout(acts)                      # the fused rollout keeps the all-gather (register) agent phases
+    for k in range(25):
+        o2, r2, d2 = orc.step_autoreset(acts[k], "next_step")
+        assert np.array_equal(obs[k], o2) and np.array_equal(rew[k], r2) and np.array_equal(term[k], d2.astype(bool)), k
     st, so = env.get_state(), orc.get_state()
     for k in so:
         assert np.array_equal(st[k], so[k]), k
@@ -1038,9 +1043,11 @@ def test_runtime_specialisation_policy(tmp_path, monkeypatch):
     reg = rware_amd.WarehouseVecEnv(4096, **rware_amd.env_kwargs("rware-small-4ag-v1"))
     assert reg.engines[0].info.jit == 0 and reg.engines[0].info.build_kind == 1            # ahead-of-time exact build
     reg.close()
-    off = rware_amd.WarehouseVecEnv(4096, jit=False, **kw)
+    # (16384 envs: four workgroups per CU — a run-time compiled build once left its stage-in DMA in flight across the barrier,
+    #  hipRTC's __syncthreads() not implying the vmcnt wait hipcc's does; one workgroup per CU hid it, a full chip did not)
+    B, N = 16384, kw["n_agents"]
+    off = rware_amd.WarehouseVecEnv(B, jit=False, **kw)
     assert off.engines[0].info.jit == 0 and off.engines[0].info.build_kind == 0
-    B, N = 4096, kw["n_agents"]
     env = rware_amd.WarehouseVecEnv(B, **kw)
     assert env.engines[0].info.jit == 1 and env.engines[0].info.build_kind == 1, env.engines[0].jit_log()
     okw = dict(kw, reward_type=rware_amd.enums.enum_value(kw["reward_type"]))
@@ -1064,6 +1071,20 @@ def test_runtime_specialisation_policy(tmp_path, monkeypatch):
     for k in so:
         assert np.array_equal(st[k], so[k]), k
     env.close(); off.close()
+    # the run-time compiled build of a REGISTERED shape at 16 workgroups per CU: the same kernel source as the ahead-of-time
+    # build next to it, every observation of every env
+    kw4 = rware_amd.env_kwargs("rware-small-4ag-v1")
+    B = 65536
+    jenv, aenv = rware_amd.WarehouseVecEnv(B, jit=True, **kw4), rware_amd.WarehouseVecEnv(B, **kw4)
+    assert jenv.engines[0].info.jit in (1, 2) and aenv.engines[0].info.jit == 0
+    orc = OracleVecEnv(B, **dict(kw4, reward_type=rware_amd.enums.enum_value(kw4["reward_type"])))
+    o0 = orc.reset(seed=3)
+    assert np.array_equal(jenv.reset(seed=3)[0], o0) and np.array_equal(aenv.reset(seed=3)[0], o0)
+    for t in range(12):
+        a = rng.integers(0, 5, size=(B, 4), dtype=np.int32)
+        o2 = orc.step_autoreset(a, "next_step")[0]
+        assert np.array_equal(jenv.step(a)[0], o2) and np.array_equal(aenv.step(a)[0], o2), t
+    jenv.close(); aenv.close()
 
 
 @pytest.mark.parametrize("threads", ["0", "1"])
