@@ -1,6 +1,7 @@
 """us per step of explicit (task, batch, geometry, observation-store) combinations, un-profiled, HIP events on the launches.
-    python profiles/tools/measure.py <env_id>:<B>[:<E>[:<stores>[:<sensor_range>[:<jit>]]]] ...
-E = 0: the engine's own geometry; stores = auto | cached | stream; jit = auto | off | force (run-time specialisation).
+    python profiles/tools/measure.py <env_id>:<B>[:<E>[:<stores>[:<sensor_range>[:<jit>[:<fused>]]]]] ...
+E = 0: the engine's own geometry; stores = auto | cached | stream; jit = auto | off | force (run-time specialisation);
+fused = n: the fused rollout instead, n steps per launch (rw_step_many_device, wall clock around 32 launches).
 <env_id> may also be one of the unregistered shapes below (constructor arguments, not ids).  Per-step launches from a device action tape
 (rw_step_tape_device_timed), uniform random actions, next_step autoreset.  One line per spec."""
 import sys
@@ -25,7 +26,8 @@ for spec in sys.argv[1:]:
     E = int(f[2]) if len(f) > 2 else 0
     stores = f[3] if len(f) > 3 and f[3] != "auto" else None
     sr = int(f[4]) if len(f) > 4 and f[4] else 0
-    jit = {"auto": None, "off": False, "force": True}[f[5]] if len(f) > 5 else None
+    jit = {"auto": None, "off": False, "force": True}[f[5]] if len(f) > 5 and f[5] else None
+    fused = int(f[6]) if len(f) > 6 else 0
     kw = dict(CUSTOM[env_id]) if env_id in CUSTOM else rware_amd.env_kwargs(env_id)
     if sr:
         kw["sensor_range"] = sr
@@ -38,12 +40,23 @@ for spec in sys.argv[1:]:
     eng = env.engines[0]
     eng.reset(seeds=rware_amd.shard_seeds(0, B))
     T = 32 if B * N > 1 << 20 else 64
+    T = max(T, fused)
     tape = torch.from_numpy(np.random.default_rng(1).integers(0, 5, size=(T, B, N), dtype=np.int32)).cuda()
     K = 2000 if B * N <= 1 << 18 else 400
     eng.step_tape_device_timed(tape.data_ptr(), T, 0, max(K // 8, 50), 0, 1)
     torch.cuda.synchronize()
     best = None
-    for rep in range(2):
+    for rep in range(2 if fused else 0):
+        import time
+        eng.step_many_device(tape.data_ptr(), fused)
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(32):
+            eng.step_many_device(tape.data_ptr(), fused)
+        eng.sync()
+        us = (time.perf_counter() - t0) / (32 * fused) * 1e6
+        best = us if best is None else min(best, us)
+    for rep in range(0 if fused else 2):
         eng.step_tape_device_timed(tape.data_ptr(), T, 0, K, 0, 1)
         torch.cuda.synchronize()
         us = eng.event_elapsed_ms(0, 1) / K * 1e3
