@@ -230,6 +230,7 @@ def hbm_regime_leg(torch, rware_amd, local_rank, env_id, sha):
             "frac_physical_of_measured_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_MEASURED_GBPS) if traffic else None,
             "peak": HBM_PEAK_GBPS, "peak_measured": HBM_MEASURED_GBPS, "unit_bw": "GB/s",
             "envs_per_workgroup": int(info.envs_per_workgroup), "kernel_specialised": bool(info.specialised),
+            "start_stagger_ns_per_slot": 10 * int(info.stagger_ticks),   # launches of two or more rounds of workgroups (rw_info.stagger_ticks)
             "observation_stores": "non-temporal" if int(info.obs_stores_stream) else "cached",
         }
         if note:
@@ -271,6 +272,76 @@ def api_closed_loop_leg(torch, rware_amd, local_rank, env_id, B):
         }
     finally:
         env.close()
+
+
+def two_pipelines_leg(torch, rware_amd, local_rank, env_id, B):
+    """The batch as TWO independent sub-batches (`rware_amd.make_pipelines(B, 2)`: one engine and one stream each), stepped
+    concurrently — what a trainer with double-buffered sampling does (policy on half A while half B steps).  The workgroups of one
+    launch run their load / agent / store phases in lock-step; two free-running launches of half the size drift out of phase and
+    fill each other's idle phases (profiles/EXPERIMENTS.md §9-10).  Same device action tapes, K per-step launches per half from a
+    launcher thread each (rw_step_tape_device releases the GIL), wall clock from the first enqueue to the last sync; the one-engine
+    number next to it is measured the same way, here, so the two are comparable.  Then the same through the Python API from ONE host
+    thread (`env.step(cuda_actions)` per sub-batch, no sync inside the loop).  Reported beside the headline, never as `value`."""
+    import threading
+    dev = f"cuda:{local_rank}"
+    out = {"submit": "rware_amd.make_pipelines(B, 2): two engines on one device, B / 2 envs each, own streams; `tape`: K per-step launches per "
+                     "half, one launcher thread each; `api`: env.step(cuda_actions) per half, alternating, one host thread",
+           "steps": 2000, "tasks": {}}
+    for task, b, extra in ((env_id, B, {}), ("rware-small-10ag-v1", 16384, {}), ("rware-large-16ag-v1", 16384, {}),
+                           ("rware-large-16ag-v1", 16384, {"sensor_range": 2})):   # (the last one: BASELINE config 5's shard)
+        kw = dict(rware_amd.env_kwargs(task), **extra)
+        N, K, KA, TS = kw["n_agents"], out["steps"], 1000, 64
+        acts = torch.from_numpy(np.random.default_rng(7).integers(0, 5, size=(TS, b, N), dtype=np.int32)).to(dev)
+        row = {}
+        for M in (1, 2):
+            if M == 1:
+                envs = [rware_amd.WarehouseVecEnv(b, devices=[local_rank], output="torch", **kw)]
+                envs[0].reset(seed=0)
+                bounds = [(0, b)]
+            else:
+                pipes = rware_amd.make_pipelines(b, 2, device=local_rank, **kw)
+                for p_ in pipes:
+                    p_.reset(seed=0)
+                envs, bounds = [p_.env for p_ in pipes], [(p_.lo, p_.hi) for p_ in pipes]
+            try:
+                engs = [e.engines[0] for e in envs]
+                tapes = [acts[:, lo:hi].contiguous() for lo, hi in bounds]
+                torch.cuda.synchronize()
+
+                def run(k, n):
+                    engs[k].step_tape_device(tapes[k].data_ptr(), TS, 0, n)
+                    engs[k].sync()
+                for k in range(M):
+                    run(k, 200)
+                best = None
+                for _ in range(3):
+                    th = [threading.Thread(target=run, args=(k, K)) for k in range(M)]
+                    t0 = time.perf_counter()
+                    for t in th:
+                        t.start()
+                    for t in th:
+                        t.join()
+                    wall = time.perf_counter() - t0
+                    best = wall if best is None else min(best, wall)
+                name = "one_engine" if M == 1 else "two_pipelines"
+                row[name] = {"tape_us_per_step": best / K * 1e6, "value": b * N * K / best, "unit": "agent-steps/s"}
+                sl = [[tp[t] for t in range(TS)] for tp in tapes]
+                for t in range(100):
+                    for k, e in enumerate(envs):
+                        e.step(sl[k][t % TS])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for t in range(KA):
+                    for k, e in enumerate(envs):
+                        e.step(sl[k][t % TS])
+                torch.cuda.synchronize()
+                row[name]["api_us_per_step"] = (time.perf_counter() - t0) / KA * 1e6
+            finally:
+                for e in envs:
+                    e.close()
+        row["speedup"] = row["one_engine"]["tape_us_per_step"] / row["two_pipelines"]["tape_us_per_step"]
+        out["tasks"][f"{task} x {b}" + "".join(f" {k}={v}" for k, v in extra.items())] = row
+    return out
 
 
 def main():
@@ -498,6 +569,7 @@ def main():
                                   else "a HIP graph holding one pass over the action tape (captured rw_step_tape_device), replayed"
                                   if args.submit == "graph" else "one Python/ctypes call per step"),
                 "envs_per_workgroup": int(info.envs_per_workgroup), "threads_per_workgroup": int(info.threads_per_workgroup),
+                "start_stagger_ns_per_slot": 10 * int(info.stagger_ticks),   # 0: the launch is resident at once (no stagger)
                 "kernel_specialised": bool(info.specialised), "kernel_build_kind": int(info.build_kind),
                 "observation_stores": "non-temporal (the engine's default rule for this shape; rw_stream_flags / obs_stores= overrides)"
                                       if int(info.obs_stores_stream) else "cached",
@@ -554,6 +626,8 @@ def main():
                 out["api_closed_loop"]["vs_native_loop"] = out["api_closed_loop"]["us_per_step"] / (out["ms_per_step"] * 1e3)
             if not args.no_hbm_regime:
                 out["hbm_regime"] = hbm_regime_leg(torch, rware_amd, local_rank, args.env_id, sha)
+            if not args.no_api_loop:
+                out["two_pipelines"] = two_pipelines_leg(torch, rware_amd, local_rank, args.env_id, B)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.env_id)
         print(json.dumps(out), flush=True)

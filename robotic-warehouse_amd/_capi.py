@@ -50,7 +50,7 @@ class RwInfo(C.Structure):
         "compute_units", "specialised", "state_layout", "build_kind")] + [
         ("algorithmic_bytes_per_env_step", C.c_int64),
         ("device_name", C.c_char * 128), ("arch_name", C.c_char * 64), ("obs_stores_stream", C.c_int32), ("jit", C.c_int32),
-        ("engine_bytes_per_env_step", C.c_int64), ("reserved", C.c_int32 * 4)]
+        ("engine_bytes_per_env_step", C.c_int64), ("stagger_ticks", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 EXPORTS = (

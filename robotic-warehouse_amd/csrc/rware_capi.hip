@@ -44,6 +44,7 @@ struct rw_engine {
     rw::Params prm{};
     int S = 0, L = 0, OW = 0;
     int E = 0, T = 0, n_wg = 0;
+    int stagger_ticks = 0, stagger_shift = 0;  // start stagger of a CU's first eight workgroups (multi-round launches: see the kernel's prologue)
     size_t lds_bytes = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -130,6 +131,7 @@ namespace {
 
 int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     la.op = op | (la.timeline ? rw::OP_FLAG_TIMELINE : 0);
+    la.op |= (eng->stagger_ticks & 0xff) << 16 | (eng->stagger_shift & 0xf) << 24;
     if (op != rw::OP_OBS) eng->grid_stale = eng->agents_stale = eng->counters_stale = true;  // the kernels keep the shadow and the packed agent records current, not the int32 views
     if (!eng->own_stream && !eng->captured) {  // (a stream of the caller's may be capturing; the engine's own stream never is)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -577,6 +579,19 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(eng->kernel_nt),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->lds_bytes);
         RW_HIP_C(lds_err);
+    }
+    {
+        // two or more rounds of workgroups (the GPU holds 8 four-wavefront workgroups per CU, fewer if LDS says so): stagger the start of
+        // the first round (the kernel's prologue says why); k = blockIdx >> log2(CUs) needs a power-of-two CU count (MI355X: 256)
+        const int n_cu = eng->prop.multiProcessorCount;
+        const long long per_cu = std::min<long long>(8, (160 * 1024) / (long long)std::max<size_t>(eng->lds_bytes, 1));
+        const bool pow2 = n_cu > 0 && (n_cu & (n_cu - 1)) == 0;
+        while (pow2 && (1 << eng->stagger_shift) < n_cu) ++eng->stagger_shift;
+        // (up to 12 agents: beyond, the workgroups are bound by their agent phases' instruction issue, there is little idle phase to
+        //  fill and the sweep is a wash — large-16ag -3 % at 4 rounds, +4 % at 2)
+        eng->stagger_ticks = (pow2 && N <= 12 && (long long)eng->n_wg >= 2 * per_cu * n_cu) ? 25 : 0;  // x 10 ns per slot (profiles/r04_stagger_sweep.txt)
+        const char *st = getenv("RWARE_STAGGER_TICKS");  // (A/B and test hook: 0 = off, n = ticks whatever the launch size)
+        if (st && *st && pow2) eng->stagger_ticks = std::min(255, std::max(0, atoi(st)));
     }
 
     // device buffers
@@ -1135,6 +1150,7 @@ int rw_get_info(const rw_engine *eng, rw_info *out) {
     out->lds_bytes = (int32_t)eng->lds_bytes;
     out->device_id = eng->cfg.device_id;
     out->compute_units = eng->prop.multiProcessorCount;
+    out->stagger_ticks = eng->stagger_ticks;
     out->specialised = eng->specialised ? 1 : 0;
     out->state_layout = 0;  // (the per-shelf position layout of round 2/3 is gone: with non-temporal observation stores the shadow wins at every batch size)
     out->build_kind = eng->build_kind;

@@ -411,6 +411,22 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                         la_act_stride, la_obs_stride, la_rew_stride, la_term_stride};
     const int op = la.op & 0xff;
     const bool tl_on = (la.op & OP_FLAG_TIMELINE) != 0;  // the flag is preloaded; la.timeline itself is fetched only when set
+    // Start stagger (launches of two or more rounds of workgroups; rw_create decides, bits 16.. of `op`): the workgroups of a launch
+    // start together and stay in lock-step — all stage in, all run their agent phases, all store — so the memory system and the
+    // SIMDs take turns idling, and the second round inherits the rhythm.  The k-th of the first eight workgroups a CU receives
+    // (k = blockIdx / CUs: profiles/tools/placement_probe.hip) waits k * stg ticks of the 100 MHz clock before it begins: their
+    // phases no longer coincide and the rounds behind them keep the offsets.  small-4ag x 65536 envs 16.5 -> 15.0 us per step,
+    // medium-6ag-hard x 65536 26.4 -> 24 (profiles/r04_stagger_sweep.txt); a single round only loses the delay: not staggered.
+    {
+        const int stg = (la.op >> 16) & 0xff;
+        if (RW_RARE(stg != 0)) {
+            const int k = (int)(blockIdx.x >> ((la.op >> 24) & 0xf));
+            if (k > 0 && k < 8) {
+                const uint64_t t0 = wall_clock64();
+                while ((int64_t)(wall_clock64() - t0) < (int64_t)(k * stg)) nap();
+            }
+        }
+    }
     // observation row length: a compile-time constant except with communication bits
     static_assert(kMsg || Cfg::kM == 0, "communication bits need a _MSG observation kind");
     const int M = kMsg ? (Cfg::kM ? Cfg::kM : p.msg_bits) : 0, AM = 1 + M, CW = 7 + M;

@@ -107,6 +107,98 @@ def make_vec(env_id: str, num_envs: int, **kwargs):
     return WarehouseVecEnv(num_envs, **kw)
 
 
+class Pipeline:
+    """One sub-batch of `make_pipelines`: `env` (a WarehouseVecEnv over envs [lo, hi) of the whole batch, output="torch") and the
+    torch `stream` everything of this sub-batch runs on.  `with pipe:` makes that stream torch's current one."""
+
+    def __init__(self, env, stream, lo, hi):
+        self.env, self.stream, self.lo, self.hi = env, stream, lo, hi
+        self._ctx = None
+
+    def __enter__(self):
+        import torch
+
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        return self.env
+
+    def __exit__(self, *exc):
+        ctx, self._ctx = self._ctx, None
+        return ctx.__exit__(*exc)
+
+    def reset(self, seed=None, **kw):
+        """reset of this sub-batch with the seeds its envs have in the whole batch (env i: seed + i)."""
+        with self:
+            return self.env.reset(seed=None if seed is None else int(seed) + self.lo, **kw)
+
+
+def make_pipelines(num_envs: int, n: int = 2, device: int = 0, env_id: str = None, **kwargs):
+    """The batch as `n` independent sub-batches on ONE GPU, each a WarehouseVecEnv(output="torch") on a torch stream of its own —
+    double-buffered sampling: `for pipe in pipes: with pipe as env: actions = policy(obs[pipe]); obs[pipe], *_ = env.step(actions)`.
+    Nothing orders one sub-batch behind another, so the GPU runs the step of one beside the policy (or the step) of the other.
+    Why bother: the workgroups of one step launch run their load / agent / store phases in lock-step and leave the memory system
+    and the SIMDs idle in turns; two free-running half-size launches fill each other's gaps — measured on MI355X, per step of the
+    whole batch: small-10ag x 16384 13.1 -> 10.7 us, large-16ag 18.1 -> 13.4, medium-6ag-hard x 16384 8.9 -> 6.7, small-4ag x 32768
+    10.8 -> 7.0 (profiles/r04_two_pipelines.txt; bench.py `two_pipelines`).  Below ~2048 envs per sub-batch the launches are too
+    short to overlap and the split costs (tiny-2ag x 4096: 4.3 -> 5.3).
+    Returns a list of Pipeline (env, stream, lo, hi); results are identical to one env over the whole batch when sub-batch k is
+    reset with `seed + lo` (Pipeline.reset does that)."""
+    import torch
+
+    from .vector_env import WarehouseVecEnv
+
+    if n < 1 or num_envs % n:
+        raise ValueError(f"num_envs {num_envs} must be a positive multiple of the number of pipelines {n}")
+    kw = env_kwargs(env_id) if env_id else {}
+    kw.update(kwargs)
+    kw.pop("output", None)
+    per = num_envs // n
+    pipes, rejected = [], []
+    for k in range(n):
+        # HIP maps streams onto a handful of hardware queues, and two streams that land on the same queue run one after the other
+        # (measured: two streams created behind two busy ones shared a queue — 19.3 us per step instead of 10.7).  Nothing reports
+        # the mapping, so each new stream is tried against the ones already chosen and replaced if it does not overlap with them.
+        stream = torch.cuda.Stream(device=device)
+        for _ in range(8):
+            if all(streams_overlap(p.stream, stream) for p in pipes):
+                break
+            rejected.append(stream)  # (kept referenced: torch's stream pool then moves on to another one)
+            stream = torch.cuda.Stream(device=device)
+        else:
+            import warnings
+
+            warnings.warn("make_pipelines: no stream found that runs beside the other pipelines' streams; the sub-batches may serialise",
+                          RuntimeWarning, stacklevel=2)
+        with torch.cuda.stream(stream):  # (output="torch": the engine enqueues on torch's current stream at construction)
+            env = WarehouseVecEnv(per, devices=[device], output="torch", **kw)
+        pipes.append(Pipeline(env, stream, k * per, (k + 1) * per))
+    return pipes
+
+
+def streams_overlap(a, b, spin_cycles: int = 600_000) -> bool:
+    """Do two torch streams of one device run side by side?  A spin kernel on `a` alone against one on each: concurrent streams take
+    about the same wall time, streams that share a hardware queue twice as long (~1 ms in all)."""
+    import time
+
+    import torch
+
+    def timed(streams):
+        for s_ in streams:
+            s_.synchronize()
+        t0 = time.perf_counter()
+        for s_ in streams:
+            with torch.cuda.stream(s_):
+                torch.cuda._sleep(spin_cycles)
+        for s_ in streams:
+            s_.synchronize()
+        return time.perf_counter() - t0
+
+    timed([a, b])  # (first use of a stream: queue creation, not part of the comparison)
+    alone = min(timed([a]) for _ in range(2))
+    both = min(timed([a, b]) for _ in range(2))
+    return both < 1.5 * alone
+
+
 def register_gymnasium(override: bool = False) -> int:
     """Attach this engine as the `vector_entry_point` of every rware id (needs real gymnasium >= 1.0)."""
     import gymnasium as gym

@@ -906,3 +906,35 @@ def test_rw_multi_enqueues_every_engine_from_one_call(threads, monkeypatch):
     with pytest.raises(_capi.EngineError):
         multi.step_device([bufs[0].ctypes.data, 0, bufs[2].ctypes.data, bufs[3].ctypes.data])   # a NULL action pointer
     multi.close(); a.close(); b.close()
+
+
+def test_start_stagger_is_a_create_time_rule_and_does_not_change_results(monkeypatch):
+    """Launches of two or more rounds of workgroups (>= 2 x 8 per CU; the emulated device has one CU) stagger the start of the first
+    eight workgroups per CU (rw_info.stagger_ticks x 10 ns per slot; RWARE_STAGGER_TICKS moves the default): a delay, never a
+    different result."""
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    kw["max_steps"] = 11
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    small = rware_amd.WarehouseVecEnv(64, library=LIB, **kw)             # 4 workgroups of 16 envs
+    assert small.engines[0].info.stagger_ticks == 0
+    small.close()
+    monkeypatch.setenv("RWARE_STAGGER_TICKS", "0")
+    off = rware_amd.WarehouseVecEnv(256, library=LIB, **kw)
+    assert off.engines[0].info.stagger_ticks == 0
+    off.close()
+    monkeypatch.setenv("RWARE_STAGGER_TICKS", "40")
+    forced = rware_amd.WarehouseVecEnv(64, library=LIB, **kw)
+    assert forced.engines[0].info.stagger_ticks == 40
+    forced.close()
+    monkeypatch.delenv("RWARE_STAGGER_TICKS")
+    env = rware_amd.WarehouseVecEnv(256, library=LIB, **kw)              # 16 workgroups: two rounds
+    assert env.engines[0].info.stagger_ticks == 25 and env.engines[0].info.n_workgroups == 16
+    orc = OracleVecEnv(256, **kw)
+    assert np.array_equal(env.reset(seed=5)[0], orc.reset(seed=5))
+    rng = np.random.default_rng(6)
+    for t in range(25):
+        a = rng.integers(0, 5, size=(256, 4), dtype=np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+    env.close()

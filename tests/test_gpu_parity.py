@@ -1077,6 +1077,8 @@ def test_runtime_specialisation_policy(tmp_path, monkeypatch):
     B = 65536
     jenv, aenv = rware_amd.WarehouseVecEnv(B, jit=True, **kw4), rware_amd.WarehouseVecEnv(B, **kw4)
     assert jenv.engines[0].info.jit in (1, 2) and aenv.engines[0].info.jit == 0
+    # 4096 workgroups = two rounds of 8 per CU: both launches stagger the start of the first round (a delay, never a different result)
+    assert aenv.engines[0].info.stagger_ticks == 25 and jenv.engines[0].info.stagger_ticks == 25
     orc = OracleVecEnv(B, **dict(kw4, reward_type=rware_amd.enums.enum_value(kw4["reward_type"])))
     o0 = orc.reset(seed=3)
     assert np.array_equal(jenv.reset(seed=3)[0], o0) and np.array_equal(aenv.reset(seed=3)[0], o0)
@@ -1133,3 +1135,96 @@ def test_rw_multi_one_call_steps_eight_engines(threads, monkeypatch):
     if threads == "0":
         assert us_multi < us_loop, (us_multi, us_single, us_loop)
     a.close(); b.close()
+
+
+def test_start_stagger_only_for_launches_of_two_or_more_rounds(monkeypatch):
+    """rw_info.stagger_ticks: 0 at the headline batch (1024 workgroups, 4 per CU) and at a full single round (2048), 25 from two
+    rounds on; RWARE_STAGGER_TICKS moves it.  With and without the stagger the same observations, rewards and state."""
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    for B, want in ((16384, 0), (32768, 0), (65536, 25)):
+        env = rware_amd.WarehouseVecEnv(B, **kw)
+        assert env.engines[0].info.stagger_ticks == want, B
+        env.close()
+    a = rware_amd.WarehouseVecEnv(65536, **kw)
+    monkeypatch.setenv("RWARE_STAGGER_TICKS", "0")
+    b = rware_amd.WarehouseVecEnv(65536, **kw)
+    assert a.engines[0].info.stagger_ticks == 25 and b.engines[0].info.stagger_ticks == 0
+    a.reset(seed=4); b.reset(seed=4)
+    rng = np.random.default_rng(5)
+    for t in range(40):
+        act = rng.integers(0, 5, size=(65536, 4), dtype=np.int32)
+        oa, ra, ta, _, _ = a.step(act)
+        ob, rb, tb, _, _ = b.step(act)
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(ta, tb), t
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    a.close(); b.close()
+
+
+def test_two_pipelines_on_one_device_match_the_single_engine():
+    """Double-buffered sampling (bench.py's `two_pipelines`): the batch as two engines on one device, own streams, stepped
+    CONCURRENTLY by one launcher thread each, against one engine over the whole batch — same observations and state."""
+    import threading
+    import torch
+    kw = rware_amd.env_kwargs("rware-small-10ag-v1")
+    B, N, T = 8192, 10, 48
+    two, one = rware_amd.WarehouseVecEnv(B, devices=[0, 0], **kw), rware_amd.WarehouseVecEnv(B, **kw)
+    assert len(two.engines) == 2
+    two.reset(seed=21); one.reset(seed=21)
+    acts = np.random.default_rng(22).choice(5, size=(T, B, N), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+    full = torch.from_numpy(acts).cuda()
+    halves = [torch.from_numpy(np.ascontiguousarray(acts[:, k * (B // 2):(k + 1) * (B // 2)])).cuda() for k in range(2)]
+
+    def run(k):
+        two.engines[k].step_tape_device(halves[k].data_ptr(), T, 0, T)
+        two.engines[k].sync()
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    one.engines[0].step_tape_device(full.data_ptr(), T, 0, T)
+    one.engines[0].sync()
+    for t in th:
+        t.join()
+    for e in two.engines + one.engines:
+        e.mark_views_stale()
+    sa, sb = two.get_state(), one.get_state()
+    for k in sb:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(two.observations(), one.observations())
+    two.close(); one.close()
+
+
+def test_make_pipelines_closed_loop_equals_the_whole_batch():
+    """rware_amd.make_pipelines: the batch as two sub-batches on torch streams of their own, stepped alternately from one host
+    thread with CUDA action tensors (nothing orders one sub-batch behind the other) — every observation, reward and terminated
+    flag equal to ONE env over the whole batch, step by step."""
+    import torch
+    kw = rware_amd.env_kwargs("rware-small-10ag-v1")
+    kw["max_steps"] = 30
+    B, N, T = 4096, 10, 70
+    pipes = rware_amd.make_pipelines(B, 2, **kw)
+    ref = rware_amd.WarehouseVecEnv(B, **kw)
+    assert [(p.lo, p.hi) for p in pipes] == [(0, 2048), (2048, 4096)] and pipes[0].stream != pipes[1].stream
+    o_ref = ref.reset(seed=50)[0]
+    o0 = [p.reset(seed=50)[0] for p in pipes]
+    with pipes[0]:
+        a0 = o0[0].cpu().numpy()
+    with pipes[1]:
+        a1 = o0[1].cpu().numpy()
+    assert np.array_equal(np.concatenate([a0, a1]), o_ref)
+    acts = np.random.default_rng(51).choice(5, size=(T, B, N), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+    dev = [[torch.from_numpy(np.ascontiguousarray(acts[t, p.lo:p.hi])).cuda() for t in range(T)] for p in pipes]
+    torch.cuda.synchronize()
+    for t in range(T):
+        got = []
+        for k, p in enumerate(pipes):
+            with p as env:
+                obs, rew, term, _, _ = env.step(dev[k][t])
+                got.append((obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()))   # (stream-ordered copies on the pipeline's stream)
+        o2, r2, d2, _, _ = ref.step(acts[t])
+        assert np.array_equal(np.concatenate([g[0] for g in got]), o2), t
+        assert np.array_equal(np.concatenate([g[1] for g in got]), r2) and np.array_equal(np.concatenate([g[2] for g in got]), d2), t
+    for p in pipes:
+        p.env.close()
+    ref.close()
