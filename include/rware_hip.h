@@ -306,7 +306,7 @@ typedef struct rw_info {
                                   cell) + packed agent records r/w + actions + queue + counters / flags + observation + rewards +
                                   terminated (+ messages r/w, IMAGE_DICT features).  The PMC traffic of a step is checked against
                                   it; bench.py prices `frac_engine` on it (<= 1 by construction)                               */
-    int32_t stagger_ticks;     /* > 0: the launch is two or more rounds of workgroups and the k-th of the first eight workgroups a CU
+    int32_t stagger_ticks;     /* > 0: the launch is two or more rounds of workgroups (and <= 12 agents) and the k-th of the first eight workgroups a CU
                                   receives starts k * stagger_ticks * 10 ns late, so that the rounds do not run their load / compute /
                                   store phases in lock-step (env RWARE_STAGGER_TICKS=n moves the default; 0 = off) */
     int32_t reserved[3];
