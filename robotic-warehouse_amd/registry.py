@@ -175,6 +175,61 @@ def make_pipelines(num_envs: int, n: int = 2, device: int = 0, env_id: str = Non
     return pipes
 
 
+class _CapturedPipelines:
+    """What capture_pipelines returns: `steps` (policy, step) rounds of every pipeline in ONE HIP graph, the pipelines side by side."""
+
+    def __init__(self, graph, origin, pipes, keep, steps):
+        self.graph, self.stream, self.pipes, self._keep, self.steps = graph, origin, pipes, keep, steps
+
+    def replay(self):
+        import torch
+
+        for p in self.pipes:                       # behind whatever the pipelines have enqueued so far
+            self.stream.wait_stream(p.stream)
+        with torch.cuda.stream(self.stream):
+            self.graph.replay()
+        for p in self.pipes:                       # and their next eager work behind the replay
+            p.stream.wait_stream(self.stream)
+            p.env.engines[0].mark_views_stale()    # (the replayed steps ran without host code)
+
+
+def capture_pipelines(pipes, policy, steps: int = 1, warmup: int = 2):
+    """`steps` rounds of `actions = policy(obs, rewards, terminated); env.step(actions)` for EVERY pipeline of make_pipelines, captured in
+    one HIP graph with one branch per pipeline (fork and join by events, nothing between the branches): on replay the GPU runs the
+    policy of one sub-batch beside the step of the other with no host code in the loop.  `policy` as for WarehouseVecEnv.capture_loop
+    (capturable, returns integer CUDA actions of its sub-batch); it is called `warmup` times per pipeline eagerly first.
+    Returns an object with `.replay()`, `.graph` and `.stream` (the stream the graph is launched on)."""
+    import torch
+
+    dev = pipes[0].stream.device
+    origin = torch.cuda.Stream(device=dev)
+    views = []
+    for p in pipes:
+        env = p.env
+        v = env._torch_views()
+        views.append((env._obs_of(v), v["rewards"], v["terminated_bool"]))
+        with torch.cuda.stream(p.stream):
+            for _ in range(max(0, int(warmup))):
+                policy(*views[-1])
+            p.stream.synchronize()
+        origin.wait_stream(p.stream)
+    keep = []
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=origin):
+        for p in pipes:
+            p.stream.wait_stream(origin)           # fork: the pipeline's stream joins the capture
+        for p, (obs, rew, term) in zip(pipes, views):
+            env = p.env
+            with torch.cuda.stream(p.stream):
+                for _ in range(int(steps)):
+                    a = env._device_actions(policy(obs, rew, term), env.num_envs, 0)
+                    keep.append(a)                 # (allocated from the graph's private pool: alive as long as the graph is)
+                    env.engines[0].step_device(a.data_ptr())
+        for p in pipes:
+            origin.wait_stream(p.stream)           # join
+    return _CapturedPipelines(g, origin, list(pipes), keep, int(steps))
+
+
 def streams_overlap(a, b, spin_cycles: int = 600_000) -> bool:
     """Do two torch streams of one device run side by side?  A spin kernel on `a` alone against one on each: concurrent streams take
     about the same wall time, streams that share a hardware queue twice as long (~1 ms in all)."""

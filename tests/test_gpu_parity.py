@@ -1228,3 +1228,49 @@ def test_make_pipelines_closed_loop_equals_the_whole_batch():
     for p in pipes:
         p.env.close()
     ref.close()
+
+
+def test_capture_pipelines_replays_what_the_eager_pipelines_do():
+    """rware_amd.capture_pipelines: (policy, step) rounds of both pipelines in ONE HIP graph, a branch per pipeline — after the
+    replay every env is where the same rounds issued eagerly (and where ONE env over the whole batch) put it."""
+    import torch
+    kw = rware_amd.env_kwargs("rware-small-6ag-v1")
+    B, R = 2048, 24
+    W = (torch.arange(71 * 5, device="cuda", dtype=torch.float32).reshape(71, 5) % 7 - 3.0) * 0.25
+
+    def policy(obs, rew, term):
+        return (obs @ W).argmax(-1).to(torch.int32)
+
+    cap, eag = rware_amd.make_pipelines(B, 2, **kw), rware_amd.make_pipelines(B, 2, **kw)
+    one = rware_amd.WarehouseVecEnv(B, output="torch", **kw)
+    for p in cap + eag:
+        p.reset(seed=11)
+    o1 = one.reset(seed=11)[0]
+    graph = rware_amd.capture_pipelines(cap, policy, steps=R)
+    graph.replay()
+    oe = [None, None]
+    for k, p in enumerate(eag):
+        with p as env:
+            v = env._torch_views()
+            obs, rew, term = env._obs_of(v), v["rewards"], v["terminated_bool"]
+            for _ in range(R):
+                obs, rew, term, _, _ = env.step(policy(obs, rew, term))
+            oe[k] = obs
+    rew1 = torch.zeros((B, 6), device="cuda"); term1 = torch.zeros((B,), dtype=torch.bool, device="cuda")
+    for _ in range(R):
+        o1, rew1, term1, _, _ = one.step(policy(o1, rew1, term1))
+    torch.cuda.synchronize()
+    for k in range(2):
+        sc, se = cap[k].env.get_state(), eag[k].env.get_state()
+        for name in se:
+            assert np.array_equal(sc[name], se[name]), (k, name)
+        assert torch.equal(cap[k].env._obs_of(cap[k].env._torch_views()), oe[k])
+    whole = torch.cat([cap[k].env._obs_of(cap[k].env._torch_views()) for k in range(2)])
+    assert torch.equal(whole, o1)
+    graph.replay()                                   # a second replay continues from there, and eager steps still work after it
+    with cap[0] as env:
+        env.step(torch.zeros((B // 2, 6), dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    for p in cap + eag:
+        p.env.close()
+    one.close()
