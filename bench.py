@@ -627,7 +627,10 @@ def main():
             if not args.no_hbm_regime:
                 out["hbm_regime"] = hbm_regime_leg(torch, rware_amd, local_rank, args.env_id, sha)
             if not args.no_api_loop:
-                out["two_pipelines"] = two_pipelines_leg(torch, rware_amd, local_rank, args.env_id, B)
+                try:  # (an extra: never at the price of the line)
+                    out["two_pipelines"] = two_pipelines_leg(torch, rware_amd, local_rank, args.env_id, B)
+                except Exception as exc:  # noqa: BLE001
+                    out["two_pipelines"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.env_id)
         print(json.dumps(out), flush=True)
