@@ -136,3 +136,13 @@ def test_bench_rank_placement_partitions_physical_cores_per_numa_node(monkeypatc
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {0, 32})
     p = bench.pin_rank(FakeTorch, 1, 8, lambda k: k)
     assert p["pinned"] is False and "physical cores" in p["why"]
+
+
+def test_make_pipelines_checks_its_arguments_before_touching_a_device():
+    """rware_amd.make_pipelines(num_envs, n): the batch has to split evenly (the GPU side is covered by the -m gpu tests)."""
+    with pytest.raises(ValueError):
+        rware_amd.make_pipelines(10, 3, env_id="rware-tiny-2ag-v1")
+    with pytest.raises(ValueError):
+        rware_amd.make_pipelines(16, 0, env_id="rware-tiny-2ag-v1")
+    p = rware_amd.Pipeline(env="e", stream="s", lo=8, hi=16)
+    assert (p.env, p.stream, p.lo, p.hi) == ("e", "s", 8, 16)
