@@ -2,6 +2,7 @@
     python profiles/tools/split_probe.py [env_id] [B] [M ...]
 Each engine steps its B / M envs K times from a device action tape (rw_step_tape_device: a C loop of launches on the engine's own
 stream, GIL released); wall clock from the first enqueue to the last sync.  M = 1 is the ordinary engine."""
+import os
 import sys
 import threading
 import time
@@ -16,6 +17,8 @@ env_id = sys.argv[1] if len(sys.argv) > 1 else "rware-small-4ag-v1"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 Ms = [int(x) for x in sys.argv[3:]] or [1, 2, 4]
 kw = rware_amd.env_kwargs(env_id)
+if os.environ.get("SPLIT_SENSOR_RANGE"):   # (BASELINE config 5: rware-large-16ag-v1 with sensor_range 2)
+    kw["sensor_range"] = int(os.environ["SPLIT_SENSOR_RANGE"])
 N = kw["n_agents"]
 K, T = 4000, 64
 for M in Ms:
