@@ -97,7 +97,14 @@ enum rw_stream_flags {
      * runs (rw_info.jit, rw_jit_log say what happened).  RW_JIT_OFF: never.  RW_JIT_FORCE: always — small batches and shapes
      * that have an ahead-of-time build included (tests, A/B).  (Also RWARE_JIT=off|force in the environment.) */
     RW_JIT_OFF = 8,
-    RW_JIT_FORCE = 16
+    RW_JIT_FORCE = 16,
+    /* The chunk-pipelined persistent build of the per-step kernel (round 5): instead of one workgroup per chunk of envs, as many
+     * workgroups as the GPU holds at once walk the chunks, the agent phases of the next chunk running beside the observation stores
+     * of the current one and the chunk after that already on its way into LDS.  Exists for the BASELINE shapes and the agent-count-
+     * static small / large warehouses (rware_static_table.h, group 18); rw_create uses it where it was measured faster
+     * (rw_info.pipe_workgroups != 0).  RW_PIPE_OFF: never.  RW_PIPE_ON: wherever a build exists.  (Also RWARE_PIPE=0|1.) */
+    RW_PIPE_OFF = 32,
+    RW_PIPE_ON = 64
 };
 
 /* Device buffers (all env-major, C-contiguous).  Replaces the attributes callers read off the
@@ -309,7 +316,9 @@ typedef struct rw_info {
     int32_t stagger_ticks;     /* > 0: the launch is two or more rounds of workgroups (and <= 12 agents) and the k-th of the first eight workgroups a CU
                                   receives starts k * stagger_ticks * 10 ns late, so that the rounds do not run their load / compute /
                                   store phases in lock-step (env RWARE_STAGGER_TICKS=n moves the default; 0 = off) */
-    int32_t reserved[3];
+    int32_t pipe_envs_per_workgroup; /* != 0: rw_step* launches run the chunk-pipelined persistent build with chunks of this many envs ... */
+    int32_t pipe_workgroups;         /* ... on this many persistent workgroups (rw_stream_flags RW_PIPE_ON / RW_PIPE_OFF)              */
+    int32_t reserved[1];
 } rw_info;
 int rw_get_info(const rw_engine *eng, rw_info *out);
 /* what the run-time specialisation did for this engine: cache file / compile time, or why it is not in use ("" if not tried) */

@@ -29,6 +29,7 @@ BUF_DTYPE = {
 RW_STREAM_USE_GIVEN = 1  # rw_stream_flags: `stream` is taken literally, NULL == the device's default stream
 RW_OBS_STORES_CACHED, RW_OBS_STORES_STREAM = 2, 4  # rw_stream_flags: keep the observation lines cached / force the non-temporal hint
 RW_JIT_OFF, RW_JIT_FORCE = 8, 16  # rw_stream_flags: run-time specialisation (hipRTC) never / always; default: shapes without an exact build, B >= 4096
+RW_PIPE_OFF, RW_PIPE_ON = 32, 64  # rw_stream_flags: the chunk-pipelined persistent per-step kernel never / wherever a build exists; default: the engine's measured rule
 
 AUTORESET = {"disabled": 0, None: 0, "next_step": 1, "same_step": 2}
 
@@ -50,7 +51,8 @@ class RwInfo(C.Structure):
         "compute_units", "specialised", "state_layout", "build_kind")] + [
         ("algorithmic_bytes_per_env_step", C.c_int64),
         ("device_name", C.c_char * 128), ("arch_name", C.c_char * 64), ("obs_stores_stream", C.c_int32), ("jit", C.c_int32),
-        ("engine_bytes_per_env_step", C.c_int64), ("stagger_ticks", C.c_int32), ("reserved", C.c_int32 * 3)]
+        ("engine_bytes_per_env_step", C.c_int64), ("stagger_ticks", C.c_int32), ("pipe_envs_per_workgroup", C.c_int32),
+        ("pipe_workgroups", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 EXPORTS = (
@@ -173,7 +175,7 @@ class Engine:
                  max_inactivity_steps, max_steps, reward_type, normalised_coordinates=False,
                  autoreset_mode="next_step", device_id=0, envs_per_workgroup=0,
                  threads_per_workgroup=0, stream=None, library=None, observation_type=1,
-                 image_layers=(), image_directional=True, msg_bits=0, use_given_stream=False, obs_stores=None, jit=None):
+                 image_layers=(), image_directional=True, msg_bits=0, use_given_stream=False, obs_stores=None, jit=None, pipe=None):
         self.lib = load(library)
         self._h = C.c_void_p()
         self._arena, self.arena_allocations = {}, 0  # rollout_host's device tapes (grow-only; freed in close())
@@ -187,7 +189,8 @@ class Engine:
             int(observation_type), int(bool(image_directional)), len(image_layers),
             (C.c_int32 * 8)(*[int(l) for l in image_layers]), int(msg_bits),
             (RW_STREAM_USE_GIVEN if use_given_stream else 0) | {None: 0, "auto": 0, "cached": RW_OBS_STORES_CACHED, "stream": RW_OBS_STORES_STREAM}[obs_stores]
-            | {None: 0, "auto": 0, False: RW_JIT_OFF, "off": RW_JIT_OFF, True: RW_JIT_FORCE, "force": RW_JIT_FORCE}[jit],
+            | {None: 0, "auto": 0, False: RW_JIT_OFF, "off": RW_JIT_OFF, True: RW_JIT_FORCE, "force": RW_JIT_FORCE}[jit]
+            | {None: 0, "auto": 0, False: RW_PIPE_OFF, "off": RW_PIPE_OFF, True: RW_PIPE_ON, "on": RW_PIPE_ON}[pipe],
             hw.ctypes.data, goals.ctypes.data, C.c_void_p(stream or 0))
         rc = self.lib.rw_create(C.byref(cfg), C.byref(self._h))
         if rc != RW_OK:

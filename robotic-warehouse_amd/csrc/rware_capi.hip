@@ -57,6 +57,12 @@ struct rw_engine {
     void (*kernel)(const rw::Params *, const int32_t *, const int32_t, const int32_t, float *, float *, uint8_t *, const uint8_t *, uint64_t *, const int64_t, const int64_t, const int64_t, const int64_t) = nullptr;  // the step kernel instance this engine launches
     void (*kernel_rollout)(const rw::Params *, const int32_t *, const int32_t, const int32_t, float *, float *, uint8_t *, const uint8_t *, uint64_t *, const int64_t, const int64_t, const int64_t, const int64_t) = nullptr;  // its fused multi-step (rollout) sibling
     rw_tab::step_kernel_t kernel_nt = nullptr;  // the per-step kernel with non-temporal observation stores, where the build has one
+    // the chunk-pipelined persistent build of this shape (rware_kernels.h "PIPE"), where the table has one and rw_create's rule (or
+    // the caller: RW_PIPE_ON / RW_PIPE_OFF) wants it: OP_STEP launches go through it — `pipe_grid` persistent workgroups walk the
+    // B / pipe_E chunks — everything else (reset, refresh, fused rollouts) through the classic kernels on the same state
+    rw_tab::step_kernel_t pipe_kernel = nullptr;
+    int pipe_E = 0, pipe_grid = 0;
+    size_t pipe_lds = 0;
     rw::Params *d_prm = nullptr;  // device copy of `prm` (constant for the engine's lifetime)
     rw::LaunchArgs la{};          // per-launch defaults: the engine's own output buffers
     bool specialised = false;
@@ -123,7 +129,8 @@ const StaticEntry *static_group(int group, int *n) {
     using fn_t = const StaticEntry *(*)(int *);
     static const fn_t kGroups[kStaticGroups] = {static_group_0,  static_group_1,  static_group_2,  static_group_3,  static_group_4,  static_group_5,
                                                 static_group_6,  static_group_7,  static_group_8,  static_group_9,  static_group_10, static_group_11,
-                                                static_group_12, static_group_13, static_group_14, static_group_15, static_group_16, static_group_17};
+                                                static_group_12, static_group_13, static_group_14, static_group_15, static_group_16, static_group_17,
+                                                static_group_18};
     return kGroups[group](n);
 }
 }  // namespace rw_tab
@@ -131,12 +138,23 @@ namespace {
 
 int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     la.op = op | (la.timeline ? rw::OP_FLAG_TIMELINE : 0);
-    la.op |= (eng->stagger_ticks & 0xff) << 16 | (eng->stagger_shift & 0xf) << 24;
+    const bool pipe = eng->pipe_kernel && op == rw::OP_STEP && !rollout;  // (persistent workgroups: no start stagger)
+    if (!pipe) la.op |= (eng->stagger_ticks & 0xff) << 16 | (eng->stagger_shift & 0xf) << 24;
     if (op != rw::OP_OBS) eng->grid_stale = eng->agents_stale = eng->counters_stale = true;  // the kernels keep the shadow and the packed agent records current, not the int32 views
     if (!eng->own_stream && !eng->captured) {  // (a stream of the caller's may be capturing; the engine's own stream never is)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(eng->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) eng->captured = true;
         else (void)hipGetLastError();
+    }
+    if (pipe) {
+        if (start || stop)
+            hipExtLaunchKernelGGL(eng->pipe_kernel, dim3(eng->pipe_grid), dim3(256), eng->pipe_lds, eng->stream, start, stop, 0,
+                                  (const rw::Params *)eng->d_prm, RW_LAUNCH_ARGS(la));
+        else
+            hipLaunchKernelGGL(eng->pipe_kernel, dim3(eng->pipe_grid), dim3(256), eng->pipe_lds, eng->stream,
+                               (const rw::Params *)eng->d_prm, RW_LAUNCH_ARGS(la));
+        RW_HIP(eng, hipGetLastError());
+        return RW_OK;
     }
     if (eng->jit_step) {  // a run-time specialised build: the same launch through the module API
         const rw::Params *cp = eng->d_prm;
@@ -444,7 +462,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             const StaticEntry *tab = rw_tab::static_group(grp, &n_se);
             for (int k_se = 0; k_se < n_se; ++k_se) {
                 const StaticEntry &se = tab[k_se];
-                if ((se.N != 0) != (exact != 0)) continue;
+                if ((se.N != 0) != (exact != 0) || se.pipe) continue;
                 if (se.image != (eng->image ? 1 : 0) || se.M != eng->msg_bits) continue;
                 if (se.NL > 0) {  // a baked-in layer list serves exactly that list
                     uint32_t packed = 0;
@@ -592,6 +610,53 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         eng->stagger_ticks = (pow2 && N <= 12 && (long long)eng->n_wg >= 2 * per_cu * n_cu) ? 25 : 0;  // x 10 ns per slot (profiles/r04_stagger_sweep.txt)
         const char *st = getenv("RWARE_STAGGER_TICKS");  // (A/B and test hook: 0 = off, n = ticks whatever the launch size)
         if (st && *st && pow2) eng->stagger_ticks = std::min(255, std::max(0, atoi(st)));
+    }
+
+    {
+        // The chunk-pipelined persistent build (rware_kernels.h "PIPE").  Candidate: a `pipe` entry of the table with this shape whose
+        // chunk size divides the batch (first match; RWARE_PIPE_E picks a geometry).  Whether it runs: the caller's RW_PIPE_ON /
+        // RW_PIPE_OFF, else RWARE_PIPE=1|0 in the environment (A/B runs), else the measured rule below.
+        int mode = 0;  // 0 rule, -1 off, 1 on
+        const char *pe = getenv("RWARE_PIPE");
+        if (pe && pe[0] == '0') mode = -1;
+        if (pe && pe[0] == '1') mode = 1;
+        if (cfg->stream_flags & RW_PIPE_OFF) mode = -1;
+        if (cfg->stream_flags & RW_PIPE_ON) mode = 1;
+        const char *pee = getenv("RWARE_PIPE_E");
+        const int want_e = pee ? atoi(pee) : 0;
+        const StaticEntry *pb = nullptr;
+        if (mode >= 0 && !eng->image && eng->msg_bits == 0 && !eng->jit_step)
+            for (int grp = 0; grp < rw_tab::kStaticGroups && !pb; ++grp) {
+                int n_se = 0;
+                const StaticEntry *tab = rw_tab::static_group(grp, &n_se);
+                for (int k_se = 0; k_se < n_se && !pb; ++k_se) {
+                    const StaticEntry &se = tab[k_se];
+                    if (!se.pipe || se.H != H || se.W != W || se.S != S || se.R != R || se.N != N) continue;
+                    if (!(se.Q == Q || (se.Q < 0 && Q <= 2 * se.N)) || B % se.E != 0 || (want_e && se.E != want_e)) continue;
+                    pb = &se;
+                }
+            }
+        if (pb) {
+            const int n_cu = eng->prop.multiProcessorCount;
+            const int n_chunks = B / pb->E;
+            const size_t lds = 2 * sizeof(int32_t) * (size_t)rw::make_lds_layout(pb->E, N, pb->Q < 0 ? 2 * N : Q, HW, SW, eng->OW, cell_bytes, AM).total;
+            step_kernel_t fn = nt_rule(pb->E) ? pb->fn_nt : pb->fn;
+            hipError_t pe_ = lds > 64 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;
+            int per_cu = 0;
+            if (pe_ == hipSuccess) pe_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(fn), 256, lds);
+            if (pe_ != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 0; }
+            const char *pw = getenv("RWARE_PIPE_WGS_PER_CU");  // (A/B hook: fewer resident workgroups, more chunks each)
+            if (pw && atoi(pw) > 0) per_cu = std::min(per_cu, atoi(pw));
+            const long long grid = std::min<long long>(n_chunks, (long long)per_cu * n_cu);
+            // the rule (profiles/EXPERIMENTS.md, round 5): pipelining needs at least two chunks per workgroup
+            const bool rule = false;
+            if (lds <= 160 * 1024 && grid >= 1 && (mode == 1 || (mode == 0 && rule && n_chunks >= 2 * grid))) {
+                eng->pipe_kernel = fn;
+                eng->pipe_E = pb->E;
+                eng->pipe_grid = (int)grid;
+                eng->pipe_lds = lds;
+            }
+        }
     }
 
     // device buffers
@@ -852,11 +917,12 @@ int rw_step_many_device(rw_engine *eng, const int32_t *actions_dev, int32_t n_st
 int rw_debug_timeline(rw_engine *eng, const int32_t *actions_dev, uint64_t *host_out, int32_t *n_workgroups, int32_t *n_marks) {
     // One OP_STEP launch with per-workgroup phase stamps (wall_clock64, 100 MHz); profiling aid only.
     if (!eng || !actions_dev) return RW_ERR_INVALID_ARG;
-    if (n_workgroups) *n_workgroups = eng->n_wg;
+    const int n_launched = eng->pipe_kernel ? eng->pipe_grid : eng->n_wg;  // (the pipelined build: one row per persistent workgroup)
+    if (n_workgroups) *n_workgroups = n_launched;
     if (n_marks) *n_marks = rw::TL_MARKS;
     if (!host_out) return RW_OK;
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
-    const size_t bytes = sizeof(uint64_t) * (size_t)eng->n_wg * rw::TL_MARKS;
+    const size_t bytes = sizeof(uint64_t) * (size_t)n_launched * rw::TL_MARKS;
     uint64_t *d = nullptr;
     RW_HIP(eng, hipMalloc(&d, bytes));
     RW_HIP(eng, hipMemsetAsync(d, 0, bytes, eng->stream));
@@ -1151,6 +1217,8 @@ int rw_get_info(const rw_engine *eng, rw_info *out) {
     out->device_id = eng->cfg.device_id;
     out->compute_units = eng->prop.multiProcessorCount;
     out->stagger_ticks = eng->stagger_ticks;
+    out->pipe_envs_per_workgroup = eng->pipe_kernel ? eng->pipe_E : 0;
+    out->pipe_workgroups = eng->pipe_kernel ? eng->pipe_grid : 0;
     out->specialised = eng->specialised ? 1 : 0;
     out->state_layout = 0;  // (the per-shelf position layout of round 2/3 is gone: with non-temporal observation stores the shadow wins at every batch size)
     out->build_kind = eng->build_kind;

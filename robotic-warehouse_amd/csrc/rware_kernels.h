@@ -69,6 +69,8 @@
 // sequential run of code (every launch starts with a cold instruction cache: a taken branch over a big rare block is a
 // fetch miss for the first wavefront that gets there)
 #define RW_RARE(c) __builtin_expect(!!(c), 0)
+// RW_INLINE: a lambda whose body goes into its caller before any optimisation runs (the pipelined flow's helpers)
+#define RW_INLINE __attribute__((always_inline))
 
 namespace rw {
 
@@ -241,14 +243,19 @@ struct DynamicCfg {
     static constexpr int kNT = -1;   // observation stores: cached or non-temporal by Params::nt_obs, at run time
     static constexpr int kNL = 0, kDirectional = -1;
     static constexpr uint32_t kLayers = 0;
+    static constexpr int kPipe = 0;
 };
 // M_: communication bits (the _MSG kernels).  NL_ / LAYERS_ / DIR_ (IMAGE kernels): a layer list baked in — NL_ layer ids,
 // 4 bits each, first layer in the low nibble — and the `image_observation_directional` switch; NL_ == 0: any list, at run time.
 // NT_: how the observation stream is stored — 0 cached, 1 with the non-temporal hint (two builds of the per-step kernel, picked
 // by rw_create), -1 by Params::nt_obs at run time (the size-static builds: two copies of the expansion pass in one kernel
 // cost 2 % at the headline batch and 9 % past the Infinity Cache, measured, so the exact builds do not do that).
-template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_, int M_ = 0, int NL_ = 0, uint32_t LAYERS_ = 0, int DIR_ = -1, int NT_ = 0>
+// PIPE_: 1 = the chunk-pipelined persistent build of the per-step kernel ("PIPE" in rware_step_kernel): a workgroup walks the
+// chunks blockIdx, blockIdx + gridDim, ... through two LDS chunk buffers — wavefront 0 runs the agent phases of chunk c + 1 while
+// wavefronts 1 and 2 expand and store the observation of chunk c and wavefront 3 stages chunk c + 2 in.
+template <int H_, int W_, int N_, int Q_, int S_, int E_, int T_, int M_ = 0, int NL_ = 0, uint32_t LAYERS_ = 0, int DIR_ = -1, int NT_ = 0, int PIPE_ = 0>
 struct StaticCfg {
+    static constexpr int kPipe = PIPE_;
     static constexpr int kNT = N_ == 0 ? -1 : NT_;
     // Q_ < 0 (with N_ != 0): an "agent-count-static" build — everything of an exact-shape build except the request-queue
     // length, which is read at run time (any Q <= 2 N_: the easy / normal / hard variants of a task and custom queue sizes
@@ -406,6 +413,18 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     constexpr int WIN = 2 * R + 1, CELLS = WIN * WIN, L0 = 8 + 7 * CELLS, OW0 = (L0 + 31) / 32;
     constexpr bool kImage = (kObs == OBS_IMAGE || kObs == OBS_IMAGE_MSG);
     constexpr bool kMsg = (kObs == OBS_FLATTENED_MSG || kObs == OBS_IMAGE_MSG);  // actions are [Action, message bits...]
+    // PIPE — the chunk-pipelined persistent build (OP_STEP launches of exact-shape / agent-count-static FLATTENED kernels).  The
+    // phases below stay in program order; the step loop further down becomes a loop over the workgroup's chunks, and because
+    // wavefront 0 has no part in the expansion at the bottom of the loop body it falls through to the top and runs the agent
+    // phases of the NEXT chunk (other LDS buffer) while wavefronts 1 and 2 are still storing the observation of this one:
+    //     wavefront 0     AG(c)            | A | gather(c)                  | B | AG(c + 1) ...
+    //     wavefronts 1,2                   | A | gather(c)                  | B | expand + store(c)
+    //     wavefront 3     wait for DMA     | A | self bits, write-back(c)   | B | clear scratch, stage chunk c + 2 in (LDS-DMA)
+    // Two barriers per chunk (A, B), both LDS-only for everybody but the DMA issuer: nobody waits for observation stores.
+    constexpr bool kPipe = Cfg::kPipe != 0;
+    static_assert(!kPipe || (Cfg::kE != 0 && Cfg::kN >= 1 && Cfg::kN <= 19 && Cfg::kT == 256 && !kRollout && kObs == OBS_FLATTENED),
+                  "the pipelined build: exact-shape or agent-count-static, FLATTENED, 256 threads, per-step");
+    static_assert(!kPipe || Cfg::kE <= 64 / (Cfg::kN ? Cfg::kN : 1), "the pipelined build runs the agent phases of a chunk on ONE wavefront");
     const Params &p = *cp;  // constant per engine, device-resident, L2-warm
     const LaunchArgs la{la_actions, la_op, la_n_steps, la_obs, la_rewards, la_terminated, la_reset_mask, la_timeline,
                         la_act_stride, la_obs_stride, la_rew_stride, la_term_stride};
@@ -440,7 +459,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     int lane = tid & 63, wave = tid >> 6;
     const int nw = T >> 6;
     const int E = Cfg::kE ? Cfg::kE : p.envs_per_wg;
-    const int e0 = blockIdx.x * E;
+    int e0 = blockIdx.x * E;
     const int ne = Cfg::kE ? E : min(E, p.B - e0);  // the static kernels are only launched with B % E == 0
     if (ne <= 0) return;
     const int N = Cfg::kN ? Cfg::kN : p.N, Q = (Cfg::kN && !Cfg::kQrt) ? Cfg::kQ : p.Q;
@@ -509,7 +528,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     // wavefront 3 = service wave after the agent phases (see WB); pays off while the observation of a workgroup is
     // small enough that three wavefronts expand it as fast as the stores drain (measured: small-4ag 8.91 -> 8.79 us,
     // fused 4.93 -> 4.56; medium-6ag-hard 8.56 -> 8.40; large-16ag r=2 with 23 K floats per workgroup 43.6 -> 46.1, so not there)
-    const bool split = nw == 4 && nea * (kImage ? k_n_layers * CELLS : L) <= 8192;
+    const bool split = kPipe || (nw == 4 && nea * (kImage ? k_n_layers * CELLS : L) <= 8192);
     const int TW = split ? T - 64 : T;        // threads that gather window rows and expand the observation
     const uint32_t mN = Cfg::kN ? rw_magic18(Cfg::kN) : p.magic_n;
     // optional per-workgroup phase stamps (100 MHz wall clock); one scalar branch per mark when off
@@ -524,6 +543,8 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     RW_MARK(TL_START);
 
     const LdsLayout lo = make_lds_layout(E, N, QL, HW, SW, OW, (int)sizeof(CellT), AM);
+    // every per-chunk array hangs off one base (PIPE: two chunk buffers of lo.total dwords each, re-bound per chunk: bind_lds)
+    int32_t *sm = smem;
     CellT *s_gs = reinterpret_cast<CellT *>(smem + lo.gs);
     uint8_t *s_ga = reinterpret_cast<uint8_t *>(smem + lo.ga);
     int32_t *s_ax = smem + lo.ax, *s_ay = smem + lo.ay, *s_dir = smem + lo.dir;
@@ -539,6 +560,25 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     uint32_t *s_obits = reinterpret_cast<uint32_t *>(smem + lo.obits);
     int32_t *s_envi = smem + lo.envi;
     int32_t *s_misc = smem + lo.misc;
+    auto bind_lds = [&](int32_t *base) RW_INLINE {
+        sm = base;
+        s_gs = reinterpret_cast<CellT *>(base + lo.gs);
+        s_ga = reinterpret_cast<uint8_t *>(base + lo.ga);
+        s_ax = base + lo.ax; s_ay = base + lo.ay; s_dir = base + lo.dir;
+        s_carry = base + lo.carry; s_deliv = base + lo.deliv; s_act = base + lo.act;
+        s_tgt = base + lo.tgt; s_nxt = base + lo.nxt; s_depth = base + lo.depth; s_win = base + lo.win;
+        s_rew = reinterpret_cast<float *>(base + lo.rew);
+        s_mv = base + lo.mv; s_msg = base + lo.msg;
+        s_xy = base + lo.tgt;
+        s_fx = reinterpret_cast<float *>(base + lo.fx); s_fy = reinterpret_cast<float *>(base + lo.fy);
+        s_queue = base + lo.queue;
+        s_req = reinterpret_cast<uint32_t *>(base + lo.req);
+        s_hw = reinterpret_cast<const uint32_t *>(base + lo.hw);
+        s_obits = reinterpret_cast<uint32_t *>(base + lo.obits);
+        s_envi = base + lo.envi;
+        s_misc = base + lo.misc;
+    };
+    (void)sm; (void)bind_lds;
     auto on_highway = [&](int c) -> bool { return (s_hw[c >> 5] >> (c & 31)) & 1u; };
     auto coordf = [&](int k, int v) -> float {
         if (k_normalised) return (float)((double)v / (double)((k == 0 ? W : H) - 1));  // :636-638
@@ -583,7 +623,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     constexpr int KMW = (kMsg && Cfg::kM) ? Cfg::kM : 1;
     int r_mw[KMW] = {};   // the action's message words (_MSG builds), r_msg: the agent's stored message
     int r_msg = 0;
-    if constexpr (kDirect) {
+    if constexpr (kDirect && !kPipe) {
         constexpr int KN = Cfg::kN, KG = 64 / KN;
         static_assert(Cfg::kE <= (Cfg::kT / 64) * KG, "every env of the chunk needs its own agent lanes");
         const int g = lane / KN, a_idx = lane - g * KN, le = wave * KG + g;
@@ -632,7 +672,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     // kEarly (exact-shape per-step kernels): the agent wavefront does not take part in the stage-in DMA; its record loads
     // were the first thing it issued, so they are back while the other wavefronts' DMA is still in flight — it computes
     // intent and occupant in that window, before the barrier that everything else of the agent phases has to wait for.
-    constexpr bool kEarly = kDirect && !kRollout && Cfg::kT >= 128;
+    constexpr bool kEarly = kDirect && !kRollout && Cfg::kT >= 128 && !kPipe;
 #ifndef RW_AB_DMA_FIRST
 #define RW_AB_DMA_FIRST 0  // A/B hook (profiles/tools/ab.sh)
 #endif
@@ -648,6 +688,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             s_ax[i] = c - y * W; s_ay[i] = y; s_dir[i] = rec_dir(r); s_carry[i] = rec_carry(r); s_deliv[i] = rec_deliv(r);
         }
     };
+    if constexpr (!kPipe) {
     if constexpr (!kDmaFirst) clear_scratch();  // before the DMA: hipcc orders any later LDS write behind an in-flight LDS-DMA (vmcnt)
     RW_MARK(TL_ZEROED);
     if constexpr (Cfg::kE != 0) {
@@ -771,6 +812,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     keep_sgpr(k_reward_type, k_max_inactivity, k_max_steps, k_autoreset, k_n_goals, k_goal0, k_goal1, k_normalised, k_nt);
     if constexpr (Cfg::kQrt) keep_sgpr(Q);
     RW_MARK(TL_LOADED);
+    }
 
     // kRollout == false is the single-step kernel (rw_step / rw_reset / rw_refresh_obs): no loop at all.
     const int n_steps = (kRollout && op == OP_STEP) ? la.n_steps : 1;
@@ -778,8 +820,68 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     // action is fetched into a register one step ahead, so its HBM latency hides under the current step.
     const bool act_prefetch = kRollout && !kMsg && (ne <= nw * (Cfg::kN ? 64 / (Cfg::kN ? Cfg::kN : 1) : p.groups_per_wave));
     int a_pref = ACT_NOOP;
-    for (int t = 0; t < n_steps; ++t) {  // fused rollout: one iteration per env step
-    if (kRollout) {
+    // ---------------------------------------------------------------- PIPE: the workgroup's chunks, the two buffers, the stage-in
+    // chunk `it` of this workgroup is chunk blockIdx + it * gridDim of the batch and lives in LDS buffer it & 1
+    const int pipe_wave = kPipe ? uniform(tid >> 6) : 0;  // (scalar: the roles below are scalar branches)
+    const int pipe_chunks = kPipe ? (B / E - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    auto pipe_e0 = [&](int it_) RW_INLINE -> int { return ((int)blockIdx.x + it_ * (int)gridDim.x) * E; };
+    // stage the chunk whose first env is ce0 into the buffer at `base`: shelf layer, packed records, actions, queue, highway bitmap,
+    // counter records — ONE wavefront issues the whole list (LDS-DMA, 1 KiB per instruction), nothing is waited for here
+    auto pipe_stage_in = [&](int ce0, int32_t *base) RW_INLINE {
+        if constexpr (kPipe) {
+            const RW_GLOBAL char *src[6] = {as_bytes(g_shadow + (size_t)ce0 * HW), as_bytes(q_rec + (size_t)ce0 * N),
+                                            as_bytes(as_global(la.actions) + (size_t)ce0 * N * AM), as_bytes(q_queue + (size_t)ce0 * Q),
+                                            as_bytes(q_hw), as_bytes(q_cnt + ce0)};
+            const int seg[6] = {lo.gs, lo.ax, lo.act, lo.queue, lo.hw, lo.dcnt}, end[6] = {lo.ax, lo.ay, lo.queue, lo.hw, lo.dcnt, lo.dflag};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int pieces = (end[k] - seg[k]) >> 2;
+                const int have = (Cfg::kQrt && k == 3) ? (E * Q) >> 2 : pieces;  // (run-time queue length: [E][Q] in HBM, contiguous)
+#pragma unroll
+                for (int c = 0; c < pieces; c += 64)
+                    if (c + lane < have) lds_dma_b128(src[k] + (size_t)(c + lane) * 16, base + seg[k] + 4 * c);
+            }
+        }
+    };
+    // zero [lo_, hi_) dwords of a buffer, one wavefront, 16 bytes per lane
+    auto pipe_zero = [&](int32_t *base, int lo_, int hi_) RW_INLINE {
+        for (int i = lane; i < ((hi_ - lo_) >> 2); i += 64) reinterpret_cast<int4 *>(base + lo_)[i] = int4{0, 0, 0, 0};
+    };
+    // the agent lanes' own record, action and counter record out of the staged chunk (what the classic flow fetches from HBM
+    // at the top of the kernel): the rest of the kDirect path is shared
+    auto load_own_lds = [&]() RW_INLINE {
+        if constexpr (kPipe) {
+            constexpr int KN = Cfg::kN, KG = 64 / KN;
+            const int g = lane / KN, a_idx = lane - g * KN;
+            if (g < KG && g < Cfg::kE) {
+                const int i = g * KN + a_idx;
+                r_rec = (uint32_t)s_ax[i];
+                if (op == OP_STEP) r_act = s_act[i * AM];
+                r_cx = sm[lo.dcnt + 2 * g];
+                r_inact = sm[lo.dcnt + 2 * g + 1];
+            }
+        }
+    };
+    if constexpr (kPipe) {
+        int4 *z = reinterpret_cast<int4 *>(smem);
+        for (int i = tid; i < (2 * lo.total) >> 2; i += T) z[i] = int4{0, 0, 0, 0};
+        lds_barrier();  // (the clear is another wavefront's: in front of the DMA into the same buffers)
+        if (pipe_wave == 3) {
+            pipe_stage_in(pipe_e0(0), smem);
+            if (pipe_chunks > 1) pipe_stage_in(pipe_e0(1), smem + lo.total);
+            dma_wait();
+        }
+        lds_barrier();
+        RW_MARK(TL_LOADED);
+    }
+    const int n_iter = kPipe ? pipe_chunks : n_steps;
+    // fused rollout: one iteration per env step, t; PIPE: one per chunk, `it` (t stays 0: every chunk takes its first and only step)
+    for (int t = 0, it = 0; (kPipe ? it : t) < n_iter; kPipe ? ++it : ++t) {
+    if constexpr (kPipe) {  // this wavefront moves on to its next chunk (wavefront 0 ahead of the others)
+        bind_lds(smem + (it & 1) * lo.total);
+        e0 = pipe_e0(it);
+    }
+    if (kRollout || kPipe) {
         // Re-derive the thread coordinates inside the loop from an opaque copy: otherwise LICM hoists every
         // tid-derived address of the unrolled phases out of the step loop and keeps them live across it
         // (200+ VGPRs, half the occupancy).
@@ -788,6 +890,10 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         wave = tid >> 6;
     }
     const bool worker = !split || wave < 3;
+    // who expands and stores the observation: the gatherers — except PIPE, where wavefronts 1 and 2 do (0 runs the next chunk's
+    // agent phases meanwhile, 3 stages the chunk after that in)
+    const bool x_worker = kPipe ? (pipe_wave == 1 || pipe_wave == 2) : worker;
+    const int x_tid = kPipe ? tid - 64 : tid, x_TW = kPipe ? 128 : TW;
     const int32_t *act_t = la.actions + (size_t)t * la.act_stride;
     float *obs_t = la.obs + (size_t)t * la.obs_stride;
     float *rew_t = la.rewards + (size_t)t * la.rew_stride;
@@ -867,6 +973,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     //           With kDirect the own record does not come from LDS either: the lane fetched it from HBM into registers
     //           at the top of the kernel.
     //   else    the sub-phases exchange through LDS arrays under wave_sync() (any N up to 64, run-time shapes).
+    if constexpr (kPipe) { if (pipe_wave == 0) load_own_lds(); }
     if constexpr (kRegAG) {
     constexpr int KN = Cfg::kN, KG = 64 / KN, QS = (Cfg::kQcap + KN - 1) / KN;
     const int KQ = Cfg::kQrt ? Q : Cfg::kQ;  // (a compile-time constant unless the build reads the queue length at run time)
@@ -1349,6 +1456,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             }
     }
     }
+    if constexpr (kPipe) { if (pipe_wave == 3) dma_wait(); }  // barrier A: the chunk staged for the NEXT agent phases has landed
     lds_barrier();
     RW_MARK(TL_AGENTS);
 
@@ -1724,9 +1832,22 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             }
         }
     }
+    if constexpr (kPipe) { if (pipe_wave == 3) write_back(0, 1); }  // (before barrier B: behind it the buffer's staging slots are refilled)
     lds_barrier();
     RW_MARK(TL_OBS_BITS);
-    if (split && wave == 3) write_back(0, 1);  // all three roles, beside the head of the observation stream
+    if constexpr (!kPipe) {
+        if (split && wave == 3) write_back(0, 1);  // all three roles, beside the head of the observation stream
+    } else if (pipe_wave == 3) {
+        // the service wavefront, beside the expansion of this chunk and the agent phases of the next: the scratch of THIS buffer
+        // (its readers — gather, write-back — ran in front of the barrier) and the bit string of the OTHER one (expanded one stage
+        // ago) are zeroed for the chunks that come next, and chunk it + 2 is staged into this buffer's slots
+        pipe_zero(sm, lo.ga, lo.zero_end);
+        pipe_zero(sm, lo.depth, lo.win);
+        pipe_zero(sm, lo.req, lo.obits);
+        pipe_zero(sm, lo.misc, lo.total);
+        pipe_zero(smem + ((it + 1) & 1) * lo.total, lo.obits, lo.envi);
+        if (it + 2 < n_iter) pipe_stage_in(pipe_e0(it + 2), sm);
+    }
 
     // ---------------------------------------------------------------- ST: obs, float4 #q == nibble #q
     if constexpr (!kImage) {
@@ -1777,13 +1898,13 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             //  front of the branch that picks one — large-16ag r=2: 102 VGPRs instead of 60, 4 workgroups per CU instead of 7)
             // (only in the builds that hold both copies: with one copy the hoisting is wanted — the address arithmetic then runs
             //  while the workgroup waits at the bit-string barrier)
-            int tq = tid;
+            int tq = x_tid;
             if constexpr (Cfg::kNT < 0) asm volatile("" : "+v"(tq));
-            const int shift = (tq & 7) << 2, words_per_pass = TW >> 3;  // (TW % 8 == 0)
+            const int shift = (tq & 7) << 2, words_per_pass = x_TW >> 3;  // (x_TW % 8 == 0)
             const uint32_t *wp = s_obits + (tq >> 3);
-            const int dm = (4 * TW) % L, di = (4 * TW) / L;
+            const int dm = (4 * x_TW) % L, di = (4 * x_TW) / L;
             int m = (4 * tq + 3) % L, ai = (4 * tq + 3) / L;
-            const int passes = (nf4 + TW - 1) / TW;  // a compile-time constant in the specialised builds (full unroll)
+            const int passes = (nf4 + x_TW - 1) / x_TW;  // a compile-time constant in the specialised builds (full unroll)
             // in groups of 8 passes: first the LDS reads of all 8 in one unconditional batch (a read past the string still
             // lands inside the workgroup's LDS; the agent index is clamped), then the 8 expansions
             for (int k0 = 0; k0 < passes; k0 += 8) {
@@ -1802,7 +1923,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (k0 + j >= passes) break;
-                    const int q4 = tq + (k0 + j) * TW;
+                    const int q4 = tq + (k0 + j) * x_TW;
                     if (q4 < nf4) {
                         const uint32_t bits = (((wv[j] >> shift) & 0xFu) * 0x00204081u) & 0x01010101u;
                         // x goes to byte 3 - m, y to byte 4 - m of this float4 (m == 4: x was the last float of the one before)
@@ -1818,7 +1939,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                 }
             }
         };
-        if (worker && xy_bytes) {
+        if (x_worker && xy_bytes) {
             if constexpr (Cfg::kNT == 1) single_pass(yes_t{});
             else if constexpr (Cfg::kNT == 0) single_pass(no_t{});
             else {  // (two copies of the pass, one taken: a scalar branch on a workgroup-uniform flag)
@@ -1827,12 +1948,12 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         }
         // normalised coordinates are fractions: bulk pass over every float4 that holds no coordinate slot (all but ~2 in
         // 18), then a second pass for the coordinate slots
-        if (worker && !xy_bytes) {
-            const int shift = (tid & 7) << 2, words_per_pass = TW >> 3;  // (TW % 8 == 0)
-            const uint32_t *wp = s_obits + (tid >> 3);
-            const int dm = (4 * TW) % L;
-            int m = (4 * tid + 3) % L;
-            const int passes = (nf4 + TW - 1) / TW;
+        if (x_worker && !xy_bytes) {
+            const int shift = (x_tid & 7) << 2, words_per_pass = x_TW >> 3;  // (x_TW % 8 == 0)
+            const uint32_t *wp = s_obits + (x_tid >> 3);
+            const int dm = (4 * x_TW) % L;
+            int m = (4 * x_tid + 3) % L;
+            const int passes = (nf4 + x_TW - 1) / x_TW;
             for (int k0 = 0; k0 < passes; k0 += 8) {
                 uint32_t wv[8];
 #pragma unroll
@@ -1840,7 +1961,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (k0 + j >= passes) break;
-                    const int q4 = tid + (k0 + j) * TW;
+                    const int q4 = x_tid + (k0 + j) * x_TW;
                     if (q4 < nf4 && m >= 5) store4(no_t{}, (uint32_t)q4 << 4, spread((wv[j] >> shift) & 0xFu));
                     m += dm;
                     m = (m >= L) ? m - L : m;
@@ -1848,8 +1969,8 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             }
         }
         // coordinate pass: per agent, the one or two float4s that hold its x (element i*L) and y (i*L + 1)
-        if (worker && !xy_bytes)
-        for (int i = tid; i < nea; i += TW) {
+        if (x_worker && !xy_bytes)
+        for (int i = x_tid; i < nea; i += x_TW) {
             const int g = i * L, q4 = g >> 2, pos = g & 3;
             const float fx = s_fx[i], fy = s_fy[i];
             if (q4 < nf4) {
@@ -1866,8 +1987,8 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                 out4[q4 + 1] = v;
             }
         }
-        if (worker)
-        for (int g = (nf4 << 2) + tid; g < nf; g += TW) {  // < 4 leftover floats (partial last workgroup)
+        if (x_worker)
+        for (int g = (nf4 << 2) + x_tid; g < nf; g += x_TW) {  // < 4 leftover floats (partial last workgroup)
             const int i = g / L, k = g - i * L;
             out[g] = (k >= 2) ? (((s_obits[g >> 5] >> (g & 31)) & 1u) ? 1.0f : 0.0f)
                               : (k == 0 ? s_fx[i] : s_fy[i]);

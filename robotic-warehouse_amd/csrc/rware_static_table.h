@@ -21,9 +21,10 @@ struct StaticEntry {
     int directional;
     step_kernel_t fn, fn_rollout;
     step_kernel_t fn_nt;  // the per-step kernel with non-temporal observation stores (nullptr: `fn` switches at run time)
+    int pipe;             // 1: a chunk-pipelined persistent build (rw::StaticCfg PIPE_ = 1; OP_STEP launches only, beside a classic entry)
 };
 
-enum : int { kStaticGroups = 18 };
+enum : int { kStaticGroups = 19 };
 const StaticEntry *static_group(int group, int *n);   // rware_capi.hip's view: dispatches to the per-group tables below
 const StaticEntry *static_group_0(int *n);
 const StaticEntry *static_group_1(int *n);
@@ -43,6 +44,7 @@ const StaticEntry *static_group_14(int *n);
 const StaticEntry *static_group_15(int *n);
 const StaticEntry *static_group_16(int *n);
 const StaticEntry *static_group_17(int *n);
+const StaticEntry *static_group_18(int *n);
 
 }  // namespace rw_tab
 
@@ -69,6 +71,11 @@ namespace {
     {H, W, N, Q, S, R, E, T, MAXB, 0, M, 0, 0u, -1, (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, false, rw::OBS_FLATTENED_MSG>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M>, true, rw::OBS_FLATTENED_MSG>, \
      (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, T, M, 0, 0u, -1, 1>, false, rw::OBS_FLATTENED_MSG>}
+// the chunk-pipelined persistent build of a shape (rware_kernels.h, "PIPE"): per-step only, cached / non-temporal stores
+#define RW_PIPE(H, W, N, Q, S, R, E)                                                                               \
+    {H, W, N, Q, S, R, E, 256, 0, 0, 0, 0, 0u, -1,                                                                   \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, 256, 0, 0, 0u, -1, 0, 1>, false>, (step_kernel_t) nullptr, \
+     (step_kernel_t)rw::rware_step_kernel<R, uint8_t, rw::StaticCfg<H, W, N, Q, S, E, 256, 0, 0, 0u, -1, 1, 1>, false>, 1}
 // the three registered warehouse sizes of the RWARE papers (rware/__init__.py:7-12): grid, shelves
 #define RW_TINY(N, Q) RW_STATIC(11, 10, N, Q, 32, 1, 16, 256, 0)
 #define RW_SMALL(N, Q) RW_STATIC(20, 10, N, Q, 80, 1, 16, 256, 0)
@@ -216,11 +223,21 @@ const StaticEntry kEntries[] = {
     RW_QRT_WIDE_A(29, 16, 224),  // large
 #elif RW_STATIC_GROUP == 17
     RW_QRT_WIDE_B(29, 16, 224),
+#elif RW_STATIC_GROUP == 18
+    // ---- chunk-pipelined persistent builds (pipe == 1): the agent phases of a chunk on one wavefront (E * N <= 64), first match wins
+    RW_PIPE(20, 10, 4, 4, 80, 1, 16), RW_PIPE(20, 10, 4, 4, 80, 1, 8),   // rware-small-4ag
+    RW_PIPE(20, 16, 6, 3, 144, 1, 8),                                      // rware-medium-6ag-hard
+    RW_PIPE(29, 16, 16, 16, 224, 2, 4),                                    // rware-large-16ag, sensor_range = 2
+    RW_PIPE(11, 10, 2, 2, 32, 1, 32), RW_PIPE(11, 10, 2, 2, 32, 1, 16),  // rware-tiny-2ag
+    RW_PIPE(20, 10, 8, -1, 80, 1, 8), RW_PIPE(20, 10, 6, -1, 80, 1, 8),   // small, 8 / 6 agents (any queue length)
+    RW_PIPE(20, 10, 10, -1, 80, 1, 4), RW_PIPE(20, 10, 12, -1, 80, 1, 4), RW_PIPE(20, 10, 16, -1, 80, 1, 4),
+    RW_PIPE(29, 16, 16, -1, 224, 1, 4),                                    // rware-large-16ag
 #else
 #error "RW_STATIC_GROUP out of range"
 #endif
 };
 #undef RW_STATIC
+#undef RW_PIPE
 #undef RW_NT_OR_NULL
 #undef RW_STATIC_IMAGE
 #undef RW_STATIC_IMAGE_LAYERS

@@ -146,7 +146,7 @@ class WarehouseVecEnv(_VectorEnvBase):
                  normalised_coordinates: bool = False, render_mode=None, *,
                  autoreset_mode: str = "next_step", devices=None, output: str = "numpy",
                  envs_per_workgroup: int = 0, threads_per_workgroup: int = 0, library: str | None = None,
-                 obs_stores: str | None = None, jit=None):
+                 obs_stores: str | None = None, jit=None, pipe=None):
         if not 0 <= int(msg_bits) <= 16:
             raise ValueError("msg_bits must be in 0..16")
         self.msg_bits = int(msg_bits)
@@ -225,7 +225,10 @@ class WarehouseVecEnv(_VectorEnvBase):
                 obs_stores=obs_stores,
                 # None / "auto": shapes without an ahead-of-time exact-shape kernel are specialised at construction (hipRTC, disk
                 # cache) when the batch has >= 4096 envs; False / "off": never; True / "force": always
-                jit=jit))
+                jit=jit,
+                # None / "auto": the engine's measured rule; False / "off", True / "on": the chunk-pipelined persistent per-step
+                # kernel never / wherever the library has a build for the shape (rw_stream_flags RW_PIPE_*)
+                pipe=pipe))
         self._bounds = [b for b in self._bounds if b[1] > b[0]]
         self.shard_bounds = list(self._bounds)  # env range [lo, hi) of every engine / device, in order
         self.devices = devices[: len(self.engines)]

@@ -105,6 +105,8 @@ inline hipError_t hipModuleLaunchKernel(hipFunction_t, unsigned, unsigned, unsig
 inline hipError_t hipExtModuleLaunchKernel(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, size_t, hipStream_t, void **, void **,
                                            hipEvent_t, hipEvent_t, unsigned) { return 1; }
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
+// (two persistent workgroups on the emulation's one "CU": the pipelined builds then walk several chunks per workgroup)
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 2; return hipSuccess; }
 
 #include <mutex>
 extern std::mutex emu_launch_mutex;  // one "device": launches from several host threads (rw_multi) run one after the other
