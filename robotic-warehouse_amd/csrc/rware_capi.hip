@@ -647,8 +647,17 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             if (pe_ != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 0; }
             const char *pw = getenv("RWARE_PIPE_WGS_PER_CU");  // (A/B hook: fewer resident workgroups, more chunks each)
             if (pw && atoi(pw) > 0) per_cu = std::min(per_cu, atoi(pw));
-            const long long grid = std::min<long long>(n_chunks, (long long)per_cu * n_cu);
-            // the rule (profiles/EXPERIMENTS.md, round 5): pipelining needs at least two chunks per workgroup
+            // (whole CUs' worth of workgroups: an "even" split — 1366 workgroups of 3 chunks instead of 1536 of 2 or 3 — loads the CUs
+            //  unevenly and measured slower, small-4ag x 65536: 19.5 vs 17.5 us)
+            long long grid = std::min<long long>(n_chunks, (long long)per_cu * n_cu);
+            const char *pg = getenv("RWARE_PIPE_GRID");  // (test hook: a handful of workgroups, so that small batches walk several chunks each)
+            if (pg && atoi(pg) > 0) grid = std::min<long long>(grid, atoi(pg));
+            // The rule, as measured (profiles/EXPERIMENTS.md, round 5, profiles/r05_pipe_*.txt): NEVER by default.  In steady state the
+            // pipelined workgroups run at the fabric's rate (small-4ag x 65536: 0.77 us per chunk and CU against the classic launch's
+            // average of 0.95), but a launch is prologue + stream + tail, the classic launch's stream already runs at that rate once it
+            // has started, and the persistent workgroups' prologue is longer (stage-in, then the agent phases of chunk 0, then its
+            // gather: 4.6 us to the first store against 3.1) — every BASELINE config and batch size came out 8 .. 40 % slower.  The
+            // build stays selectable (RW_PIPE_ON) and parity-tested.
             const bool rule = false;
             if (lds <= 160 * 1024 && grid >= 1 && (mode == 1 || (mode == 0 && rule && n_chunks >= 2 * grid))) {
                 eng->pipe_kernel = fn;

@@ -174,7 +174,10 @@ enum : int { OP_FLAG_TIMELINE = 0x100 };
 enum : int { TL_START = 0, TL_ZEROED, TL_DMA_ISSUED, TL_ENV_LOADED, TL_LOADED, TL_AGENTS, TL_RESET, TL_OBS_BITS,
              TL_OBS_STORED, TL_END,  // 10, 11: where the wavefronts ran
              TL_AG_RECORD = 12, TL_AG_CELLS, TL_AG_WINNERS, TL_AG_APPLIED, TL_AG_GOALS,  // inside the agent phases (wavefront 0)
-             TL_MARKS = 20 };
+             // the pipelined build, chunk it < 4 of the workgroup, slot TL_PIPE + 8 * it + ...: behind barrier A | wavefront 0 done gathering |
+             // wavefront 3 done with self bits + write-back | behind barrier B | wavefront 0 done with the next chunk's agent phases |
+             // wavefront 1 done expanding | wavefront 3 has issued the stage-in of chunk it + 2 | ... and has seen it land (next stage)
+             TL_PIPE = 16, TL_MARKS = 48 };
 
 // LDS carve-up, in dwords.  Every sub-array starts on a 16-byte boundary.
 struct LdsLayout {
@@ -533,6 +536,8 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     const uint32_t mN = Cfg::kN ? rw_magic18(Cfg::kN) : p.magic_n;
     // optional per-workgroup phase stamps (100 MHz wall clock); one scalar branch per mark when off
 #define RW_MARK(k) do { if (RW_RARE(tl_on) && tid == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + (k)] = wall_clock64(); } while (0)
+    // (the pipelined build: stamp k of chunk `it`, taken by the first lane of wavefront `w`)
+#define RW_PIPE_MARK(k, w) do { if (kPipe && RW_RARE(tl_on) && it < 4 && tid == 64 * (w)) la.timeline[(size_t)blockIdx.x * TL_MARKS + TL_PIPE + 8 * it + (k)] = wall_clock64(); } while (0)
     // marks INSIDE the agent phases: only in a -DRW_TL_AG_MARKS build (profiles/tools/timeline_probe.py says how) — even
     // switched off each one is a scalar test and a branch on the one wavefront every other wavefront is waiting for
 #ifdef RW_TL_AG_MARKS
@@ -1456,9 +1461,13 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             }
     }
     }
-    if constexpr (kPipe) { if (pipe_wave == 3) dma_wait(); }  // barrier A: the chunk staged for the NEXT agent phases has landed
-    lds_barrier();
+    RW_PIPE_MARK(4 - 8, 0);  // (the agent phases of this chunk ran one stage ago: slot 4 of chunk it - 1)
+    lds_barrier();  // (PIPE: barrier A)
     RW_MARK(TL_AGENTS);
+    RW_PIPE_MARK(0, 0);
+    // PIPE: the stage-in wavefront 3 issued one stage ago (chunk it + 1, for the agent phases that start behind barrier B) is waited
+    // for HERE, behind barrier A and on wavefront 3 only: it has had a whole stage to land, and the gather does not wait for it
+    if constexpr (kPipe) { if (pipe_wave == 3) { dma_wait(); RW_PIPE_MARK(7 - 8, 3); } }
 
     // ---------------------------------------------------------------- RS: reset flagged envs (:757-802)
     if (RW_RARE(s_misc[0] != 0)) {  // workgroup-uniform; rare
@@ -1833,8 +1842,11 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         }
     }
     if constexpr (kPipe) { if (pipe_wave == 3) write_back(0, 1); }  // (before barrier B: behind it the buffer's staging slots are refilled)
+    RW_PIPE_MARK(1, 0);
+    RW_PIPE_MARK(2, 3);
     lds_barrier();
     RW_MARK(TL_OBS_BITS);
+    RW_PIPE_MARK(3, 0);
     if constexpr (!kPipe) {
         if (split && wave == 3) write_back(0, 1);  // all three roles, beside the head of the observation stream
     } else if (pipe_wave == 3) {
@@ -1847,6 +1859,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         pipe_zero(sm, lo.misc, lo.total);
         pipe_zero(smem + ((it + 1) & 1) * lo.total, lo.obits, lo.envi);
         if (it + 2 < n_iter) pipe_stage_in(pipe_e0(it + 2), sm);
+        RW_PIPE_MARK(6, 3);
     }
 
     // ---------------------------------------------------------------- ST: obs, float4 #q == nibble #q
@@ -2047,6 +2060,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         }
     }
     RW_MARK(TL_OBS_STORED);
+    RW_PIPE_MARK(5, 1);
     if (!split && kRollout) write_back(wave, nw);
     }  // fused-rollout step loop
     RW_MARK(TL_END);
@@ -2056,6 +2070,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
         if (wave == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + 11] = xcc_id();
     }
 #undef RW_MARK
+#undef RW_PIPE_MARK
 #undef RW_AG_MARK
 }
 

@@ -225,13 +225,12 @@ const StaticEntry kEntries[] = {
     RW_QRT_WIDE_B(29, 16, 224),
 #elif RW_STATIC_GROUP == 18
     // ---- chunk-pipelined persistent builds (pipe == 1): the agent phases of a chunk on one wavefront (E * N <= 64), first match wins
-    RW_PIPE(20, 10, 4, 4, 80, 1, 16), RW_PIPE(20, 10, 4, 4, 80, 1, 8),   // rware-small-4ag
-    RW_PIPE(20, 16, 6, 3, 144, 1, 8),                                      // rware-medium-6ag-hard
-    RW_PIPE(29, 16, 16, 16, 224, 2, 4),                                    // rware-large-16ag, sensor_range = 2
-    RW_PIPE(11, 10, 2, 2, 32, 1, 32), RW_PIPE(11, 10, 2, 2, 32, 1, 16),  // rware-tiny-2ag
-    RW_PIPE(20, 10, 8, -1, 80, 1, 8), RW_PIPE(20, 10, 6, -1, 80, 1, 8),   // small, 8 / 6 agents (any queue length)
-    RW_PIPE(20, 10, 10, -1, 80, 1, 4), RW_PIPE(20, 10, 12, -1, 80, 1, 4), RW_PIPE(20, 10, 16, -1, 80, 1, 4),
-    RW_PIPE(29, 16, 16, -1, 224, 1, 4),                                    // rware-large-16ag
+    RW_PIPE(20, 10, 4, 4, 80, 1, 16),      // rware-small-4ag
+    RW_PIPE(20, 16, 6, 3, 144, 1, 8),      // rware-medium-6ag-hard
+    RW_PIPE(29, 16, 16, 16, 224, 2, 4),    // rware-large-16ag, sensor_range = 2
+    RW_PIPE(11, 10, 2, 2, 32, 1, 32),      // rware-tiny-2ag
+    RW_PIPE(20, 10, 10, -1, 80, 1, 4),     // small, 10 agents (any queue length): the per-cell agent phases
+    RW_PIPE(29, 16, 16, -1, 224, 1, 4),    // rware-large-16ag
 #else
 #error "RW_STATIC_GROUP out of range"
 #endif

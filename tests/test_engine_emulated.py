@@ -938,3 +938,52 @@ def test_start_stagger_is_a_create_time_rule_and_does_not_change_results(monkeyp
         o2, r2, d2 = orc.step_autoreset(a, "next_step")
         assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
     env.close()
+
+
+@pytest.mark.parametrize("env_id,extra,B,mode", [
+    ("rware-small-4ag-v1", {"max_steps": 25}, 64, "next_step"),                     # 4 chunks on the emulation's 2 persistent workgroups
+    ("rware-small-4ag-v1", {"max_steps": 25}, 48, "same_step"),                     # ragged: 2 + 1 chunks; terminal observations
+    ("rware-small-4ag-v1", {"max_steps": 25}, 16, "disabled"),                      # one chunk: the pipeline never fills
+    ("rware-small-4ag-v1", {"max_steps": 20, "reward_type": 2, "max_inactivity_steps": 11}, 80, "next_step"),
+    ("rware-medium-6ag-hard-v1", {"max_steps": 20, "reward_type": 0}, 40, "next_step"),
+    ("rware-large-16ag-v1", {"sensor_range": 2, "max_steps": 15}, 20, "same_step"),  # BASELINE config 5's shape: 4-env chunks
+    ("rware-tiny-2ag-v1", {"max_steps": 25}, 96, "next_step"),                      # 32-env chunks
+    ("rware-small-10ag-easy-v1", {"max_steps": 20}, 12, "same_step"),               # agent-count-static, run-time queue length, per-cell agent phases
+    ("rware-large-16ag-v1", {"max_steps": 15}, 12, "next_step"),
+])
+def test_emulated_pipelined_build_matches_oracle(env_id, extra, B, mode):
+    """The chunk-pipelined persistent build of the per-step kernel (rware_kernels.h "PIPE", opt-in: pipe=True): two workgroups walk
+    the batch's chunks through two LDS buffers, the next chunk's agent phases beside this chunk's observation stores.  Resets
+    (rw_reset, autoreset in both modes) go through the classic kernel on the same state."""
+    kw = rware_amd.env_kwargs(env_id)
+    kw.update(extra)
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    env = rware_amd.WarehouseVecEnv(B, autoreset_mode=mode, library=LIB, pipe=True, **kw)
+    info = env.engines[0].info
+    assert info.pipe_workgroups in (1, 2) and B % info.pipe_envs_per_workgroup == 0
+    orc = OracleVecEnv(B, **kw)
+    obs, _ = env.reset(seed=7)
+    assert np.array_equal(obs, orc.reset(seed=7))
+    rng = np.random.default_rng(3)
+    for t in range(50):
+        a = rng.choice(5, size=(B, kw["n_agents"]), p=[0.1, 0.55, 0.1, 0.1, 0.15]).astype(np.int32)
+        obs, rew, term, trunc, inf = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, mode)
+        assert np.array_equal(obs, o2), t
+        assert np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+        if mode == "same_step" and d2.any():
+            assert np.array_equal(inf["final_obs"][orc.final_mask], orc.final_obs[orc.final_mask]), t
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    env.close()
+
+
+def test_emulated_pipelined_build_is_opt_in():
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    env = rware_amd.WarehouseVecEnv(64, library=LIB, **kw)
+    assert env.engines[0].info.pipe_workgroups == 0      # the measured rule: never by default (profiles/EXPERIMENTS.md, round 5)
+    env.close()
+    env = rware_amd.WarehouseVecEnv(64, library=LIB, pipe=True, observation_type=2, **kw)
+    assert env.engines[0].info.pipe_workgroups == 0      # no pipelined build for IMAGE observations: the classic kernel runs
+    env.close()

@@ -1274,3 +1274,48 @@ def test_capture_pipelines_replays_what_the_eager_pipelines_do():
     for p in cap + eag:
         p.env.close()
     one.close()
+
+
+@pytest.mark.parametrize("name,tile,grid", [("small-4ag", 20, 2), ("medium-6ag-hard", 8, 2), ("large-16ag-sr2", 6, 2), ("tiny-2ag", 40, 3)])
+def test_pipelined_builds_replay_reference_golden(name, tile, grid, monkeypatch):
+    """The reference's golden traces on the chunk-pipelined persistent builds (opt-in, pipe=True): a handful of persistent workgroups
+    (RWARE_PIPE_GRID) walk several chunks each — uneven shares included — so the two-buffer hand-over is what is being replayed."""
+    monkeypatch.setenv("RWARE_PIPE_GRID", str(grid))
+    meta, z = gu.load_fixture(name)
+    be = EngineBackend(meta["E"], tile=tile, pipe=True, **gu.ctor_kwargs(meta))
+    info = be.env.engines[0].info
+    assert info.pipe_workgroups == grid and (meta["E"] * tile) // info.pipe_envs_per_workgroup > grid
+    assert gu.replay(be, meta, z) == meta["T"]
+    be.env.close()
+
+
+@pytest.mark.parametrize("env_id,extra,B,T,mode", [
+    ("rware-small-4ag-v1", {"max_steps": 60}, 65536, 130, "next_step"),              # 4096 chunks on ~1500 persistent workgroups
+    ("rware-small-4ag-v1", {"max_steps": 40}, 16384, 90, "same_step"),               # one chunk per workgroup: the pipeline never fills
+    ("rware-medium-6ag-hard-v1", {"max_steps": 50, "reward_type": 0}, 32768, 110, "next_step"),
+    ("rware-large-16ag-v1", {"sensor_range": 2, "max_steps": 30}, 16384, 70, "same_step"),   # BASELINE config 5's shard
+    ("rware-small-10ag-v1", {"max_steps": 40}, 16384, 90, "next_step"),              # per-cell agent phases, run-time queue length
+    ("rware-large-16ag-v1", {"max_steps": 30}, 16384, 70, "next_step"),
+])
+def test_pipelined_builds_match_oracle_full_batch(env_id, extra, B, T, mode):
+    kw = rware_amd.env_kwargs(env_id)
+    kw.update(extra)
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    env = rware_amd.WarehouseVecEnv(B, autoreset_mode=mode, pipe=True, **kw)
+    assert env.engines[0].info.pipe_workgroups > 0
+    orc = OracleVecEnv(B, **kw)
+    obs, _ = env.reset(seed=11)
+    assert np.array_equal(obs, orc.reset(seed=11))
+    rng = np.random.default_rng(5)
+    for t in range(T):
+        a = rng.choice(5, size=(B, kw["n_agents"]), p=[0.1, 0.55, 0.1, 0.1, 0.15]).astype(np.int32)
+        obs, rew, term, trunc, info = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, mode)
+        assert np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+        assert np.array_equal(obs, o2), t
+        if mode == "same_step" and d2.any():
+            assert np.array_equal(info["final_obs"][orc.final_mask], orc.final_obs[orc.final_mask]), t
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    env.close()
