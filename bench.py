@@ -15,10 +15,14 @@ The printed JSON line carries
   value / ms_per_step   exactly K steps after W warm-up steps, barrier + device sync on both sides
   sustained             the same launches for a fixed 2000 steps after 100 warm-up steps (SURVEY.md §8(d) protocol,
                         spans 4 mass resets) — the steady state, whatever K and W the caller chose
-  roofline              algorithmic bytes per launch / HIP-event time per launch on the engine's stream (the two events ride
-                        on the first and the last launch of the timed region: rw_step_tape_device_timed), vs the 8 TB/s
-                        HBM peak and the 6.29 TB/s measured copy ceiling; `traffic` = physical bytes per launch from
-                        the rocprofv3 PMC passes (profiles/pmc_traffic.json, tied to the kernel sources by hash)
+  roofline              bytes per launch / HIP-event time per launch on the engine's stream (the two events ride on the first
+                        and the last launch of the timed region: rw_step_tape_device_timed) vs the 8 TB/s HBM peak.
+                        `achieved` / `frac` are the PHYSICAL bandwidth: `traffic` (bytes per launch from the rocprofv3 PMC
+                        passes, profiles/pmc_traffic.json, tied to the kernel sources by hash) when that record is current,
+                        else the bytes this engine's layout has to move (`basis` says which) — never above 1.
+                        `achieved_algorithmic` / `frac_algorithmic` price SURVEY.md §8(d)'s algorithmic bytes, which the engine
+                        does not move (a work rate in that unit; it may exceed 1).  `regime`: whether a step's bytes fit the
+                        256 MiB Infinity Cache ("infinity-cache") or not ("hbm")
   (--submit graph: the same per-step launches replayed from a HIP graph — for rocprofv3 traces, see profiles/tools/sweep.sh)
   cpu_baseline (N = 1)  the reference's pure-Python step on the host cores when /root/reference exists, else the C port
                         of it, 1 process and one per core, with the core count and CPU model
@@ -41,6 +45,25 @@ ENV_ID = "rware-small-4ag-v1"
 BATCH_PER_GPU = 16384
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_MEASURED_GBPS = 6290.0   # same guide: measured float4 copy ceiling
+INFINITY_CACHE_BYTES = 256 * 1024 * 1024  # same guide: 256 MiB memory-side cache in front of HBM
+
+
+def roofline_fields(a_bytes, e_bytes, traffic, k_ms):
+    """The bandwidth fields of one measured kernel time.  `achieved` / `frac`: the physical figure — PMC traffic when the recorded pass
+    belongs to these kernel sources, else the engine-layout bytes (`basis`); `*_algorithmic`: SURVEY.md §8(d)'s bytes (a work rate);
+    `regime`: do a step's bytes fit the Infinity Cache.  No key named frac* other than frac_algorithmic can exceed 1."""
+    sec = k_ms * 1e-3
+    phys = traffic if traffic else e_bytes
+    return {
+        "achieved": phys / sec / 1e9, "frac": phys / sec / 1e9 / HBM_PEAK_GBPS, "basis": "pmc-traffic" if traffic else "engine-bytes",
+        "regime": "hbm" if phys > INFINITY_CACHE_BYTES else "infinity-cache",
+        "achieved_algorithmic": a_bytes / sec / 1e9, "frac_algorithmic": a_bytes / sec / 1e9 / HBM_PEAK_GBPS,
+        "achieved_engine": e_bytes / sec / 1e9, "frac_engine": e_bytes / sec / 1e9 / HBM_PEAK_GBPS,
+        "traffic": traffic, "traffic_over_engine_bytes": (traffic / e_bytes) if traffic else None,
+        "frac_physical": (traffic / sec / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+        "algorithmic_bytes_per_launch": a_bytes, "engine_bytes_per_launch": e_bytes,
+        "peak": HBM_PEAK_GBPS, "peak_measured": HBM_MEASURED_GBPS,
+    }
 TAPE_STEPS = int(os.environ.get("RWARE_BENCH_TAPE_STEPS", "256"))
 SUSTAINED_STEPS, SUSTAINED_WARMUP = 2000, 100
 try:
@@ -220,15 +243,8 @@ def hbm_regime_leg(torch, rware_amd, local_rank, env_id, sha):
                         "past the 256 MiB Infinity Cache), same per-step launches as `value`",
             "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3, "kernel_ms_per_launch": k_ms,
             "value": B * N * K / wall, "unit": "agent-steps/s",
-            # `frac` is priced on SURVEY.md §8(d)'s algorithmic bytes (a work rate in that unit: the engine moves fewer bytes than
-            # A charges, so it can exceed 1); `frac_engine` on the bytes this engine's layout has to move — a bandwidth, <= 1
-            "algorithmic_bytes_per_launch": a_bytes, "achieved_algorithmic": a_bytes / (k_ms * 1e-3) / 1e9, "frac": a_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "engine_bytes_per_launch": e_bytes, "achieved_engine": e_bytes / (k_ms * 1e-3) / 1e9, "frac_engine": e_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "traffic": traffic, "traffic_over_engine_bytes": (traffic / e_bytes) if traffic else None,
-            "achieved_physical": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
-            "frac_physical": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-            "frac_physical_of_measured_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_MEASURED_GBPS) if traffic else None,
-            "peak": HBM_PEAK_GBPS, "peak_measured": HBM_MEASURED_GBPS, "unit_bw": "GB/s",
+            # (`achieved` / `frac`: physical bytes / time; `*_algorithmic`: SURVEY.md §8(d)'s bytes, a work rate — see roofline_fields)
+            **roofline_fields(a_bytes, e_bytes, traffic, k_ms), "unit_bw": "GB/s",
             "envs_per_workgroup": int(info.envs_per_workgroup), "kernel_specialised": bool(info.specialised),
             "start_stagger_ns_per_slot": 10 * int(info.stagger_ticks),   # launches of two or more rounds of workgroups (rw_info.stagger_ticks)
             "observation_stores": "non-temporal" if int(info.obs_stores_stream) else "cached",
@@ -344,6 +360,53 @@ def two_pipelines_leg(torch, rware_amd, local_rank, env_id, B):
     return out
 
 
+def submit_modes_leg(torch, rware_amd, rank, local_rank, kw, B, tape_ptr, args, dist):
+    """Per rank: (1) host time per issued launch — n launches enqueued through the library's native loop on an idle stream, clock
+    stopped when the call returns (nothing waited for); (2) the per-step launches of the timed region captured into a HIP graph
+    (min(steps, one tape pass) of them) and replayed: one host call per replay.  A second engine of the same shape on a stream
+    torch can capture; all ranks run this side by side (barrier in front), like the timed region."""
+    G = max(1, min(args.steps, TAPE_STEPS))
+    gs = torch.cuda.Stream(device=local_rank)
+    with torch.cuda.stream(gs):
+        env2 = rware_amd.WarehouseVecEnv(B, devices=[local_rank], envs_per_workgroup=args.envs_per_wg,
+                                         threads_per_workgroup=args.threads_per_wg, output="torch", **kw)
+    try:
+        e2 = env2.engines[0]
+        e2.reset(seeds=rware_amd.shard_seeds(rank, B))
+        with torch.cuda.stream(gs):
+            e2.step_tape_device(tape_ptr, TAPE_STEPS, 0, 64)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            n = 256
+            t0 = time.perf_counter()
+            e2.step_tape_device(tape_ptr, TAPE_STEPS, 0, n)
+            issue = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            native = time.perf_counter() - t0
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=gs):
+                e2.step_tape_device(tape_ptr, TAPE_STEPS, 0, G)
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            reps = max(1, 512 // G)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                graph.replay()
+            torch.cuda.synchronize()
+            g = time.perf_counter() - t0
+        e2.sync()
+        return {"host_issue_us_per_step": issue / n * 1e6, "native_ms_per_step_256": native / n * 1e3,
+                "graph_ms_per_step": g / (reps * G) * 1e3, "graph_launches_per_replay": G}
+    except Exception as exc:  # noqa: BLE001  (a side measurement: never at the price of the line)
+        return {"submit_modes_error": repr(exc)}
+    finally:
+        env2.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -364,17 +427,19 @@ def main():
                          "default), one Python -> ctypes rw_step_device call per step, or the same launches captured once in a "
                          "HIP graph (one whole pass over the action tape) and replayed — for rocprofv3 traces of the small "
                          "kernels, where the profiled host cannot issue single launches fast enough; the launches are identical.  "
-                         "auto = native at N = 1, graph at N > 1: with the launches in a graph a rank's host thread issues one call "
-                         "per 256 steps, so 8 ranks cannot slow each other down on the host side (SURVEY.md §8(e))")
+                         "auto = native at EVERY N (the N = 1 number and the N > 1 numbers of a scaling curve then take the same "
+                         "path); every rank also reports, beside it, the same launches replayed from a HIP graph and the host time "
+                         "per issued launch (`ranks[i].graph_ms_per_step`, `.host_issue_us_per_step`) — SURVEY.md §8(e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-rollout measurement (profiling runs)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the fixed 2000-step sustained leg (profiling runs)")
     ap.add_argument("--no-hbm-regime", action="store_true", help="skip the cache-exceeding leg (small-4ag x 262144 envs)")
     ap.add_argument("--no-api-loop", action="store_true", help="skip the Python closed-loop API leg")
+    ap.add_argument("--no-submit-modes", action="store_true", help="skip the per-rank host-issue / HIP-graph side measurement")
     args = ap.parse_args()
 
     if args.submit == "auto":
-        args.submit = "graph" if (args.gpus > 1 and args.many == 0) else "native"
+        args.submit = "native"  # (the same submission path at every N; the graph path is measured beside it, per rank)
     children = []
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         import torch  # (before spawning: a rank without a device would leave the others waiting at the rendezvous)
@@ -443,26 +508,21 @@ def main():
     tape = torch.from_numpy(acts).to(f"cuda:{local_rank}")
     base, stride = tape.data_ptr(), B * N * AM * 4
 
-    graph = None
-    if gstream is not None:  # one pass over the whole tape = TAPE_STEPS per-step launches, captured once
-        torch.cuda.synchronize()
+    graph, G = None, max(1, min(args.steps, TAPE_STEPS))
+    if gstream is not None:  # G = min(steps, one pass over the tape) per-step launches, captured once: a short timed region
+        torch.cuda.synchronize()  # (the driver's --steps 20) replays it too instead of falling back to plain launches
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=gstream):
-            eng.step_tape_device(base, TAPE_STEPS, 0, TAPE_STEPS)
+            eng.step_tape_device(base, TAPE_STEPS, 0, G)
         torch.cuda.synchronize()
 
     def run(n, t_start, many=args.many):
         if graph is not None and many == 0:
-            t = t_start
             with torch.cuda.stream(gstream):
-                while t < t_start + n:
-                    if t % TAPE_STEPS == 0 and t + TAPE_STEPS <= t_start + n:
-                        graph.replay()
-                        t += TAPE_STEPS
-                    else:  # up to the next tape boundary / the tail: plain launches on the same stream
-                        c = min(TAPE_STEPS - t % TAPE_STEPS, t_start + n - t)
-                        eng.step_tape_device(base, TAPE_STEPS, t % TAPE_STEPS, c)
-                        t += c
+                for _ in range(n // G):  # (the graph always reads tape rows 0 .. G - 1: which random actions a step gets is immaterial)
+                    graph.replay()
+                if n % G:   # the tail: plain launches on the same stream
+                    eng.step_tape_device(base, TAPE_STEPS, 0, n % G)
             return
         if many > 0:
             t = t_start
@@ -521,13 +581,16 @@ def main():
         fused = timed(args.steps, t_next, many=64)
     eng.sync()
 
+    # Every rank, at every N (N = 1 included): what a launch costs this rank's host thread, and the same launches replayed from a HIP
+    # graph — so that a scaling curve can be read for host-side effects (a straggler rank, launch-rate contention) rank by rank
+    modes = submit_modes_leg(torch, rware_amd, rank, local_rank, kw, B, base, args, dist) if (args.many == 0 and not args.no_submit_modes) else {}
     vals = [elapsed, kernel_ms, sus[0] if sus else 0.0, sus[1] if sus else 0.0, fused[0] if fused else 0.0]
     if dist is not None:
         tt = torch.tensor(vals, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         vals = [float(v) for v in tt]
     mine = {"rank": rank, "device": local_rank, "ms_per_step": elapsed / args.steps * 1e3, "kernel_ms_per_launch": kernel_ms,
-            "sustained_ms_per_step": (sus[0] / SUSTAINED_STEPS * 1e3) if sus else None, "placement": placement}
+            "sustained_ms_per_step": (sus[0] / SUSTAINED_STEPS * 1e3) if sus else None, "placement": placement, **modes}
     per_rank = [mine]
     if dist is not None:  # (objects over gloo: still nothing on the data path)
         per_rank = [None] * world
@@ -539,8 +602,6 @@ def main():
         per_launch = a_bytes * B
         e_launch = int(info.engine_bytes_per_env_step) * B  # what this engine's layout has to move per launch (rw_info)
         k_ms = kernel_ms  # HIP-event time per step (== per launch unless --many fuses several steps into one launch)
-        achieved = per_launch / (k_ms * 1e-3) / 1e9
-        achieved_engine = e_launch / (k_ms * 1e-3) / 1e9
         sha = kernel_sources_sha()
         traffic, traffic_note = pmc_traffic(args.env_id, B, sha, args.sensor_range, args.observation_type, args.msg_bits)
         out = {
@@ -576,39 +637,32 @@ def main():
                 "device": info.device_name.decode(), "arch": info.arch_name.decode(),
             },
             "roofline": {
-                # `achieved` / `frac`: SURVEY.md §8(d)'s ALGORITHMIC bytes per launch / kernel time — the contract's figure.  The
-                # engine reads a 1-byte shelf shadow and one dword per agent where A charges two int32 grid layers and five int32
-                # fields, so this is a work rate in A's unit, not a bandwidth (it can exceed the peak at large batches).
-                # `achieved_engine` / `frac_engine`: the bytes this engine's layout has to move (rw_info.engine_bytes_per_env_step)
-                # / the same time — a real bandwidth, <= 1 of peak by construction, measured by THIS run (no tracked constant).
-                # `traffic` / `frac_physical`: PMC bytes of a recorded rocprofv3 pass (profiles/pmc_traffic.json), beside it.
-                "bound": "hbm", "achieved": achieved, "achieved_algorithmic": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "note": "achieved / frac are priced on SURVEY.md §8(d)'s ALGORITHMIC bytes (the contract's figure: two int32 grid layers "
-                        "and five int32 agent fields per env), which this engine does not move — it reads a 1-byte shelf layer and one "
-                        "dword per agent — so they are a work rate in A's unit and may exceed the peak; the bandwidth figures are "
-                        "achieved_engine / frac_engine (bytes the layout must move, measured by this run, <= 1 by construction) and "
-                        "traffic / frac_physical (rocprofv3 PMC bytes of the same kernel sources)",
-                "engine_bytes_per_launch": e_launch, "achieved_engine": achieved_engine, "frac_engine": achieved_engine / HBM_PEAK_GBPS,
-                "traffic": traffic, "traffic_over_engine_bytes": (traffic / e_launch) if traffic else None,
-                "peak_measured": HBM_MEASURED_GBPS, "frac_of_measured_peak": achieved / HBM_MEASURED_GBPS,
-                "frac_engine_of_measured_peak": achieved_engine / HBM_MEASURED_GBPS,
-                "frac_physical": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                # `achieved` / `frac`: the PHYSICAL bandwidth of the step kernel — PMC bytes of a recorded rocprofv3 pass on these kernel
+                # sources (`traffic`), else the bytes this engine's layout has to move (rw_info.engine_bytes_per_env_step) — over the
+                # kernel time THIS run measured: a fraction of the 8 TB/s peak, <= 1.  `achieved_algorithmic` / `frac_algorithmic`:
+                # SURVEY.md §8(d)'s bytes (two int32 grid layers and five int32 agent fields per env, which the engine replaces by a
+                # 1-byte shelf layer and one dword per agent) over the same time: a work rate in that unit, it may exceed 1.
+                "bound": "hbm", "unit": "GB/s", **roofline_fields(per_launch, e_launch, traffic, k_ms),
+                "note": "achieved / frac = physical bytes per launch (basis: PMC traffic of the recorded rocprofv3 pass when it belongs to "
+                        "these kernel sources, else the engine-layout bytes) / kernel time / 8 TB/s; regime says whether those bytes "
+                        "fit the 256 MiB Infinity Cache (then the figure is a cache bandwidth, not an HBM one); *_algorithmic prices "
+                        "SURVEY.md §8(d)'s bytes, which the engine does not move",
                 "kernel": "rw::rware_step_kernel", "kernel_ms_per_launch": k_ms,
-                "algorithmic_bytes_per_launch": per_launch, "kernel_sources_sha": sha,
+                "kernel_sources_sha": sha,
             },
         }
         out["ranks"] = per_rank  # a straggler (or a badly placed rank) shows here: `value` uses the MAX over ranks
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
         if sus_s:
-            s_ach = per_launch / (sus_kernel_ms * 1e-3) / 1e9
+            s_rf = roofline_fields(per_launch, e_launch, traffic, sus_kernel_ms)
             out["sustained"] = {
                 "value": world * B * N * SUSTAINED_STEPS / sus_s, "unit": "agent-steps/s",
                 "steps": SUSTAINED_STEPS, "warmup": SUSTAINED_WARMUP, "ms_per_step": sus_s / SUSTAINED_STEPS * 1e3,
-                "kernel_ms_per_launch": sus_kernel_ms, "roofline_achieved_algorithmic": s_ach, "roofline_frac": s_ach / HBM_PEAK_GBPS,
-                "roofline_frac_engine": e_launch / (sus_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "roofline_frac_physical": (traffic / (sus_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                "kernel_ms_per_launch": sus_kernel_ms, "roofline_achieved": s_rf["achieved"], "roofline_frac": s_rf["frac"],
+                "roofline_basis": s_rf["basis"], "roofline_regime": s_rf["regime"],
+                "roofline_frac_engine": s_rf["frac_engine"], "roofline_frac_physical": s_rf["frac_physical"],
+                "roofline_achieved_algorithmic": s_rf["achieved_algorithmic"], "roofline_frac_algorithmic": s_rf["frac_algorithmic"],
                 "what": "same launches as `value`, fixed length (SURVEY.md §8(d): 2000 steps after 100 warm-up, spans 4 mass resets)",
             }
         if fused_s:

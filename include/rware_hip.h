@@ -41,9 +41,10 @@ enum rw_status {
     RW_ERR_HIP = -3,            /* a HIP runtime call failed                                      */
     RW_ERR_UNSUPPORTED = -4,    /* feature outside the accelerated path (DICT observations, ...)  */
     RW_ERR_NO_DEVICE = -5,      /* no usable HIP device: there is NO CPU fallback                 */
-    RW_ERR_INDEX = -6           /* an AGENT_DIRECTION / AGENT_LOAD image layer met an agent at
+    RW_ERR_INDEX = -6,          /* an AGENT_DIRECTION / AGENT_LOAD image layer met an agent at
                                    x >= grid_h or y >= grid_w, where the reference raises IndexError
                                    (rware/warehouse.py:552,558); sticky until rw_sync             */
+    RW_ERR_SELFTEST = -7        /* rw_selftest: this device / toolchain breaks an assumption the kernels are built on */
 };
 
 /* rware/warehouse.py:31-36 */
@@ -141,12 +142,13 @@ enum rw_buffer_kind {
     RW_BUF_FEATURES = 16,    /* float32 [B][N][6]  IMAGE_DICT features: one-hot direction, on_highway,
                                                    carrying (:727-742); unused otherwise          */
     RW_BUF_AGENT_MSG = 17,   /* int32   [B][N]     bit k == message[k] of the agent (msg_bits > 0, :89)   */
-    RW_BUF_FINAL_OBS = 18,   /* float32 [B][N][L]  SAME_STEP autoreset, FLATTENED observations: the observation of the terminating
-                                                   step itself — what Warehouse.step returns with done = True (:929-946) —
-                                                   written for the envs whose `terminated` flag that step set (rows of other
-                                                   envs keep older contents); the reset observation goes to RW_BUF_OBS.  Empty
-                                                   in the other modes and for IMAGE observations                          */
-    RW_BUF_KIND_COUNT = 19
+    RW_BUF_FINAL_OBS = 18,   /* float32 [B][N][L]  SAME_STEP autoreset: the observation of the terminating step itself — what
+                                                   Warehouse.step returns with done = True (:929-946; the image, :527-596, for the
+                                                   IMAGE types) — written for the envs whose `terminated` flag that step set (rows of
+                                                   other envs keep older contents); the reset observation goes to RW_BUF_OBS.  Empty in
+                                                   the other autoreset modes                                              */
+    RW_BUF_FINAL_FEATURES = 19, /* float32 [B][N][6] ... and, IMAGE_DICT, the feature vectors of that observation (:727-742)   */
+    RW_BUF_KIND_COUNT = 20
 };
 
 /* Mirrors the constructor of rware.warehouse.Warehouse (rware/warehouse.py:146-170).  The
@@ -328,6 +330,14 @@ const char *rw_jit_log(const rw_engine *eng);
  * 2 FLATTENED + messages), baked image layers, packed layer list, image_directional (-1 for FLATTENED), non-temporal stores};
  * returns the size of the gfx code object (compiled or found in the disk cache), -1 on failure (`log` says why). */
 int64_t rw_jit_probe(const int32_t shape[15], const char *arch, char *log, size_t log_len);
+
+/* On-device self-test (no engine needed; no reference counterpart — the reference is CPU Python): runs, on HIP device `device_id`,
+ * the two toolchain / hardware facts the step kernels are written around — cross-lane exchange results compared as values in
+ * registers of their own (a DPP move folded into a non-commutative instruction came out with swapped operands on gfx950), and an
+ * LDS-DMA stage-in that is waited for explicitly in front of the workgroup barrier (a run-time compiled build once left it in flight)
+ * — with code compiled into this library, so it runs where there is no hipcc.  RW_OK, or RW_ERR_SELFTEST with the counts in `log`.
+ * RWARE_SELFTEST_BREAK=1 in the environment runs the known-bad forms instead (tests: the guard has to be able to fail). */
+int rw_selftest(int32_t device_id, char *log, size_t log_len);
 
 /* numpy SeedSequence(seed) -> PCG64 initial state, as 6 uint64 in RW_BUF_RNG field order.
  * Pure host function (exposed so tests can check the seeding against numpy). */

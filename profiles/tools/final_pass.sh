@@ -44,7 +44,7 @@ import json
 for f in ("gpurun_out/${TAG}_bench_default.json", "gpurun_out/${TAG}_bench_k20.json"):
     d = json.loads(open(f).read().strip().splitlines()[-1])
     print(f, "G=%.3f" % (d["value"] / 1e9), "us/step=%.3f" % (d["ms_per_step"] * 1e3), "sustained=%.3f" % (d["sustained"]["ms_per_step"] * 1e3),
-          "traffic=", d["roofline"]["traffic"], "frac=%.3f" % d["roofline"]["frac"], "frac_physical=", d["roofline"]["frac_physical"])
+          "traffic=", d["roofline"]["traffic"], "frac=%.3f (%s, %s)" % (d["roofline"]["frac"], d["roofline"]["basis"], d["roofline"]["regime"]), "frac_algorithmic=%.3f" % d["roofline"]["frac_algorithmic"])
 PY
 # in the build container afterwards:
 #   cp gpurun_out/pmc_traffic.json profiles/; cp gpurun_out/${TAG}_* profiles/

@@ -14,16 +14,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "librware_hip.so")
 
 RW_ABI_VERSION = 3
-RW_OK, RW_ERR_INVALID_ARG, RW_ERR_INVALID_ACTION, RW_ERR_HIP, RW_ERR_UNSUPPORTED, RW_ERR_NO_DEVICE, RW_ERR_INDEX = 0, -1, -2, -3, -4, -5, -6
+RW_OK, RW_ERR_INVALID_ARG, RW_ERR_INVALID_ACTION, RW_ERR_HIP, RW_ERR_UNSUPPORTED, RW_ERR_NO_DEVICE, RW_ERR_INDEX, RW_ERR_SELFTEST = 0, -1, -2, -3, -4, -5, -6, -7
 
 BUF = {
     "obs": 0, "rewards": 1, "terminated": 2, "truncated": 3, "grid": 4, "agent_x": 5, "agent_y": 6,
     "agent_dir": 7, "agent_carry": 8, "agent_delivered": 9, "queue": 10, "steps": 11, "inactive": 12,
-    "rng": 13, "need_reset": 14, "actions": 15, "features": 16, "agent_msg": 17, "final_obs": 18,
+    "rng": 13, "need_reset": 14, "actions": 15, "features": 16, "agent_msg": 17, "final_obs": 18, "final_features": 19,
 }
 BUF_DTYPE = {
     "obs": np.float32, "rewards": np.float32, "terminated": np.uint8, "truncated": np.uint8,
-    "rng": np.uint64, "need_reset": np.uint8, "features": np.float32, "final_obs": np.float32,
+    "rng": np.uint64, "need_reset": np.uint8, "features": np.float32, "final_obs": np.float32, "final_features": np.float32,
 }
 
 RW_STREAM_USE_GIVEN = 1  # rw_stream_flags: `stream` is taken literally, NULL == the device's default stream
@@ -60,7 +60,7 @@ EXPORTS = (
     "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_mark_views_stale", "rw_set_stream", "rw_jit_log", "rw_jit_probe", "rw_multi_create", "rw_multi_step_device", "rw_multi_destroy", "rw_sync", "rw_get_buffer", "rw_read", "rw_read_outputs", "rw_write",
     "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
     "rw_abi_version", "rw_debug_timeline", "rw_device_malloc", "rw_device_free", "rw_copy_to_device",
-    "rw_copy_to_host", "rw_snapshot_create", "rw_snapshot_save", "rw_snapshot_restore", "rw_snapshot_destroy",
+    "rw_copy_to_host", "rw_selftest", "rw_snapshot_create", "rw_snapshot_save", "rw_snapshot_restore", "rw_snapshot_destroy",
 )
 
 _libs = {}
@@ -118,6 +118,7 @@ def load(path: str | None = None):
     lib.rw_jit_log.restype = C.c_char_p
     lib.rw_jit_probe.argtypes = [C.POINTER(C.c_int32), C.c_char_p, C.c_char_p, C.c_size_t]
     lib.rw_jit_probe.restype = C.c_int64
+    lib.rw_selftest.argtypes = [i32, C.c_char_p, C.c_size_t]
     lib.rw_multi_create.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
     lib.rw_multi_step_device.argtypes = [vp, C.POINTER(vp)]
     lib.rw_multi_destroy.argtypes = [vp]
@@ -168,6 +169,14 @@ class DeviceArray:
         return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 2, "strides": None}
 
 
+def selftest(device_id: int = 0, library=None):
+    """rw_selftest: the on-device check of the toolchain facts the kernels rely on; returns (ok, message)."""
+    lib = load(library)
+    log = C.create_string_buffer(1024)
+    rc = lib.rw_selftest(int(device_id), log, len(log))
+    return rc == RW_OK, log.value.decode()
+
+
 class Engine:
     """One rw_engine: `num_envs` warehouses on one HIP device."""
 
@@ -204,7 +213,7 @@ class Engine:
         win = 2 * int(sensor_range) + 1
         obs_shape = (self.B, self.N, self.L) if int(observation_type) == 1 else (self.B, self.N, self.L // (win * win), win, win)
         self.shapes = {
-            "features": (self.B, self.N, 6),
+            "features": (self.B, self.N, 6), "final_features": (self.B, self.N, 6),
             "obs": obs_shape, "final_obs": obs_shape, "rewards": (self.B, self.N), "terminated": (self.B,),
             "truncated": (self.B,), "grid": (self.B, 2, self.H, self.W), "agent_x": (self.B, self.N),
             "agent_y": (self.B, self.N), "agent_dir": (self.B, self.N), "agent_carry": (self.B, self.N),
@@ -404,8 +413,9 @@ class MultiEngine:
             p[k] = v
         rc = self.lib.rw_multi_step_device(self._h, p)
         if rc != RW_OK:
-            msgs = [(e.lib.rw_last_error(e._h) or b"").decode() for e in self.engines]
-            raise EngineError(rc, next((m for m in msgs if m), "rw_multi_step_device failed"))
+            # (engine 0's message names the engine that failed this round; older messages of the others are not this call's)
+            msg = (self.lib.rw_last_error(self.engines[0]._h) or b"").decode()
+            raise EngineError(rc, msg or "rw_multi_step_device failed")
 
     def close(self):
         if self._h:

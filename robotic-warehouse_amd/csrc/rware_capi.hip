@@ -265,7 +265,7 @@ int pack_counters(rw_engine *eng) {
 
 size_t elem_size(int kind) {
     switch (kind) {
-        case RW_BUF_OBS: case RW_BUF_REWARDS: case RW_BUF_FEATURES: case RW_BUF_FINAL_OBS: return 4;
+        case RW_BUF_OBS: case RW_BUF_REWARDS: case RW_BUF_FEATURES: case RW_BUF_FINAL_OBS: case RW_BUF_FINAL_FEATURES: return 4;
         case RW_BUF_TERMINATED: case RW_BUF_TRUNCATED: case RW_BUF_NEED_RESET: return 1;
         case RW_BUF_RNG: return 8;
         default: return 4;
@@ -685,16 +685,17 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     n_elems[RW_BUF_ACTIONS] = szB * N * AM;
     n_elems[RW_BUF_FEATURES] = szB * N * 6;
     n_elems[RW_BUF_AGENT_MSG] = szB * N;
-    // the terminal observation of SAME_STEP autoreset (FLATTENED): allocated only where the kernel writes it
-    const bool want_final = cfg->autoreset_mode == RW_AUTORESET_SAME_STEP && !eng->image;
+    // the terminal observation of SAME_STEP autoreset (+ its IMAGE_DICT feature vectors): allocated only where the kernel writes it
+    const bool want_final = cfg->autoreset_mode == RW_AUTORESET_SAME_STEP;
     n_elems[RW_BUF_FINAL_OBS] = want_final ? szB * N * eng->L : 0;
+    n_elems[RW_BUF_FINAL_FEATURES] = want_final && obs_type == RW_OBS_IMAGE_DICT ? szB * N * 6 : 0;
     // One slab for every buffer: the per-step working set (agent SoA, queue, counters, flags, rewards,
     // shelf shadow) sits in a few contiguous MiB, so a workgroup's ~15 streams share TLB entries
     // instead of touching 15 separate allocations.  Order = hot and small first.
     static const int order[RW_BUF_KIND_COUNT] = {
         RW_BUF_AGENT_X, RW_BUF_AGENT_Y, RW_BUF_AGENT_DIR, RW_BUF_AGENT_CARRY, RW_BUF_AGENT_DELIVERED, RW_BUF_QUEUE,
         RW_BUF_AGENT_MSG, RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_NEED_RESET, RW_BUF_REWARDS, RW_BUF_TERMINATED, RW_BUF_TRUNCATED,
-        RW_BUF_ACTIONS, RW_BUF_RNG, RW_BUF_FEATURES, RW_BUF_OBS, RW_BUF_FINAL_OBS, RW_BUF_GRID};
+        RW_BUF_ACTIONS, RW_BUF_RNG, RW_BUF_FEATURES, RW_BUF_OBS, RW_BUF_FINAL_OBS, RW_BUF_FINAL_FEATURES, RW_BUF_GRID};
     auto up = [](size_t x) { return (x + 4095) & ~(size_t)4095; };
     size_t slab_bytes = 0, off[RW_BUF_KIND_COUNT];
     eng->rec_off = 0;  // the packed agent records lead the hot set, the counter records follow
@@ -786,6 +787,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.msg_bits = cfg->msg_bits;
     p.amsg = (int32_t *)eng->buf[RW_BUF_AGENT_MSG].ptr;
     p.final_obs = want_final ? (float *)eng->buf[RW_BUF_FINAL_OBS].ptr : nullptr;
+    p.final_features = n_elems[RW_BUF_FINAL_FEATURES] ? (float *)eng->buf[RW_BUF_FINAL_FEATURES].ptr : nullptr;
     rw::LaunchArgs &la = eng->la;
     la.actions = (const int32_t *)eng->buf[RW_BUF_ACTIONS].ptr;
     la.reset_mask = eng->d_mask;
@@ -1108,7 +1110,7 @@ int rw_set_stream(rw_engine *eng, void *stream) {
 
 int rw_mark_views_stale(rw_engine *eng) {
     if (!eng) return RW_ERR_INVALID_ARG;
-    eng->grid_stale = eng->agents_stale = true;
+    eng->grid_stale = eng->agents_stale = eng->counters_stale = true;  // (every derived view: grid, the five agent arrays, steps / inactive / need_reset)
     return RW_OK;
 }
 
@@ -1298,10 +1300,12 @@ void multi_worker(rw_multi *m, int k) {
 #endif
                 continue;
             }
+            // (sleepers and round are a store-then-load pair on both sides — this thread: sleepers, then round; the caller: round, then
+            //  sleepers — which needs sequential consistency to rule out "both read the old value" on weakly ordered CPUs)
             std::unique_lock<std::mutex> lk(m->mu);
-            m->sleepers.fetch_add(1);
-            m->cv.wait(lk, [&] { return m->round.load(std::memory_order_acquire) != seen || m->stop.load(); });
-            m->sleepers.fetch_sub(1);
+            m->sleepers.fetch_add(1, std::memory_order_seq_cst);
+            m->cv.wait(lk, [&] { return m->round.load(std::memory_order_seq_cst) != seen || m->stop.load(std::memory_order_seq_cst); });
+            m->sleepers.fetch_sub(1, std::memory_order_seq_cst);
         }
         if (m->stop.load(std::memory_order_acquire)) return;
         seen = m->round.load(std::memory_order_acquire);
@@ -1357,8 +1361,8 @@ int rw_multi_step_device(rw_multi *m, const int32_t *const *actions_dev) {
     }
     for (int k = 0; k < n; ++k) m->actions[(size_t)k] = actions_dev[k];
     m->pending.store(n - 1, std::memory_order_release);
-    m->round.fetch_add(1, std::memory_order_acq_rel);
-    if (m->sleepers.load(std::memory_order_acquire) > 0) {
+    m->round.fetch_add(1, std::memory_order_seq_cst);
+    if (m->sleepers.load(std::memory_order_seq_cst) > 0) {
         std::lock_guard<std::mutex> lk(m->mu);
         m->cv.notify_all();
     }
@@ -1374,7 +1378,9 @@ int rw_multi_step_device(rw_multi *m, const int32_t *const *actions_dev) {
         __builtin_ia32_pause();
 #endif
     }
-    for (int k = 1; k < n && rc == RW_OK; ++k) rc = m->rc[(size_t)k];
+    for (int k = 1; k < n && rc == RW_OK; ++k)
+        if ((rc = m->rc[(size_t)k]) != RW_OK)  // which engine, and why: into engine 0's message, the one callers of this entry point read
+            fail(e0, rc, "rw_multi_step_device: engine %d: %s", k, m->engs[(size_t)k]->err.c_str());
     return rc;
 }
 

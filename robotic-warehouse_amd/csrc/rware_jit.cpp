@@ -36,14 +36,22 @@ Rtc *rtc() {
     static std::once_flag once;
     std::call_once(once, [] {
         // a copy that is already in the process (PyTorch-ROCm bundles one next to its HIP runtime) wins; then the system's
+        // (RWARE_JIT_LIBRARY: load exactly this file instead — tests point it at a path that does not exist to take the
+        //  "no hipRTC on this box" road, which has to end in the generic kernel, not in a crash)
         const char *names[] = {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6", "/opt/rocm/lib/libhiprtc.so"};
-        for (const char *n : names) {
-            r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-            if (r.lib) break;
+        const char *only = getenv("RWARE_JIT_LIBRARY");
+        if (only && *only) {
+            r.lib = dlopen(only, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char *n : names) {
+                r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+                if (r.lib) break;
+            }
+            for (size_t i = 0; !r.lib && i < sizeof names / sizeof names[0]; ++i) r.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
         }
-        for (size_t i = 0; !r.lib && i < sizeof names / sizeof names[0]; ++i) r.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
         if (!r.lib) {
-            r.why = std::string("hipRTC not available: ") + (dlerror() ? dlerror() : "dlopen failed");
+            const char *e = dlerror();  // (ONE call: dlerror() hands the message out once and returns NULL after that)
+            r.why = std::string("hipRTC not available: ") + (e ? e : "dlopen failed");
             return;
         }
         bool ok = true;
@@ -77,15 +85,26 @@ uint64_t fnv1a(const std::string &s, uint64_t h) {
     return h;
 }
 
+// Where compiled code objects are kept: $RWARE_JIT_CACHE, else ~/.cache/rware_amd/jit.  "" = no disk cache: without HOME
+// there is no directory that is this user's alone, and a code object read back from a shared one (/tmp) would be somebody
+// else's code running in this process — so such a process compiles every time and keeps nothing.
 std::string cache_dir() {
     if (const char *e = getenv("RWARE_JIT_CACHE")) return e;
     const char *home = getenv("HOME");
-    return std::string(home && *home ? home : "/tmp") + "/.cache/rware_amd/jit";
+    if (!home || !*home) return "";
+    return std::string(home) + "/.cache/rware_amd/jit";
 }
 
 void mkdirs(const std::string &path) {
     for (size_t i = 1; i <= path.size(); ++i)
-        if (i == path.size() || path[i] == '/') mkdir(path.substr(0, i).c_str(), 0755);
+        if (i == path.size() || path[i] == '/') mkdir(path.substr(0, i).c_str(), 0700);  // (new directories: this user's only)
+}
+
+// the cache directory is trusted only if it belongs to this user and nobody else may write to it
+bool dir_is_private(const std::string &dir) {
+    struct stat st;
+    if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+    return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
 }
 
 // cache file: "RWJIT1\n<step name>\n<rollout name>\n" + code object
@@ -141,7 +160,8 @@ bool compile(const Shape &s, const char *arch, Result *out) {
              (unsigned long long)fnv1a(key, 0x84222325cbf29ce4ULL));
     const std::string dir = cache_dir(), file = dir + "/" + name;
     const char *nocache = getenv("RWARE_JIT_NO_CACHE");
-    if (!(nocache && nocache[0] == '1') && cache_read(file, out)) {
+    const bool use_cache = !dir.empty() && !(nocache && nocache[0] == '1');
+    if (use_cache && dir_is_private(dir) && cache_read(file, out)) {
         out->from_cache = true;
         out->log = "loaded " + file;
         return true;
@@ -190,11 +210,20 @@ bool compile(const Shape &s, const char *arch, Result *out) {
         out->code.clear();
         return false;
     }
-    mkdirs(dir);
-    cache_write(file, *out);
     char note[160];
-    snprintf(note, sizeof note, "compiled in %.2f s -> ", out->compile_seconds);
-    out->log = note + file;
+    snprintf(note, sizeof note, "compiled in %.2f s", out->compile_seconds);
+    out->log = note;
+    if (use_cache) {
+        mkdirs(dir);
+        if (dir_is_private(dir)) {
+            cache_write(file, *out);
+            out->log += " -> " + file;
+        } else {
+            out->log += " (not cached: " + dir + " is not a private directory of this user)";
+        }
+    } else {
+        out->log += " (not cached: no HOME / RWARE_JIT_CACHE)";
+    }
     return true;
 }
 

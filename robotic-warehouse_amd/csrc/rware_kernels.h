@@ -133,9 +133,10 @@ struct Params {
     // communication bits (rware/warehouse.py:255-259, 660-667, 810-812); only the OBS_FLATTENED_MSG kernels
     int32_t msg_bits;     // M: an action is [Action, bit_0 .. bit_{M-1}] per agent, L = 8 + (7 + M)(2r+1)^2
     int32_t *amsg;        // [B][N] bit k == message[k]
-    // SAME_STEP autoreset, FLATTENED observations: where the terminal observation of an env goes when the step that ends its
-    // episode also resets it (RW_BUF_FINAL_OBS, [B][N][L]); nullptr otherwise
+    // SAME_STEP autoreset: where the terminal observation of an env goes when the step that ends its episode also resets it
+    // (RW_BUF_FINAL_OBS, [B][N][L] — the image for the IMAGE types); nullptr otherwise
     float *final_obs;
+    float *final_features;  // ... and its IMAGE_DICT feature vectors (RW_BUF_FINAL_FEATURES, [B][N][6]), or nullptr
 };
 
 // What changes from launch to launch.  The kernel-argument segment is rewritten by the host for every
@@ -1505,6 +1506,61 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                     }
                     as_global(fin)[((size_t)e0 * N) * L + g] = v;
                 }
+                lds_barrier();  // (the reset below overwrites the arrays this read)
+            }
+        } else {
+            // ... and for the IMAGE types (rware/warehouse.py:527-596, 722-744): the terminating step's image — every requested layer of
+            // the (rotated) window, one thread per float, from the definition — and, for IMAGE_DICT, its feature vectors
+            float *fin = p.final_obs;
+            if (op == OP_STEP && k_autoreset == AR_SAME_STEP && fin != nullptr) {
+                const int Limg = k_n_layers * CELLS;
+                for (int g = tid; g < nea * Limg; g += T) {
+                    const int i = g / Limg, rest = g - i * Limg, e = rw_div18(i, mN);
+                    if (!s_envi[e * ENVI_W + ENVI_DONE]) continue;  // (only envs this step terminated)
+                    const int l = rest / CELLS, rc = rest - l * CELLS, r = rc / WIN, cc = rc - r * WIN;
+                    // (the layer id by arithmetic on the packed list or a load from the parameter block: not from the register copy,
+                    //  which a run-time index would push into scratch memory)
+                    const int layer = Cfg::kNL > 0 ? (int)((Cfg::kLayers >> (4 * l)) & 15u) : p.layers[l];
+                    const int ax = s_ax[i], ay = s_ay[i], d = k_directional ? s_dir[i] : (int)DIR_UP;
+                    int wr = r, wc = cc;  // (r, cc) indexes the rotated image, (wr, wc) the north-up window (:584-595)
+                    if (d == DIR_DOWN) { wr = WIN - 1 - r; wc = WIN - 1 - cc; }
+                    else if (d == DIR_LEFT) { wr = WIN - 1 - cc; wc = r; }
+                    else if (d == DIR_RIGHT) { wr = cc; wc = WIN - 1 - r; }
+                    const int y = ay - R + wr, x = ax - R + wc;
+                    const bool ok = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;  // outside: np.pad zeros (:573)
+                    const int cell = ok ? y * W + x : 0;
+                    const int ida = ok ? (s_ga[e * HW + cell] & 0x7f) : 0, ids = ok ? (int)s_gs[e * HW + cell] : 0;
+                    const bool tok = ok && x < H && y < W;   // layer[ag.x, ag.y]: the agent standing at (x', y') = (y, x)  (:552, :558)
+                    const int gt = tok ? (int)s_ga[e * HW + x * W + y] : 0;
+                    float v = 0.0f;
+                    if (layer == LAYER_SHELVES) v = ids ? 1.0f : 0.0f;
+                    else if (layer == LAYER_REQUESTS) {  // straight from the queue (see the FLATTENED path above)
+                        int rq = 0;
+                        for (int q = 0; q < Q; ++q) rq |= (s_queue[e * Q + q] == ids) ? 1 : 0;
+                        v = (ids && rq) ? 1.0f : 0.0f;
+                    } else if (layer == LAYER_AGENTS) v = ida ? 1.0f : 0.0f;
+                    else if (layer == LAYER_GOALS) {
+                        int gl = 0;
+                        for (int q = 0; q < k_n_goals; ++q) gl |= (ok && p.goal_cells[q] == cell) ? 1 : 0;
+                        v = gl ? 1.0f : 0.0f;
+                    } else if (layer == LAYER_ACCESSIBLE) v = (ok && !ida) ? 1.0f : 0.0f;
+                    else if (layer == LAYER_AGENT_DIRECTION) v = (gt & 0x7f) ? (float)(s_dir[e * N + (gt & 0x7f) - 1] + 1) : 0.0f;
+                    else if (layer == LAYER_AGENT_LOAD) v = (gt & 0x80) ? 1.0f : 0.0f;
+                    as_global(fin)[((size_t)e0 * N) * Limg + g] = v;
+                    if (rest == 0 && k_transposed) {  // the reference's IndexError of those two layers (:552, :558), at the terminating step too
+                        const bool counted = (k_transposed & 1) || s_carry[i];
+                        if (counted && (ax >= H || ay >= W)) atomicOr(p.status, STATUS_IMAGE_INDEX);
+                    }
+                }
+                if (p.final_features)
+                    for (int i = tid; i < nea; i += T) {
+                        if (!s_envi[rw_div18(i, mN) * ENVI_W + ENVI_DONE]) continue;
+                        RW_GLOBAL float *f = as_global(p.final_features) + ((size_t)e0 * N + i) * 6;
+                        const int d = s_dir[i];
+                        f[0] = d == 0 ? 1.0f : 0.0f; f[1] = d == 1 ? 1.0f : 0.0f; f[2] = d == 2 ? 1.0f : 0.0f; f[3] = d == 3 ? 1.0f : 0.0f;
+                        f[4] = on_highway(s_ay[i] * W + s_ax[i]) ? 1.0f : 0.0f;
+                        f[5] = s_carry[i] ? 1.0f : 0.0f;
+                    }
                 lds_barrier();  // (the reset below overwrites the arrays this read)
             }
         }

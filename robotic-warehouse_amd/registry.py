@@ -152,6 +152,8 @@ def make_pipelines(num_envs: int, n: int = 2, device: int = 0, env_id: str = Non
     kw = env_kwargs(env_id) if env_id else {}
     kw.update(kwargs)
     kw.pop("output", None)
+    if "devices" in kw:
+        raise ValueError("make_pipelines puts every sub-batch on ONE GPU: pass device=<ordinal>, not devices=")
     per = num_envs // n
     pipes, rejected = [], []
     for k in range(n):

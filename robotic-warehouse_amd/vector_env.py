@@ -240,7 +240,7 @@ class WarehouseVecEnv(_VectorEnvBase):
         self._multi = None
         # step()'s fast path: (tensor type, dtype, shape, device, bound C function, engine handle, cached result tuple); only for
         # output="torch" envs whose results are the same zero-copy views every step and whose observation needs no host-side check
-        self._has_final_obs = autoreset_mode == "same_step" and not image
+        self._has_final_obs = autoreset_mode == "same_step"
         self._fast = None
         self._fast_ok = output == "torch" and not self._dict_obs and len(devices) == 1
 
@@ -403,6 +403,8 @@ class WarehouseVecEnv(_VectorEnvBase):
             info = {"final_obs": self._gather("final_obs"), "_final_obs": term.view(np.bool_).copy()}
             if self._dict_obs:
                 info["final_obs"] = self.dict_from_flat(info["final_obs"])
+            elif want_f:  # IMAGE_DICT: the terminal observation is a dict like every other one (rware/warehouse.py:739-742)
+                info["final_obs"] = {"image": info["final_obs"], "features": self._gather("final_features")}
         if self._dict_obs:
             obs = self.dict_from_flat(obs)
         elif want_f:
@@ -605,6 +607,8 @@ class WarehouseVecEnv(_VectorEnvBase):
         if "final_obs" not in v:
             t, eng = self._torch, self.engines[d]
             v["final_obs"] = t.as_tensor(eng.device_array("final_obs"), device=v["obs"].device)
+            if self.observation_type == ObservationType.IMAGE_DICT:
+                v["final_obs"] = {"image": v["final_obs"], "features": t.as_tensor(eng.device_array("final_features"), device=v["obs"].device)}
         return {"final_obs": v["final_obs"], "_final_obs": v["terminated_bool"]}
 
     def _obs_of(self, v):
@@ -709,6 +713,9 @@ class WarehouseVecEnv(_VectorEnvBase):
             eng.close()
         self.engines = []
         self._tviews = {}
+        self._fast = None          # (the fast path of step() holds the raw engine handle and views of the freed slab)
+        self._fast_ok = False
+        self._live_actions = None
         if self._pool is not None:
             self._pool.shutdown(wait=False)
             self._pool = None

@@ -59,3 +59,35 @@ def replay(backend, meta, z, steps=None):
             bad = np.argwhere(o != w)[:5]
             raise AssertionError(f"obs differs at step {t}: {bad.tolist()}")
     return T
+
+
+def check_same_step_image_run(env, orc, B, N, steps, seed):
+    """Steps `env` (IMAGE / IMAGE_DICT, same_step autoreset) beside the oracle: observations, rewards, flags every step, and the
+    terminal observation of every env that ended an episode (info["final_obs"], rows info["_final_obs"]).  Returns how many
+    terminal observations were compared."""
+    def same(a, b):
+        if isinstance(a, dict):
+            return np.array_equal(a["image"], b[0]) and np.array_equal(a["features"], b[1])
+        return np.array_equal(a, b)
+
+    assert same(env.reset(seed=seed)[0], orc.reset(seed=seed))
+    rng = np.random.default_rng(3)
+    n_final = 0
+    for t in range(steps):
+        a = rng.choice(5, size=(B, N), p=[0.1, 0.55, 0.1, 0.1, 0.15]).astype(np.int32)
+        obs, rew, term, trunc, info = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "same_step")
+        assert same(obs, o2), t
+        assert np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+        assert ("final_obs" in info) == bool(d2.any()), t
+        if d2.any():
+            m = orc.final_mask
+            assert np.array_equal(info["_final_obs"], m), t
+            f, fo = info["final_obs"], orc.final_obs
+            if isinstance(f, dict):
+                assert np.array_equal(f["image"][m], fo[0][m]), (t, "image")
+                assert np.array_equal(f["features"][m], fo[1][m]), (t, "features")
+            else:
+                assert np.array_equal(f[m], fo[m]), t
+            n_final += int(m.sum())
+    return n_final

@@ -155,3 +155,41 @@ def test_runtime_specialisation_compiles_without_a_device(tmp_path, monkeypatch)
     assert len(list(tmp_path.glob("*.hsaco"))) == len(shapes)
     n, log = _capi.jit_probe(sensor_range=1, H=11, W=10, N=9, Q=9, S=32, E=4)       # a 4-env shelf chunk of 440 bytes: no whole DMA pieces
     assert n == -1 and "16-byte granular" in log, log
+
+
+def test_runtime_specialisation_without_hiprtc_fails_softly(tmp_path):
+    """A box without libhiprtc is the documented fall-back case (the generic kernel runs): the loader must come back with a message,
+    not crash — ADVICE r4: dlerror() was called twice in one expression, the second call returns NULL, std::string + NULL.  The
+    library handle is process-wide, so the no-library road is taken in a fresh interpreter (RWARE_JIT_LIBRARY: load exactly this)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from rware_amd import _capi; "
+            "n, log = _capi.jit_probe(sensor_range=1, H=7, W=7, N=3, Q=3, S=20, E=16); print(n); print(log)" % ROOT)
+    env = dict(os.environ, RWARE_JIT_LIBRARY=str(tmp_path / "no_such_libhiprtc.so"), RWARE_JIT_CACHE=str(tmp_path), RWARE_JIT_NO_CACHE="1")
+    pr = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, (pr.returncode, pr.stderr[-800:])
+    out = pr.stdout.strip().splitlines()
+    assert out[0] == "-1" and "hipRTC not available" in out[1], out
+
+
+def test_runtime_specialisation_keeps_no_cache_in_shared_directories(tmp_path):
+    """Without HOME (and without RWARE_JIT_CACHE) there is no directory that is this user's alone: nothing is cached; a cache directory
+    that others may write to is neither read nor written (a pre-planted code object would run inside the engine's process)."""
+    import subprocess
+    import sys
+    if not any(os.path.exists(p) for p in ("/opt/rocm/lib/libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7")):
+        pytest.skip("no hipRTC on this box")
+    code = ("import sys; sys.path.insert(0, %r); from rware_amd import _capi; "
+            "n, log = _capi.jit_probe(sensor_range=1, H=7, W=7, N=3, Q=3, S=20, E=16); print(n); print(log)" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("HOME", "RWARE_JIT_CACHE")}
+    pr = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-800:]
+    out = pr.stdout.strip().splitlines()
+    assert int(out[0]) > 10000 and "not cached" in out[1], out
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    pr = subprocess.run([sys.executable, "-c", code], env=dict(env, RWARE_JIT_CACHE=str(shared)), capture_output=True, text=True, timeout=600)
+    out = pr.stdout.strip().splitlines()
+    assert pr.returncode == 0 and int(out[0]) > 10000 and "not a private directory" in out[1], (out, pr.stderr[-400:])
+    assert not list(shared.glob("*.hsaco"))

@@ -82,8 +82,9 @@ def test_emulated_engine_matches_oracle(env_id, extra, B, geom, mode):
         o2, r2, d2 = orc.step_autoreset(a, mode)
         assert np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
         assert np.array_equal(obs, o2), t
-        if mode == "same_step" and kw.get("observation_type", 1) == 1:
+        if mode == "same_step":
             # the terminal observation of the step that ended (and reset) an episode: info["final_obs"], as Gymnasium >= 1.0 has it
+            # (FLATTENED and, round 5, the IMAGE types)
             assert ("final_obs" in info) == bool(d2.any()), t
             if d2.any():
                 assert np.array_equal(info["_final_obs"], orc.final_mask)
@@ -986,4 +987,27 @@ def test_emulated_pipelined_build_is_opt_in():
     env.close()
     env = rware_amd.WarehouseVecEnv(64, library=LIB, pipe=True, observation_type=2, **kw)
     assert env.engines[0].info.pipe_workgroups == 0      # no pipelined build for IMAGE observations: the classic kernel runs
+    env.close()
+
+
+SQUARE5 = dict(shelf_columns=3, column_height=3, shelf_rows=2, n_agents=5, msg_bits=0, sensor_range=2,
+               request_queue_size=3, max_inactivity_steps=None, max_steps=12, reward_type=1)   # a 10 x 10 grid
+
+
+@pytest.mark.parametrize("kw,extra,B,geom", [
+    (dict(rware_amd.env_kwargs("rware-small-4ag-v1"), max_steps=15), dict(observation_type=2), 16, (0, 0)),          # exact IMAGE build
+    (dict(rware_amd.env_kwargs("rware-medium-6ag-hard-v1"), max_steps=14, max_inactivity_steps=9), dict(observation_type=3), 8, (8, 128)),
+    (dict(rware_amd.env_kwargs("rware-tiny-2ag-v1"), max_steps=20, sensor_range=2), dict(observation_type=3, image_observation_directional=False), 7, (4, 64)),
+    # every layer incl. the two the reference writes with transposed indices (a square grid: no IndexError), rotated and north-up
+    (SQUARE5, dict(observation_type=2, image_observation_layers=[3, 4, 0, 1, 2, 5, 6]), 8, (4, 64)),
+    (SQUARE5, dict(observation_type=3, image_observation_layers=[4, 5, 3], image_observation_directional=False), 5, (4, 128)),
+])
+def test_emulated_image_terminal_observations_same_step(kw, extra, B, geom):
+    """SAME_STEP autoreset with IMAGE / IMAGE_DICT observations: the image (and feature vectors) the terminating step itself produced
+    (rware/warehouse.py:527-596, 722-744, 929-946) are kept as info["final_obs"] — round 5 closes the hole FLATTENED / DICT never had."""
+    kw = dict(kw, reward_type=rware_amd.enums.enum_value(kw["reward_type"]))
+    env = rware_amd.WarehouseVecEnv(B, autoreset_mode="same_step", library=LIB, envs_per_workgroup=geom[0], threads_per_workgroup=geom[1], **kw, **extra)
+    orc = OracleVecEnv(B, **kw, **extra)
+    n = gu.check_same_step_image_run(env, orc, B, kw["n_agents"], steps=45, seed=5)
+    assert n > 0
     env.close()

@@ -531,6 +531,19 @@ def test_timed_tape_launches_carry_their_own_events():
     a.close(); b.close()
 
 
+def _no_frac_above_one(d, path=""):
+    """every key named frac* in the line is a fraction of a bandwidth — only frac_algorithmic (SURVEY.md §8(d)'s
+    bytes, which the engine does not move: a work rate) may exceed 1."""
+    if isinstance(d, dict):
+        for k, v in d.items():
+            if "frac" in k and "algorithmic" not in k and isinstance(v, (int, float)):
+                assert 0 <= v <= 1.0, f"{path}.{k} = {v}"
+            _no_frac_above_one(v, f"{path}.{k}")
+    elif isinstance(d, list):
+        for i, v in enumerate(d):
+            _no_frac_above_one(v, f"{path}[{i}]")
+
+
 def _check_bench_line(out, n_gpus, steps, warmup, batch):
     import json
     assert out.returncode == 0, out.stderr[-2000:]
@@ -542,6 +555,11 @@ def _check_bench_line(out, n_gpus, steps, warmup, batch):
     expect = n_gpus * batch * 4 * steps / (d["ms_per_step"] * 1e-3 * steps)
     assert abs(d["value"] - expect) / expect < 1e-6     # whole-job aggregate over all ranks
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
+    _no_frac_above_one(d)
+    assert d["roofline"]["regime"] in ("infinity-cache", "hbm") and d["roofline"]["basis"] in ("pmc-traffic", "engine-bytes")
+    assert "native loop" in d["config"]["submit"]        # the SAME submission path at N = 1 and N > 1 ...
+    for r in d["ranks"]:                                 # ... and the graph path + the host's cost per launch beside it, per rank
+        assert r["host_issue_us_per_step"] > 0 and r["graph_ms_per_step"] > 0 and r["graph_launches_per_replay"] == min(steps, 256), r
     # priced on the bytes the engine's layout has to move: a fraction of a bandwidth, never above 1 (a timed kernel that
     # skipped work, or a byte model that over-counts, would show here)
     assert 0 < d["roofline"]["frac_engine"] <= 1.0 and 0 < d["sustained"]["roofline_frac_engine"] <= 1.0
@@ -704,8 +722,9 @@ def test_multi_device_torch_output_launches_every_shard():
 
 
 def test_bench_eight_ranks_report_placement_and_per_rank_times():
-    """`bench.py --gpus 8` (self-spawned; all ranks on this box's one device): N > 1 submits through a HIP graph by default,
-    every rank pins itself to physical cores of its GPU's NUMA node, and the line lists every rank's own time and CPUs."""
+    """`bench.py --gpus 8` (self-spawned; all ranks on this box's one device): the same native submission path as N = 1, every rank
+    pins itself to physical cores of its GPU's NUMA node, and the line lists every rank's own time, CPUs, host cost per launch and
+    the HIP-graph replay time of the same launches."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -714,7 +733,6 @@ def test_bench_eight_ranks_report_placement_and_per_rank_times():
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "300", "--warmup", "20", "--batch", "2048"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     d = _check_bench_line(out, 8, 300, 20, 2048)
-    assert "HIP graph" in d["config"]["submit"]
     ranks = d["ranks"]
     assert [r["rank"] for r in ranks] == list(range(8))
     assert all(r["ms_per_step"] > 0 and r["kernel_ms_per_launch"] > 0 for r in ranks)
@@ -742,7 +760,10 @@ def test_bench_driver_invocation_carries_every_leg():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["envs_per_gpu"] == 16384
     h = d["hbm_regime"]
-    assert h["steps"] >= 200 and 0.02 < h["kernel_ms_per_launch"] < 0.5 and 0.2 < h["frac"] < 2.0
+    assert h["steps"] >= 200 and 0.02 < h["kernel_ms_per_launch"] < 0.5 and 0.2 < h["frac"] <= 1.0 and h["frac_algorithmic"] > h["frac"]
+    assert h["regime"] == "hbm" and d["roofline"]["regime"] == "infinity-cache"   # 376 MB per step vs 23 MB
+    _no_frac_above_one(d)
+    assert d["ranks"][0]["graph_launches_per_replay"] == 20 and d["ranks"][0]["graph_ms_per_step"] > 0   # the 20-step graph replays
     a = d["api_closed_loop"]
     assert a["steps"] == 2000 and 3.0 < a["us_per_step"] < 100.0
     c = d["cpu_baseline"]
@@ -1318,4 +1339,45 @@ def test_pipelined_builds_match_oracle_full_batch(env_id, extra, B, T, mode):
     st, so = env.get_state(), orc.get_state()
     for k in so:
         assert np.array_equal(st[k], so[k]), k
+    env.close()
+
+
+def test_library_selftest_guards_run_on_this_gpu(monkeypatch):
+    """rw_selftest: the two compiler / hardware facts the kernels are written around — gathered values compared in registers of their
+    own (a DPP move folded into a subtract comes out with swapped operands on gfx950) and an LDS-DMA stage-in waited for explicitly
+    in front of the barrier — checked on THIS device by code prebuilt into the library (no hipcc needed, nothing to skip).  And the
+    guard can fail: with the known-bad forms switched in (RWARE_SELFTEST_BREAK=1) it must."""
+    from rware_amd import _capi
+    ok, msg = _capi.selftest(0)
+    assert ok, msg
+    print("rw_selftest:", msg)
+    monkeypatch.setenv("RWARE_SELFTEST_BREAK", "1")
+    ok, msg = _capi.selftest(0)
+    assert not ok, f"the broken forms passed: {msg}"
+    print("rw_selftest (broken forms):", msg)
+
+
+@pytest.mark.parametrize("env_id,extra,B", [
+    ("rware-small-4ag-v1", dict(observation_type=2, max_steps=40), 4096),                                   # exact IMAGE build
+    ("rware-medium-6ag-hard-v1", dict(observation_type=3, max_steps=35, max_inactivity_steps=20), 2048),     # IMAGE_DICT, generic kernel
+    ("rware-tiny-2ag-v1", dict(observation_type=3, image_observation_directional=False, sensor_range=2, max_steps=30), 1000),
+])
+def test_image_terminal_observations_same_step(env_id, extra, B):
+    """SAME_STEP autoreset keeps the terminating step's own IMAGE / IMAGE_DICT observation (rware/warehouse.py:
+    527-596, 929-946) as info["final_obs"]; compared with the oracle's pre-reset image on every env that ended an episode."""
+    kw = rware_amd.env_kwargs(env_id)
+    kw.update(extra)
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    env = rware_amd.WarehouseVecEnv(B, autoreset_mode="same_step", **kw)
+    orc = OracleVecEnv(B, **kw)
+    assert gu.check_same_step_image_run(env, orc, B, kw["n_agents"], steps=100, seed=4) >= 2 * B
+    env.close()
+
+
+def test_image_terminal_observations_same_step_transposed_layers():
+    kw = dict(shelf_columns=3, column_height=3, shelf_rows=2, n_agents=5, msg_bits=0, sensor_range=2, request_queue_size=3,
+              max_inactivity_steps=None, max_steps=25, reward_type=1, observation_type=2, image_observation_layers=[3, 4, 0, 1, 2, 5, 6])
+    env = rware_amd.WarehouseVecEnv(2048, autoreset_mode="same_step", **kw)
+    orc = OracleVecEnv(2048, **kw)
+    assert gu.check_same_step_image_run(env, orc, 2048, 5, steps=60, seed=9) >= 2 * 2048
     env.close()
