@@ -1011,3 +1011,34 @@ def test_emulated_image_terminal_observations_same_step(kw, extra, B, geom):
     n = gu.check_same_step_image_run(env, orc, B, kw["n_agents"], steps=45, seed=5)
     assert n > 0
     env.close()
+
+
+def test_rw_multi_launcher_threads_overlap_the_enqueues(monkeypatch):
+    """what rw_multi's thread mode is FOR, measured without eight GPUs — the emulation's launch is made a
+    "null device" that costs the calling thread 1 ms of busy time per enqueue (RWARE_EMU_LAUNCH_COST_US) and runs nothing.  One
+    rw_multi_step_device call over 8 engines: with a launcher thread per engine the call returns in about ONE enqueue (<= 1.5 x),
+    with the in-call loop in about eight."""
+    import time
+    from rware_amd import _capi
+    kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
+    res = {}
+    for threads in ("1", "0"):
+        monkeypatch.setenv("RWARE_MULTI_THREADS", threads)
+        monkeypatch.delenv("RWARE_EMU_LAUNCH_COST_US", raising=False)
+        env = rware_amd.WarehouseVecEnv(64, library=LIB, devices=[0] * 8, **kw)
+        env.reset(seed=1)
+        multi = _capi.MultiEngine(env.engines)
+        bufs = [np.zeros((8, 2), np.int32) for _ in range(8)]
+        ptrs = [x.ctypes.data for x in bufs]
+        multi.step_device(ptrs)                                     # (threads up and spinning)
+        monkeypatch.setenv("RWARE_EMU_LAUNCH_COST_US", "1000")
+        best = 1e9
+        for _ in range(12):
+            t0 = time.perf_counter()
+            multi.step_device(ptrs)
+            best = min(best, time.perf_counter() - t0)
+        res[threads] = best * 1e6
+        monkeypatch.delenv("RWARE_EMU_LAUNCH_COST_US")
+        multi.close(); env.close()
+    assert res["1"] <= 1500, res          # a launcher thread per engine: one enqueue's worth of wall time ...
+    assert res["0"] >= 7500, res          # ... the in-call loop: eight

@@ -437,9 +437,9 @@ def test_dict_observations_are_the_unflattened_oracle_vector():
     ("rware-large-16ag-v1", {"sensor_range": 2}, 16384, 520),         # config 5, per-GPU shard of 131072 / 8
 ])
 def test_full_batch_soak_every_env_against_oracle(env_id, extra, B, T):
-    """Every BASELINE config at its full per-GPU batch: EVERY env's rewards and done flags each step,
-    observations every 25 steps, and the complete final state, against the oracle; per-step launches
-    interleaved with fused 40-step rollouts, across the mass autoreset at step 500."""
+    """Every BASELINE config at its full per-GPU batch: EVERY env's rewards, done flags AND observations each step, and the
+    complete final state, against the oracle; per-step launches interleaved with fused 40-step rollouts (the first of them with
+    its observation tape, every step of it compared), across the mass autoreset at step 500."""
     kw = rware_amd.env_kwargs(env_id)
     kw.update(extra)
     N = kw["n_agents"]
@@ -455,15 +455,23 @@ def test_full_batch_soak_every_env_against_oracle(env_id, extra, B, T):
             obs, rew, term, _, _ = env.step(a)
             o2, r2, d2 = orc.step_autoreset(a, "next_step")
             assert np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
-            if t % 25 == 0:
-                assert np.array_equal(obs, o2), t
+            assert np.array_equal(obs, o2), t          # (every step: VERDICT r4 item 3 — it was every 25th)
             t += 1
-        else:              # a fused 40-step rollout
+        else:              # a fused 40-step rollout; the first one hands its observation tape back as well
             acts = rng.choice(5, size=(40, B, N), p=[.1, .5, .15, .15, .1]).astype(np.int32)
-            _, rew, term = env.rollout(acts, want_obs=False)
+            with_obs = t < 100
+            n_obs = 40 if B * N * env.engines[0].L * 4 * 40 < 2e9 else 8   # (config 5: 192 MB per step — the first 8 steps' worth)
+            if with_obs and n_obs < 40:   # two launches: 8 steps with observations, 32 without
+                otape, rew_a, term_a = env.rollout(acts[:n_obs], want_obs=True)
+                _, rew_b, term_b = env.rollout(acts[n_obs:], want_obs=False)
+                rew, term = np.concatenate([rew_a, rew_b]), np.concatenate([term_a, term_b])
+            else:
+                otape, rew, term = env.rollout(acts, want_obs=with_obs)
             for k in range(40):
                 o2, r2, d2 = orc.step_autoreset(acts[k], "next_step")
                 assert np.array_equal(rew[k], r2) and np.array_equal(term[k], d2.astype(bool)), t + k
+                if with_obs and k < n_obs:
+                    assert np.array_equal(otape[k], o2), t + k
             t += 40
     st, so = env.get_state(), orc.get_state()
     for k in so:
@@ -1380,4 +1388,44 @@ def test_image_terminal_observations_same_step_transposed_layers():
     env = rware_amd.WarehouseVecEnv(2048, autoreset_mode="same_step", **kw)
     orc = OracleVecEnv(2048, **kw)
     assert gu.check_same_step_image_run(env, orc, 2048, 5, steps=60, seed=9) >= 2 * 2048
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,extra,B,T,shards", [
+    ("rware-medium-6ag-hard-v1", {}, 65536, 540, 16),                 # BASELINE config 4 at its FULL batch on ONE device; crosses the mass autoreset
+    ("rware-large-16ag-v1", {"sensor_range": 2}, 131072, 100, 16),    # config 5 at its FULL batch: 1.54 GB of observations per step
+])
+def test_largest_single_gpu_configurations_every_step(env_id, extra, B, T, shards):
+    """with no 8-GPU node, BASELINE configs 4 and 5 run at their FULL batch on one device — every env's rewards and
+    flags, and EVERY step's observations through a per-env fixed-weight dot product (integer weights: exact in float64) computed on
+    the GPU from the engine's observation tensor and on the host from the oracle's array (tests/oracle_shards.py: the C oracle on
+    16 host threads); the complete state at the end."""
+    import torch
+    from oracle_shards import ShardedOracle
+    kw = rware_amd.env_kwargs(env_id)
+    kw.update(extra)
+    N = kw["n_agents"]
+    env = rware_amd.WarehouseVecEnv(B, output="torch", **kw)
+    assert env.engines[0].info.specialised == 1
+    orc = ShardedOracle(B, shards, **dict(kw, reward_type=kw["reward_type"].value))
+    w = torch.from_numpy(orc.w).cuda()
+
+    def cs(obs):   # (in slices: the float64 copy of 1.5 GB of observations would be 3 GB)
+        flat = obs.view(B, -1)
+        return torch.cat([flat[i:i + 16384].to(torch.float64) @ w for i in range(0, B, 16384)]).cpu().numpy()
+
+    obs, _ = env.reset(seed=77)
+    assert np.array_equal(cs(obs), orc.reset(77))
+    rng = np.random.default_rng(41)
+    for t in range(T):
+        a = rng.choice(5, size=(B, N), p=[.1, .5, .15, .15, .1]).astype(np.int32)
+        obs, rew, term, _, _ = env.step(torch.from_numpy(a).cuda())
+        c2, r2, d2 = orc.step(a)
+        assert np.array_equal(rew.cpu().numpy(), r2) and np.array_equal(term.cpu().numpy(), d2.astype(bool)), t
+        bad = np.nonzero(cs(obs) != c2)[0]
+        assert bad.size == 0, f"step {t}: the observations of {bad.size} envs differ (first: env {bad[0]})"
+    st, so = env.get_state(), orc.get_state()
+    for k in so:
+        assert np.array_equal(st[k], so[k]), k
+    orc.close()
     env.close()
