@@ -71,7 +71,8 @@ try:
 except AttributeError:
     ORIG_AFFINITY = None
 # everything that decides what a step moves: the kernels AND the host side's choices (store mode, build / geometry selection)
-KERNEL_SOURCES = ("rware_kernels.h", "rware_cdna4.h", "rware_pcg64.h", "rware_static_table.h", "rware_static.hip", "rware_generic.hip",
+KERNEL_SOURCES = ("rware_kernels.h", "rware_phase_stage_in.h", "rware_phase_pipe.h", "rware_phase_goals.h", "rware_phase_agents_reg.h",
+                  "rware_phase_agents_lds.h", "rware_phase_reset.h", "rware_phase_write_back.h", "rware_phase_gather.h", "rware_phase_expand.h", "rware_cdna4.h", "rware_pcg64.h", "rware_static_table.h", "rware_static.hip", "rware_generic.hip",
                   "rware_kernel_table.h", "rware_capi.hip")
 
 

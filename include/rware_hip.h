@@ -88,7 +88,7 @@ enum rw_stream_flags {
      * reads) wherever that was measured faster, which is everywhere except workgroups with a large observation chunk
      * (16 agents) below the Infinity Cache size.  A learner that reads the observations right behind the step finds
      * non-temporal lines in HBM rather than in the cache: RW_OBS_STORES_CACHED keeps them cached, RW_OBS_STORES_STREAM forces
-     * the hint.  (Also RWARE_OBS_STORES=cached|stream in the environment, for A/B runs.) */
+     * the hint.  (A/B runs: RWARE_OBS_STORES=cached|stream in the environment, honoured with RWARE_HOOKS=1 — csrc/rware_hooks.h.) */
     RW_OBS_STORES_CACHED = 2,
     RW_OBS_STORES_STREAM = 4,
     /* Run-time specialisation.  A task without an ahead-of-time exact-shape kernel build — a `layout=` string, column_height
@@ -96,14 +96,14 @@ enum rw_stream_flags {
      * compiled by rw_create through hipRTC (a few seconds; cached on disk under $RWARE_JIT_CACHE or ~/.cache/rware_amd/jit)
      * when the batch has at least 4096 envs; without hipRTC, or when the compile fails, the ahead-of-time generic kernel
      * runs (rw_info.jit, rw_jit_log say what happened).  RW_JIT_OFF: never.  RW_JIT_FORCE: always — small batches and shapes
-     * that have an ahead-of-time build included (tests, A/B).  (Also RWARE_JIT=off|force in the environment.) */
+     * that have an ahead-of-time build included (tests, A/B).  (A/B runs: RWARE_JIT=off|force with RWARE_HOOKS=1.) */
     RW_JIT_OFF = 8,
     RW_JIT_FORCE = 16,
     /* The chunk-pipelined persistent build of the per-step kernel (round 5): instead of one workgroup per chunk of envs, as many
      * workgroups as the GPU holds at once walk the chunks, the agent phases of the next chunk running beside the observation stores
      * of the current one and the chunk after that already on its way into LDS.  Exists for the BASELINE shapes and the agent-count-
      * static small / large warehouses (rware_static_table.h, group 18); rw_create uses it where it was measured faster
-     * (rw_info.pipe_workgroups != 0).  RW_PIPE_OFF: never.  RW_PIPE_ON: wherever a build exists.  (Also RWARE_PIPE=0|1.) */
+     * (rw_info.pipe_workgroups != 0).  RW_PIPE_OFF: never.  RW_PIPE_ON: wherever a build exists.  (A/B runs: RWARE_PIPE=0|1 with RWARE_HOOKS=1.) */
     RW_PIPE_OFF = 32,
     RW_PIPE_ON = 64
 };
@@ -317,7 +317,7 @@ typedef struct rw_info {
                                   it; bench.py prices `frac_engine` on it (<= 1 by construction)                               */
     int32_t stagger_ticks;     /* > 0: the launch is two or more rounds of workgroups (and <= 12 agents) and the k-th of the first eight workgroups a CU
                                   receives starts k * stagger_ticks * 10 ns late, so that the rounds do not run their load / compute /
-                                  store phases in lock-step (env RWARE_STAGGER_TICKS=n moves the default; 0 = off) */
+                                  store phases in lock-step (A/B runs: RWARE_STAGGER_TICKS=n with RWARE_HOOKS=1; 0 = off) */
     int32_t pipe_envs_per_workgroup; /* != 0: rw_step* launches run the chunk-pipelined persistent build with chunks of this many envs ... */
     int32_t pipe_workgroups;         /* ... on this many persistent workgroups (rw_stream_flags RW_PIPE_ON / RW_PIPE_OFF)              */
     int32_t reserved[1];
@@ -336,7 +336,7 @@ int64_t rw_jit_probe(const int32_t shape[15], const char *arch, char *log, size_
  * registers of their own (a DPP move folded into a non-commutative instruction came out with swapped operands on gfx950), and an
  * LDS-DMA stage-in that is waited for explicitly in front of the workgroup barrier (a run-time compiled build once left it in flight)
  * — with code compiled into this library, so it runs where there is no hipcc.  RW_OK, or RW_ERR_SELFTEST with the counts in `log`.
- * RWARE_SELFTEST_BREAK=1 in the environment runs the known-bad forms instead (tests: the guard has to be able to fail). */
+ * RWARE_SELFTEST_BREAK=1 (with RWARE_HOOKS=1) runs the known-bad forms instead (tests: the guard has to be able to fail). */
 int rw_selftest(int32_t device_id, char *log, size_t log_len);
 
 /* numpy SeedSequence(seed) -> PCG64 initial state, as 6 uint64 in RW_BUF_RNG field order.

@@ -5,9 +5,12 @@ fused = n: the fused rollout instead, n steps per launch (rw_step_many_device, w
 pipe = auto | off | on: the chunk-pipelined persistent per-step kernel (RWARE_PIPE_E / RWARE_PIPE_WGS_PER_CU pick its geometry).
 <env_id> may also be one of the unregistered shapes below (constructor arguments, not ids).  Per-step launches from a device action tape
 (rw_step_tape_device_timed), uniform random actions, next_step autoreset.  One line per spec."""
+import os
 import sys
 
 import numpy as np
+
+os.environ.setdefault("RWARE_HOOKS", "1")  # (this tool drives the library's A/B hooks: csrc/rware_hooks.h)
 import torch
 
 sys.path.insert(0, ".")

@@ -7,6 +7,8 @@ import sys
 
 import numpy as np
 
+os.environ.setdefault("RWARE_HOOKS", "1")  # (this tool drives the library's A/B hooks: csrc/rware_hooks.h)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/rware_hip.h"
+#include "rware_hooks.h"
 #include "rware_kernel_table.h"
 #include "rware_kernels.h"
 #include "rware_static_table.h"
@@ -454,7 +455,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // Pick a specialised build: exact-shape entries before size-static ones, first match wins.
         const bool geom_default = cfg->envs_per_workgroup == 0 && cfg->threads_per_workgroup == 0;
         const StaticEntry *best = nullptr;
-        const char *pq = getenv("RWARE_PREFER_QRT");  // (test / A-B hook: skip the exact (N, Q) builds)
+        const char *pq = rw_hook("RWARE_PREFER_QRT");  // (test / A-B hook: skip the exact (N, Q) builds)
         const bool prefer_qrt = pq && pq[0] == '1';
         for (int exact = 1; exact >= 0 && !best; --exact)
             for (int grp = 0; grp < rw_tab::kStaticGroups && !best; ++grp) {
@@ -499,7 +500,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         const long long chunk = (long long)e_ * N * eng->L;                    // floats of one workgroup's observations
         const double obs_mb = (double)B * N * eng->L * 4 / 1e6;
         bool nt = chunk <= 9500 || obs_mb > 240.0;
-        const char *pref = getenv("RWARE_OBS_STORES");  // (A/B hook: moves the default only — an explicit flag of the caller wins)
+        const char *pref = rw_hook("RWARE_OBS_STORES");  // (A/B hook: moves the default only — an explicit flag of the caller wins)
         if (pref && !strcmp(pref, "cached")) nt = false;
         if (pref && !strcmp(pref, "stream")) nt = true;
         if (cfg->stream_flags & RW_OBS_STORES_CACHED) nt = false;
@@ -513,7 +514,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // on a long run), the caller said no, or hipRTC is not there.  RW_JIT_FORCE: also for small batches and for shapes
         // that have an ahead-of-time build (tests, A/B).
         int mode = 0;  // 0 auto, -1 off, 1 force
-        const char *je = getenv("RWARE_JIT");
+        const char *je = rw_hook("RWARE_JIT");
         if (je && (!strcmp(je, "0") || !strcmp(je, "off"))) mode = -1;
         if (je && !strcmp(je, "force")) mode = 1;
         if (cfg->stream_flags & RW_JIT_OFF) mode = -1;
@@ -608,7 +609,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // (up to 12 agents: beyond, the workgroups are bound by their agent phases' instruction issue, there is little idle phase to
         //  fill and the sweep is a wash — large-16ag -3 % at 4 rounds, +4 % at 2)
         eng->stagger_ticks = (pow2 && N <= 12 && (long long)eng->n_wg >= 2 * per_cu * n_cu) ? 25 : 0;  // x 10 ns per slot (profiles/r04_stagger_sweep.txt)
-        const char *st = getenv("RWARE_STAGGER_TICKS");  // (A/B and test hook: 0 = off, n = ticks whatever the launch size)
+        const char *st = rw_hook("RWARE_STAGGER_TICKS");  // (A/B and test hook: 0 = off, n = ticks whatever the launch size)
         if (st && *st && pow2) eng->stagger_ticks = std::min(255, std::max(0, atoi(st)));
     }
 
@@ -617,12 +618,12 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // chunk size divides the batch (first match; RWARE_PIPE_E picks a geometry).  Whether it runs: the caller's RW_PIPE_ON /
         // RW_PIPE_OFF, else RWARE_PIPE=1|0 in the environment (A/B runs), else the measured rule below.
         int mode = 0;  // 0 rule, -1 off, 1 on
-        const char *pe = getenv("RWARE_PIPE");
+        const char *pe = rw_hook("RWARE_PIPE");
         if (pe && pe[0] == '0') mode = -1;
         if (pe && pe[0] == '1') mode = 1;
         if (cfg->stream_flags & RW_PIPE_OFF) mode = -1;
         if (cfg->stream_flags & RW_PIPE_ON) mode = 1;
-        const char *pee = getenv("RWARE_PIPE_E");
+        const char *pee = rw_hook("RWARE_PIPE_E");
         const int want_e = pee ? atoi(pee) : 0;
         const StaticEntry *pb = nullptr;
         if (mode >= 0 && !eng->image && eng->msg_bits == 0 && !eng->jit_step)
@@ -645,12 +646,12 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             int per_cu = 0;
             if (pe_ == hipSuccess) pe_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(fn), 256, lds);
             if (pe_ != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 0; }
-            const char *pw = getenv("RWARE_PIPE_WGS_PER_CU");  // (A/B hook: fewer resident workgroups, more chunks each)
+            const char *pw = rw_hook("RWARE_PIPE_WGS_PER_CU");  // (A/B hook: fewer resident workgroups, more chunks each)
             if (pw && atoi(pw) > 0) per_cu = std::min(per_cu, atoi(pw));
             // (whole CUs' worth of workgroups: an "even" split — 1366 workgroups of 3 chunks instead of 1536 of 2 or 3 — loads the CUs
             //  unevenly and measured slower, small-4ag x 65536: 19.5 vs 17.5 us)
             long long grid = std::min<long long>(n_chunks, (long long)per_cu * n_cu);
-            const char *pg = getenv("RWARE_PIPE_GRID");  // (test hook: a handful of workgroups, so that small batches walk several chunks each)
+            const char *pg = rw_hook("RWARE_PIPE_GRID");  // (test hook: a handful of workgroups, so that small batches walk several chunks each)
             if (pg && atoi(pg) > 0) grid = std::min<long long>(grid, atoi(pg));
             // The rule, as measured (profiles/EXPERIMENTS.md, round 5, profiles/r05_pipe_*.txt): NEVER by default.  In steady state the
             // pipelined workgroups run at the fabric's rate (small-4ag x 65536: 0.77 us per chunk and CU against the classic launch's
@@ -1336,7 +1337,7 @@ int rw_multi_create(rw_engine **engines, int32_t n, rw_multi **out) {
     for (int a = 0; a < n && distinct; ++a)
         for (int b = a + 1; b < n; ++b)
             if (engines[a]->cfg.device_id == engines[b]->cfg.device_id) { distinct = false; break; }
-    const char *force = getenv("RWARE_MULTI_THREADS");  // (1 / 0: force either mode — tests)
+    const char *force = rw_hook("RWARE_MULTI_THREADS");  // (1 / 0: force either mode — tests)
     if (force && (force[0] == '0' || force[0] == '1')) distinct = force[0] == '1';
     if (distinct)
         for (int k = 1; k < n; ++k) m->threads.emplace_back(multi_worker, m, k);

@@ -26,16 +26,6 @@ __device__ __forceinline__ void lds_dma_b32(const RW_GLOBAL void *g_lane, void *
     __builtin_amdgcn_global_load_lds(g_lane,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
 }
-// lds_zero_b128_blind(p): 16 bytes of zeros to LDS through an instruction hipcc does not look into.  hipcc orders every LDS
-// write it can see behind an LDS-DMA still in flight (s_waitcnt vmcnt(0): it cannot prove that the destinations differ), which
-// serialises "issue the stage-in DMA, then clear the scratch arrays" into DMA round trip + clear.  The scratch arrays never
-// overlap a DMA destination (rw::LdsLayout), so the clear may run underneath the DMA; the caller waits lgkmcnt(0) itself.
-__device__ __forceinline__ void lds_zero_b128_blind(void *lds_ptr) {
-    typedef int v4i_t __attribute__((ext_vector_type(4)));
-    const v4i_t z = {0, 0, 0, 0};
-    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_ptr;
-    asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(z));
-}
 // dma_wait(): every LDS-DMA (and every other vector-memory load) this wavefront has issued is complete.  The stage-in barrier
 // used to rely on __syncthreads() for this; hipRTC's runtime header defines __syncthreads() with a fence that does NOT make the
 // compiler wait for vmcnt there, so a run-time compiled build left the DMA in flight across the barrier (round 4: wrong

@@ -1,0 +1,17 @@
+// rware_hooks.h — the library's test / A-B hooks.
+//
+// A handful of decisions rw_create makes by a measured rule (observation-store mode, start stagger, which kernel build, run-time
+// specialisation, launcher threads) can be moved from the environment — for the same-box A/B runs under profiles/tools and for tests
+// that have to reach a path the rule would not take.  None of it is API: callers use rw_config.stream_flags.  So the variables are
+// honoured ONLY when RWARE_HOOKS=1 is set as well — a production process that happens to inherit one of them runs the rules.
+//   RWARE_OBS_STORES=cached|stream   RWARE_STAGGER_TICKS=n   RWARE_PREFER_QRT=1   RWARE_JIT=off|force   RWARE_JIT_LIBRARY=path
+//   RWARE_JIT_NO_CACHE=1   RWARE_PIPE=0|1   RWARE_PIPE_E=n   RWARE_PIPE_WGS_PER_CU=n   RWARE_PIPE_GRID=n   RWARE_MULTI_THREADS=0|1
+//   RWARE_SELFTEST_BREAK=1
+// (RWARE_JIT_CACHE — where compiled code objects are kept — is configuration, not a hook, and is read unconditionally.)
+#pragma once
+#include <cstdlib>
+
+inline const char *rw_hook(const char *name) {
+    const char *on = getenv("RWARE_HOOKS");
+    return (on && on[0] == '1' && on[1] == '\0') ? getenv(name) : nullptr;
+}

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 
+#include "rware_hooks.h"
 #include "rware_jit_sources.inc"
 
 namespace rw_jit {
@@ -39,7 +40,7 @@ Rtc *rtc() {
         // (RWARE_JIT_LIBRARY: load exactly this file instead — tests point it at a path that does not exist to take the
         //  "no hipRTC on this box" road, which has to end in the generic kernel, not in a crash)
         const char *names[] = {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6", "/opt/rocm/lib/libhiprtc.so"};
-        const char *only = getenv("RWARE_JIT_LIBRARY");
+        const char *only = rw_hook("RWARE_JIT_LIBRARY");
         if (only && *only) {
             r.lib = dlopen(only, RTLD_NOW | RTLD_LOCAL);
         } else {
@@ -159,7 +160,7 @@ bool compile(const Shape &s, const char *arch, Result *out) {
     snprintf(name, sizeof name, "%016llx%016llx.hsaco", (unsigned long long)fnv1a(key, 0xcbf29ce484222325ULL),
              (unsigned long long)fnv1a(key, 0x84222325cbf29ce4ULL));
     const std::string dir = cache_dir(), file = dir + "/" + name;
-    const char *nocache = getenv("RWARE_JIT_NO_CACHE");
+    const char *nocache = rw_hook("RWARE_JIT_NO_CACHE");
     const bool use_cache = !dir.empty() && !(nocache && nocache[0] == '1');
     if (use_cache && dir_is_private(dir) && cache_read(file, out)) {
         out->from_cache = true;

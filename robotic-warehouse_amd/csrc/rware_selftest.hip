@@ -23,6 +23,7 @@
 
 #include "../../include/rware_hip.h"
 #include <rware_cdna4.h>
+#include "rware_hooks.h"
 
 namespace rw {
 
@@ -91,7 +92,7 @@ extern "C" int rw_selftest(int32_t device_id, char *log, size_t log_len) {
         return done(RW_ERR_NO_DEVICE);
     }
     if (hipSetDevice(device_id) != hipSuccess) { msg = "hipSetDevice failed"; return done(RW_ERR_HIP); }
-    const char *br = getenv("RWARE_SELFTEST_BREAK");
+    const char *br = rw_hook("RWARE_SELFTEST_BREAK");
     const bool broken = br && br[0] == '1';
     char line[256];
 

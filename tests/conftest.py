@@ -7,6 +7,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# the library's test / A-B hooks (RWARE_STAGGER_TICKS, RWARE_PIPE_GRID, RWARE_MULTI_THREADS, ...: csrc/rware_hooks.h) are honoured
+# only with this switch on — tests reach paths through them that the measured rules would not take
+os.environ["RWARE_HOOKS"] = "1"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver via gpurun)")
 

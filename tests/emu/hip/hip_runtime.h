@@ -113,12 +113,11 @@ extern std::mutex emu_launch_mutex;  // one "device": launches from several host
 template <typename... KArgs, typename... Args>
 void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds_bytes, hipStream_t, Args... args) {
     (void)lds_bytes;
-    // RWARE_EMU_LAUNCH_COST_US=n (tests of the host-side fan-out): a "null device" — the launch costs the CALLING thread n
-    // microseconds of busy time, as a real enqueue does, and runs nothing; outside the one-device mutex, so launches from several
-    // host threads overlap the way enqueues on several real devices would
+    // RWARE_EMU_LAUNCH_COST_US=n (tests of the host-side fan-out): a "null device" — the launch holds the CALLING thread for n
+    // microseconds (asleep, not spinning: the measurement must not depend on how many cores the test box has free) and runs nothing;
+    // outside the one-device mutex, so launches from several host threads overlap the way enqueues on several real devices would
     if (const char *lc = getenv("RWARE_EMU_LAUNCH_COST_US")) {
-        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(atoi(lc));
-        while (std::chrono::steady_clock::now() < until) {}
+        std::this_thread::sleep_for(std::chrono::microseconds(atoi(lc)));
         return;
     }
     std::lock_guard<std::mutex> emu_launch_lock(emu_launch_mutex);

@@ -33,7 +33,6 @@ inline void keep_vgpr(int, int) {}
 inline uint32_t opaque(uint32_t x) { return x; }
 inline void store_f4_nt(float4 *dst, float4 v) { *dst = v; }  // (the hint has no host meaning)
 inline int uniform(int x) { return x; }
-inline void lds_zero_b128_blind(void *lds_ptr) { memset(lds_ptr, 0, 16); }
 inline void lds_wait() {}
 inline void dma_wait() {}
 inline void lds_barrier() { pthread_barrier_wait(emu_barrier); }

@@ -1015,7 +1015,7 @@ def test_emulated_image_terminal_observations_same_step(kw, extra, B, geom):
 
 def test_rw_multi_launcher_threads_overlap_the_enqueues(monkeypatch):
     """what rw_multi's thread mode is FOR, measured without eight GPUs — the emulation's launch is made a
-    "null device" that costs the calling thread 1 ms of busy time per enqueue (RWARE_EMU_LAUNCH_COST_US) and runs nothing.  One
+    "null device" that holds the calling thread for 2 ms per enqueue (RWARE_EMU_LAUNCH_COST_US) and runs nothing.  One
     rw_multi_step_device call over 8 engines: with a launcher thread per engine the call returns in about ONE enqueue (<= 1.5 x),
     with the in-call loop in about eight."""
     import time
@@ -1031,7 +1031,7 @@ def test_rw_multi_launcher_threads_overlap_the_enqueues(monkeypatch):
         bufs = [np.zeros((8, 2), np.int32) for _ in range(8)]
         ptrs = [x.ctypes.data for x in bufs]
         multi.step_device(ptrs)                                     # (threads up and spinning)
-        monkeypatch.setenv("RWARE_EMU_LAUNCH_COST_US", "1000")
+        monkeypatch.setenv("RWARE_EMU_LAUNCH_COST_US", "2000")
         best = 1e9
         for _ in range(12):
             t0 = time.perf_counter()
@@ -1040,5 +1040,20 @@ def test_rw_multi_launcher_threads_overlap_the_enqueues(monkeypatch):
         res[threads] = best * 1e6
         monkeypatch.delenv("RWARE_EMU_LAUNCH_COST_US")
         multi.close(); env.close()
-    assert res["1"] <= 1500, res          # a launcher thread per engine: one enqueue's worth of wall time ...
-    assert res["0"] >= 7500, res          # ... the in-call loop: eight
+    assert res["1"] <= 3000, res          # a launcher thread per engine: one enqueue's worth of wall time (<= 1.5 x) ...
+    assert res["0"] >= 15000, res         # ... the in-call loop: eight
+
+
+def test_library_hooks_need_their_switch(monkeypatch):
+    """The environment hooks (csrc/rware_hooks.h) are test / A-B instruments, not API: without RWARE_HOOKS=1 a process that happens to
+    inherit one of them runs the measured rules."""
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    monkeypatch.setenv("RWARE_STAGGER_TICKS", "40")
+    monkeypatch.setenv("RWARE_PIPE", "1")
+    env = rware_amd.WarehouseVecEnv(64, library=LIB, **kw)
+    assert env.engines[0].info.stagger_ticks == 40 and env.engines[0].info.pipe_workgroups > 0     # conftest.py switched the hooks on
+    env.close()
+    monkeypatch.delenv("RWARE_HOOKS")
+    env = rware_amd.WarehouseVecEnv(64, library=LIB, **kw)
+    assert env.engines[0].info.stagger_ticks == 0 and env.engines[0].info.pipe_workgroups == 0
+    env.close()
