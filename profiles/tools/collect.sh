@@ -9,8 +9,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-STEP="python $ROOT/bench.py --no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra"
-FUSED="python $ROOT/bench.py --no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --many 64 --steps 1024 --warmup 64"
+STEP="python $ROOT/bench.py --no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes"
+FUSED="python $ROOT/bench.py --no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes --many 64 --steps 1024 --warmup 64"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace_step" -o bench -- $STEP --steps 1000 --warmup 100 > "$OUT/trace_step.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/trace_fused" -o bench -- $FUSED > "$OUT/trace_fused.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do

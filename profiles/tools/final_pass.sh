@@ -9,8 +9,9 @@
 set -u
 TAG=${1:-rNN}
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -60 > gpurun_out/${TAG}_gpu_suite_full.txt; tail -3 gpurun_out/${TAG}_gpu_suite_full.txt | tee gpurun_out/${TAG}_gpu_suite.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+# (-rs: the reason of every skip lands in the committed file — VERDICT r4 item 7: a skipped guard must be visible)
+python -m pytest tests -m gpu -q --tb=short -rs --durations=10 2>&1 | tail -80 > gpurun_out/${TAG}_gpu_suite_full.txt; tail -3 gpurun_out/${TAG}_gpu_suite_full.txt | tee gpurun_out/${TAG}_gpu_suite.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee gpurun_out/${TAG}_smoke.txt
 bash profiles/tools/sweep.sh $TAG 2>&1 | tail -15
 cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
@@ -35,6 +36,18 @@ I2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_
 I3="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQC_DCACHE_REQ SQC_DCACHE_MISSES"
 for c in "$I1" "$I2" "$I3"; do bash profiles/tools/pmc_pass.sh ${TAG}_headline "$c"; done
 for c in "$I1" "$I2"; do bash profiles/tools/pmc_pass.sh ${TAG}_small10 "$c" --env-id rware-small-10ag-v1; bash profiles/tools/pmc_pass.sh ${TAG}_cfg5 "$c" --env-id rware-large-16ag-v1 --sensor-range 2; done
+# round 5: the chunk-pipelined persistent build against the classic launch (same box, alternating), its stage timeline, and what a
+# device-side mailbox costs per step (the resident-kernel question)
+{
+for cfg in "rware-small-4ag-v1:16384" "rware-small-4ag-v1:65536" "rware-small-4ag-v1:262144" "rware-medium-6ag-hard-v1:8192" "rware-large-16ag-v1:16384:0:auto:2" \
+           "rware-large-16ag-v1:32768:0:auto:2" "rware-small-10ag-v1:16384" "rware-large-16ag-v1:16384" "rware-tiny-2ag-v1:4096"; do
+  IFS=: read -r id B E st sr <<< "$cfg"
+  python profiles/tools/measure.py "$id:$B:0:${st:-auto}:${sr}:::off" "$id:$B:0:${st:-auto}:${sr}:::on"
+done
+} 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_pipe_ab.txt
+{ python profiles/tools/pipe_timeline.py rware-small-4ag-v1 65536; RWARE_PIPE_WGS_PER_CU=1 python profiles/tools/pipe_timeline.py rware-small-4ag-v1 65536;
+  python profiles/tools/pipe_timeline.py rware-large-16ag-v1 16384 2; python profiles/tools/pipe_timeline.py rware-small-10ag-v1 16384; } 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_pipe_timeline.txt
+[ -x profiles/tools/resident_probe ] && timeout 200 ./profiles/tools/resident_probe > gpurun_out/${TAG}_resident_probe.txt 2>&1
 python profiles/tools/k20_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_k20_probe.txt
 python profiles/tools/api_rates.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_api_rates.txt
 bash profiles/tools/unprofiled.sh $TAG > gpurun_out/${TAG}_unprofiled.txt

@@ -17,7 +17,7 @@
 #include <cstdio>
 #include <vector>
 
-struct Mailbox { uint32_t post, done, count, error; };
+struct Mailbox { uint32_t post, done, count, error; uint32_t pad[28]; uint32_t group[32 * 32]; };  // (group counters: one 128-byte line each)
 
 __device__ __forceinline__ uint64_t now_ticks() { return wall_clock64(); }  // 100 MHz
 
@@ -41,11 +41,15 @@ __global__ void __launch_bounds__(256) resident_kernel(Mailbox *mb, float *out, 
     const uint64_t t0 = now_ticks();
     for (int t = 1; t <= n_steps; ++t) {
         if (threadIdx.x == 0) {
+            // (the poll itself is a RELAXED agent-scope load — no cache invalidate per iteration — with one acquire fence behind the loop;
+            //  the first version polled with acquire loads and read the wall clock every iteration: 62 us per empty round)
             int ok = 1;
-            while (__hip_atomic_load(&mb->post, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)t) {
-                __builtin_amdgcn_s_sleep(1);
-                if (now_ticks() - t0 > 200000000ull) { ok = 0; __hip_atomic_store(&mb->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&mb->post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)t) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 0xfff) == 0 && now_ticks() - t0 > 200000000ull) { ok = 0; __hip_atomic_store(&mb->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
             go = ok;
         }
         __syncthreads();
@@ -55,9 +59,20 @@ __global__ void __launch_bounds__(256) resident_kernel(Mailbox *mb, float *out, 
         if (threadIdx.x == 0) {
             // fence_mode 0: agent-scope release on the counting atomic (L2 write-back on every workgroup); 1: workgroup-scope only
             // (NOT a valid protocol across XCDs — a lower bound for what the fence costs)
+            // 2: release, counted through a two-level tree (32 groups of 32 workgroups, one cache line per group counter): 64 serialised
+            // same-address atomics per step instead of 1024
+            if (fence_mode == 2) {
+                const uint32_t g = blockIdx.x >> 5, per = 32u;
+                const uint32_t o1 = __hip_atomic_fetch_add(&mb->group[g * 32], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (o1 + 1 == (uint32_t)t * per) {
+                    const uint32_t o2 = __hip_atomic_fetch_add(&mb->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    if (o2 + 1 == (uint32_t)t * (gridDim.x / per)) __hip_atomic_store(&mb->done, (uint32_t)t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
             const uint32_t old = fence_mode == 0 ? __hip_atomic_fetch_add(&mb->count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
                                                  : __hip_atomic_fetch_add(&mb->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old + 1 == (uint32_t)t * gridDim.x) __hip_atomic_store(&mb->done, (uint32_t)t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -66,10 +81,12 @@ __global__ void post_and_wait_kernel(Mailbox *mb, uint32_t t) {
     if (threadIdx.x != 0) return;
     const uint64_t t0 = now_ticks();
     __hip_atomic_store(&mb->post, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(&mb->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < t) {
+    uint32_t spins = 0;
+    while (__hip_atomic_load(&mb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t) {
         __builtin_amdgcn_s_sleep(1);
-        if (now_ticks() - t0 > 200000000ull) { __hip_atomic_store(&mb->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if ((++spins & 0xfff) == 0 && now_ticks() - t0 > 200000000ull) { __hip_atomic_store(&mb->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
 
 template <bool kNT>
@@ -104,7 +121,7 @@ int main() {
                 if (rep) printf("%-10s %6d B/wg  launched, one stream:            %7.3f us/step\n", nt ? "nt stores" : "cached", bytes, (wall() - t0) / T * 1e6);
             }
             // ---- resident kernel + post/wait kernels on a second stream
-            for (int fence = 0; fence < 2; ++fence) {
+            for (int fence = 0; fence < 3; ++fence) {
                 double best = 1e9;
                 uint32_t err = 0;
                 for (int rep = 0; rep < 2; ++rep) {
@@ -122,7 +139,7 @@ int main() {
                     err |= h.error | (h.done != (uint32_t)T ? 4u : 0u);
                 }
                 printf("%-10s %6d B/wg  resident, %s: %7.3f us/step%s\n", nt ? "nt stores" : "cached", bytes,
-                       fence == 0 ? "agent-scope release per wg" : "no release (lower bound)  ", best / T * 1e6, err ? "  [PROTOCOL ERROR / TIMEOUT]" : "");
+                       fence == 0 ? "agent-scope release per wg" : fence == 1 ? "no release (lower bound)  " : "release, two-level count  ", best / T * 1e6, err ? "  [PROTOCOL ERROR / TIMEOUT]" : "");
             }
         }
     // ---- the post/wait kernels alone (back-to-back dependent one-wavefront launches on one stream): the floor of the policy side

@@ -11,7 +11,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/sweep_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-sustained"
+COMMON="--no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes --no-sustained"
 # name | tape steps | trace steps | bench.py arguments
 # (small kernels get long trace runs: rocprofv3 slows the host's first few thousand launches down to ~10 us each, which
 #  leaves idle gaps in front of a ~8 us kernel; sweep_collect.py reports the back-to-back dispatches separately)
@@ -23,6 +23,8 @@ CONFIGS=(
   "small4_B65536|64|400|--batch 65536"
   "hbm_small4_B262144|16|200|--batch 262144"
   "hbm_large16_r2_B32768|16|200|--env-id rware-large-16ag-v1 --sensor-range 2 --batch 32768"
+  "cfg4_medium6hard_B65536|16|200|--env-id rware-medium-6ag-hard-v1 --batch 65536"
+  "cfg5_large16_r2_B131072|8|100|--env-id rware-large-16ag-v1 --sensor-range 2 --batch 131072"
   "image_small4_B16384|256|6000|--observation-type 2"
   "image_tiny2_B4096|256|6000|--env-id rware-tiny-2ag-v1 --batch 4096 --observation-type 2"
   "msg2_small4_B16384|256|6000|--msg-bits 2"
