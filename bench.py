@@ -235,6 +235,10 @@ def hbm_regime_leg(torch, rware_amd, local_rank, env_id, sha):
         wall = time.perf_counter() - t0
         k_ms = eng.event_elapsed_ms(0, 1) / K
         eng.sync()
+        try:
+            floor_ms = eng.debug_store_floor(100)
+        except Exception:  # noqa: BLE001
+            floor_ms = None
         info = eng.info
         a_bytes = int(info.algorithmic_bytes_per_env_step) * B
         e_bytes = int(info.engine_bytes_per_env_step) * B
@@ -246,6 +250,7 @@ def hbm_regime_leg(torch, rware_amd, local_rank, env_id, sha):
             "value": B * N * K / wall, "unit": "agent-steps/s",
             # (`achieved` / `frac`: physical bytes / time; `*_algorithmic`: SURVEY.md §8(d)'s bytes, a work rate — see roofline_fields)
             **roofline_fields(a_bytes, e_bytes, traffic, k_ms), "unit_bw": "GB/s",
+            "store_only_kernel_ms_per_launch": floor_ms, "frac_of_store_only_kernel": (floor_ms / k_ms) if floor_ms else None,
             "envs_per_workgroup": int(info.envs_per_workgroup), "kernel_specialised": bool(info.specialised),
             "start_stagger_ns_per_slot": 10 * int(info.stagger_ticks),   # launches of two or more rounds of workgroups (rw_info.stagger_ticks)
             "observation_stores": "non-temporal" if int(info.obs_stores_stream) else "cached",
@@ -582,6 +587,12 @@ def main():
         fused = timed(args.steps, t_next, many=64)
     eng.sync()
 
+    # The practical floor beside the 8 TB/s one: a kernel that only WRITES this step's observations (same geometry, same store
+    # instruction), launched back to back like the step kernel (rw_debug_store_floor)
+    try:
+        floor_ms = eng.debug_store_floor(2000 if B * N <= 1 << 18 else 200) if args.many == 0 else None
+    except Exception:  # noqa: BLE001  (a side measurement)
+        floor_ms = None
     # Every rank, at every N (N = 1 included): what a launch costs this rank's host thread, and the same launches replayed from a HIP
     # graph — so that a scaling curve can be read for host-side effects (a straggler rank, launch-rate contention) rank by rank
     modes = submit_modes_leg(torch, rware_amd, rank, local_rank, kw, B, base, args, dist) if (args.many == 0 and not args.no_submit_modes) else {}
@@ -649,6 +660,10 @@ def main():
                         "fit the 256 MiB Infinity Cache (then the figure is a cache bandwidth, not an HBM one); *_algorithmic prices "
                         "SURVEY.md §8(d)'s bytes, which the engine does not move",
                 "kernel": "rw::rware_step_kernel", "kernel_ms_per_launch": k_ms,
+                # a kernel that does nothing but write this step's observations, same launch geometry and store instruction, launched
+                # back to back: what ANY kernel producing these observations takes at the least on this device, and the step kernel's
+                # time as a multiple of it (the simulation, the window gather and the state traffic are what is on top)
+                "store_only_kernel_ms_per_launch": floor_ms, "frac_of_store_only_kernel": (floor_ms / k_ms) if floor_ms else None,
                 "kernel_sources_sha": sha,
             },
         }

@@ -347,6 +347,12 @@ int rw_seed_state(uint64_t seed, uint64_t out[6]);
 int rw_event_record(rw_engine *eng, int32_t slot /* 0..7 */);
 int rw_event_elapsed_ms(rw_engine *eng, int32_t slot_begin, int32_t slot_end, float *ms);
 
+/* measurement aid (no reference counterpart): `n_launches` back-to-back launches of a kernel that only WRITES one step's
+ * observations — the engine's launch geometry and store instruction, nothing else — timed with HIP events on the first / last launch:
+ * the least any kernel producing this step's observations can take on this device (bench.py reports it beside the 8 TB/s roofline).
+ * RW_BUF_OBS is refreshed afterwards (rw_refresh_obs). */
+int rw_debug_store_floor(rw_engine *eng, int32_t n_launches, float *ms_per_launch);
+
 /* profiling aid: runs ONE step (device actions) with per-workgroup phase stamps taken from the
  * 100 MHz wall clock; host_out receives uint64 [n_workgroups][n_marks].  Call with host_out ==
  * NULL to query the two sizes first. */

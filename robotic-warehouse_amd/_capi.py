@@ -59,7 +59,7 @@ EXPORTS = (
     "rw_create", "rw_destroy", "rw_last_error", "rw_reset", "rw_step", "rw_step_device",
     "rw_step_many_device", "rw_step_tape_device", "rw_step_tape_device_timed", "rw_refresh_obs", "rw_refresh_grid", "rw_mark_views_stale", "rw_set_stream", "rw_jit_log", "rw_jit_probe", "rw_multi_create", "rw_multi_step_device", "rw_multi_destroy", "rw_sync", "rw_get_buffer", "rw_read", "rw_read_outputs", "rw_write",
     "rw_recalc_grid", "rw_get_info", "rw_seed_state", "rw_event_record", "rw_event_elapsed_ms",
-    "rw_abi_version", "rw_debug_timeline", "rw_device_malloc", "rw_device_free", "rw_copy_to_device",
+    "rw_abi_version", "rw_debug_timeline", "rw_debug_store_floor", "rw_device_malloc", "rw_device_free", "rw_copy_to_device",
     "rw_copy_to_host", "rw_selftest", "rw_snapshot_create", "rw_snapshot_save", "rw_snapshot_restore", "rw_snapshot_destroy",
 )
 
@@ -119,6 +119,7 @@ def load(path: str | None = None):
     lib.rw_jit_probe.argtypes = [C.POINTER(C.c_int32), C.c_char_p, C.c_char_p, C.c_size_t]
     lib.rw_jit_probe.restype = C.c_int64
     lib.rw_selftest.argtypes = [i32, C.c_char_p, C.c_size_t]
+    lib.rw_debug_store_floor.argtypes = [vp, i32, C.POINTER(C.c_float)]
     lib.rw_multi_create.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
     lib.rw_multi_step_device.argtypes = [vp, C.POINTER(vp)]
     lib.rw_multi_destroy.argtypes = [vp]
@@ -384,6 +385,12 @@ class Engine:
         out = np.zeros((nwg.value, nm.value), dtype=np.uint64)
         self._check(self.lib.rw_debug_timeline(self._h, C.c_void_p(int(actions_dev_ptr)), out.ctypes.data, None, None))
         return out
+
+    def debug_store_floor(self, n_launches=2000) -> float:
+        """ms per launch of a kernel that only writes one step's observations (same geometry and store instruction): measurement aid."""
+        ms = C.c_float()
+        self._check(self.lib.rw_debug_store_floor(self._h, int(n_launches), C.byref(ms)))
+        return float(ms.value)
 
     def event_record(self, slot):
         self._check(self.lib.rw_event_record(self._h, slot))

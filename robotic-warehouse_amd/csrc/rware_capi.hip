@@ -951,6 +951,31 @@ int rw_debug_timeline(rw_engine *eng, const int32_t *actions_dev, uint64_t *host
     return rc;
 }
 
+int rw_debug_store_floor(rw_engine *eng, int32_t n_launches, float *ms_per_launch) {
+    // Measurement aid: n launches of a kernel that does NOTHING but write one step's observations — the engine's launch geometry,
+    // the engine's store instruction (16 bytes per lane, non-temporal if the engine stores that way), back to back on the engine's
+    // stream, HIP events on the first / last launch.  What any kernel that produces this step's observations pays at the least:
+    // the practical floor beside the 8 TB/s one (bench.py `roofline.store_only_*`).  RW_BUF_OBS is refreshed afterwards.
+    if (!eng || n_launches < 1 || !ms_per_launch) return RW_ERR_INVALID_ARG;
+    RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
+    const int per_wg = eng->E * eng->prm.N * eng->L;  // floats
+    float *obs = (float *)eng->buf[RW_BUF_OBS].ptr;
+    const int total = eng->prm.B * eng->prm.N * eng->L;
+    for (int k = 0; k < n_launches; ++k) {
+        hipEvent_t a = k == 0 ? eng->events[6] : nullptr, b = k == n_launches - 1 ? eng->events[7] : nullptr;
+        if (eng->prm.nt_obs)
+            hipExtLaunchKernelGGL((rw::rware_store_floor_kernel<true>), dim3(eng->n_wg), dim3(eng->T), 0, eng->stream, a, b, 0, obs, per_wg, total);
+        else
+            hipExtLaunchKernelGGL((rw::rware_store_floor_kernel<false>), dim3(eng->n_wg), dim3(eng->T), 0, eng->stream, a, b, 0, obs, per_wg, total);
+    }
+    RW_HIP(eng, hipGetLastError());
+    RW_HIP(eng, hipEventSynchronize(eng->events[7]));
+    float ms = 0.0f;
+    RW_HIP(eng, hipEventElapsedTime(&ms, eng->events[6], eng->events[7]));
+    *ms_per_launch = ms / (float)n_launches;
+    return launch(eng, eng->la, rw::OP_OBS);
+}
+
 int rw_device_malloc(rw_engine *eng, size_t bytes, void **dev_ptr) {
     if (!eng || !dev_ptr) return RW_ERR_INVALID_ARG;
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));

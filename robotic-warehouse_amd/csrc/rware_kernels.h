@@ -359,6 +359,18 @@ __global__ void rware_pack_counters_kernel(int32_t *cnt, const int32_t *steps, c
     }
 }
 
+// rw_debug_store_floor: writes `per_wg` floats per workgroup (one step's observation chunk) with the step kernel's store instruction and
+// nothing else — the floor of any kernel that has to produce those observations (measurement aid)
+template <bool kNT>
+__global__ void __launch_bounds__(256) rware_store_floor_kernel(float *obs, int per_wg, int total) {
+    const int base = (int)blockIdx.x * per_wg, n4 = min(per_wg, total - base) >> 2;
+    float4 *o = reinterpret_cast<float4 *>(obs + base);
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+        const float4 v = float4{0.0f, 1.0f, 0.0f, 0.0f};
+        if constexpr (kNT) store_f4_nt(o + i, v); else o[i] = v;
+    }
+}
+
 // Rebuilds the exported int32 grid [B][2][H][W] (rware/warehouse.py:749-755, _recalc_grid) from the state the kernels keep:
 // layer 1 = the shelf shadow, layer 0 = agent ids at the agent coordinates.  Two launches: cells, then agents.
 template <typename CellT>

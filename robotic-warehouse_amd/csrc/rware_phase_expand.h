@@ -46,6 +46,8 @@
         // (the coordinates travel as bytes: layouts wider or taller than 256 cells take the two-pass form as well — a
         //  compile-time fact in the exact-shape and size-static builds)
         const bool xy_bytes = !kRollout && !k_normalised && W <= 256 && H <= 256;  // workgroup-uniform
+        // (round 5 A/B: two passes for sensor_range >= 2 — half the expansion's VALU work, 4 % of the float4s written by the second pass —
+        //  is slower: config 5's shard 36.2 -> 36.8 us, past the Infinity Cache 76 -> 96: the partial lines cost more than the instructions)
         auto single_pass = [&](auto nt) {
             // (the thread index through an opaque copy: otherwise the address arithmetic of BOTH copies of the pass is hoisted in
             //  front of the branch that picks one — large-16ag r=2: 102 VGPRs instead of 60, 4 workgroups per CU instead of 7)

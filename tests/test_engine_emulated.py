@@ -1015,13 +1015,23 @@ def test_emulated_image_terminal_observations_same_step(kw, extra, B, geom):
 
 def test_rw_multi_launcher_threads_overlap_the_enqueues(monkeypatch):
     """what rw_multi's thread mode is FOR, measured without eight GPUs — the emulation's launch is made a
-    "null device" that holds the calling thread for 2 ms per enqueue (RWARE_EMU_LAUNCH_COST_US) and runs nothing.  One
-    rw_multi_step_device call over 8 engines: with a launcher thread per engine the call returns in about ONE enqueue (<= 1.5 x),
-    with the in-call loop in about eight."""
+    "null device" that holds the calling thread for 5 ms per enqueue (RWARE_EMU_LAUNCH_COST_US) and runs nothing.  One
+    rw_multi_step_device call over 8 engines: with a launcher thread per engine the call returns in about ONE enqueue (<= 1.5 x
+    what a single engine's call takes on this box right now, plus scheduling slack: the suite runs 6 workers on 8 cores), with
+    the in-call loop in about eight."""
     import time
     from rware_amd import _capi
     kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
     res = {}
+
+    def best_of(fn, n=10):
+        best = 1e9
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            best = min(best, time.perf_counter() - t0)
+        return best * 1e6
+
     for threads in ("1", "0"):
         monkeypatch.setenv("RWARE_MULTI_THREADS", threads)
         monkeypatch.delenv("RWARE_EMU_LAUNCH_COST_US", raising=False)
@@ -1031,17 +1041,14 @@ def test_rw_multi_launcher_threads_overlap_the_enqueues(monkeypatch):
         bufs = [np.zeros((8, 2), np.int32) for _ in range(8)]
         ptrs = [x.ctypes.data for x in bufs]
         multi.step_device(ptrs)                                     # (threads up and spinning)
-        monkeypatch.setenv("RWARE_EMU_LAUNCH_COST_US", "2000")
-        best = 1e9
-        for _ in range(12):
-            t0 = time.perf_counter()
-            multi.step_device(ptrs)
-            best = min(best, time.perf_counter() - t0)
-        res[threads] = best * 1e6
+        monkeypatch.setenv("RWARE_EMU_LAUNCH_COST_US", "5000")
+        res[threads] = best_of(lambda: multi.step_device(ptrs))
+        res["one"] = best_of(lambda: env.engines[0].step_device(ptrs[0]))
         monkeypatch.delenv("RWARE_EMU_LAUNCH_COST_US")
         multi.close(); env.close()
-    assert res["1"] <= 3000, res          # a launcher thread per engine: one enqueue's worth of wall time (<= 1.5 x) ...
-    assert res["0"] >= 15000, res         # ... the in-call loop: eight
+    assert res["1"] <= 1.5 * res["one"] + 1500, res   # a launcher thread per engine: one enqueue's worth of wall time ...
+    assert res["0"] >= 7.5 * 5000, res                # ... the in-call loop: eight
+    assert res["1"] <= 0.4 * res["0"], res
 
 
 def test_library_hooks_need_their_switch(monkeypatch):
@@ -1056,4 +1063,19 @@ def test_library_hooks_need_their_switch(monkeypatch):
     monkeypatch.delenv("RWARE_HOOKS")
     env = rware_amd.WarehouseVecEnv(64, library=LIB, **kw)
     assert env.engines[0].info.stagger_ticks == 0 and env.engines[0].info.pipe_workgroups == 0
+    env.close()
+
+
+def test_store_floor_measurement_leaves_the_observations_alone():
+    """rw_debug_store_floor (bench.py's `roofline.store_only_*`): launches that only write one step's observation bytes; RW_BUF_OBS is
+    refreshed afterwards, the state is not touched."""
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    env = rware_amd.WarehouseVecEnv(32, library=LIB, **kw)
+    o0, _ = env.reset(seed=3)
+    s0 = env.get_state()
+    assert env.engines[0].debug_store_floor(2) > 0
+    assert np.array_equal(env.observations(), o0)
+    s1 = env.get_state()
+    for k in s0:
+        assert np.array_equal(s0[k], s1[k]), k
     env.close()

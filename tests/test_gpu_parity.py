@@ -565,6 +565,8 @@ def _check_bench_line(out, n_gpus, steps, warmup, batch):
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
     _no_frac_above_one(d)
     assert d["roofline"]["regime"] in ("infinity-cache", "hbm") and d["roofline"]["basis"] in ("pmc-traffic", "engine-bytes")
+    # the practical floor beside the 8 TB/s one: a kernel that only writes this step's observations, same geometry, launched the same way
+    assert 0 < d["roofline"]["store_only_kernel_ms_per_launch"] < d["roofline"]["kernel_ms_per_launch"]
     assert "native loop" in d["config"]["submit"]        # the SAME submission path at N = 1 and N > 1 ...
     for r in d["ranks"]:                                 # ... and the graph path + the host's cost per launch beside it, per rank
         assert r["host_issue_us_per_step"] > 0 and r["graph_ms_per_step"] > 0 and r["graph_launches_per_replay"] == min(steps, 256), r
