@@ -63,8 +63,20 @@ MOVES = {
 }
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("case", sorted(MOVES))
+def _movement_params():
+    """(backend, case) pairs; the "-static" backends run the exact-shape build of rware-small-4ag, so cases with more than 4 agents
+    are not generated for them (they used to be generated and skipped: a skip in the GPU record reads like a guard that did not run)."""
+    out = []
+    for case in sorted(MOVES):
+        for b in BACKENDS:
+            name, marks = (b.values[0], b.marks) if hasattr(b, "values") else (b, ())
+            if "-static" in name and len(MOVES[case][0]) > 4:
+                continue
+            out.append(pytest.param(name, case, marks=marks, id=f"{case}-{name}"))
+    return out
+
+
+@pytest.mark.parametrize("backend,case", _movement_params())
 def test_movement_kat(backend, case):
     agents, actions, expect = MOVES[case]
     env = make(backend, len(agents))
