@@ -370,7 +370,7 @@ def submit_modes_leg(torch, rware_amd, rank, local_rank, kw, B, tape_ptr, args, 
     """Per rank: (1) host time per issued launch — n launches enqueued through the library's native loop on an idle stream, clock
     stopped when the call returns (nothing waited for); (2) the per-step launches of the timed region captured into a HIP graph
     (min(steps, one tape pass) of them) and replayed: one host call per replay.  A second engine of the same shape on a stream
-    torch can capture; all ranks run this side by side (barrier in front), like the timed region."""
+    torch can capture; all ranks run this side by side (they arrive together from the timed region's closing fence)."""
     G = max(1, min(args.steps, TAPE_STEPS))
     gs = torch.cuda.Stream(device=local_rank)
     with torch.cuda.stream(gs):
@@ -382,8 +382,8 @@ def submit_modes_leg(torch, rware_amd, rank, local_rank, kw, B, tape_ptr, args, 
         with torch.cuda.stream(gs):
             e2.step_tape_device(tape_ptr, TAPE_STEPS, 0, 64)
             torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
+            # (no barrier in here: the ranks arrive together from the timed region's closing fence, and a rank that failed in this
+            #  side measurement must not leave the others waiting at a rendezvous)
             n = 256
             t0 = time.perf_counter()
             e2.step_tape_device(tape_ptr, TAPE_STEPS, 0, n)
@@ -396,8 +396,6 @@ def submit_modes_leg(torch, rware_amd, rank, local_rank, kw, B, tape_ptr, args, 
             torch.cuda.synchronize()
             graph.replay()
             torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
             reps = max(1, 512 // G)
             t0 = time.perf_counter()
             for _ in range(reps):

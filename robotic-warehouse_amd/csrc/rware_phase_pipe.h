@@ -11,6 +11,8 @@
     // counter records — ONE wavefront issues the whole list (LDS-DMA, 1 KiB per instruction), nothing is waited for here
     auto pipe_stage_in = [&](int ce0, int32_t *base) RW_INLINE {
         if constexpr (kPipe) {
+            static_assert(!kPipe || ((Cfg::kE * Cfg::kN) % 4 == 0 && (Cfg::kE * Cfg::kQcap) % 4 == 0 && Cfg::kE % 4 == 0 &&
+                                     (Cfg::kE * Cfg::kH * Cfg::kW * (int)sizeof(CellT)) % 16 == 0), "chunk not 16-byte granular");
             const RW_GLOBAL char *src[6] = {as_bytes(g_shadow + (size_t)ce0 * HW), as_bytes(q_rec + (size_t)ce0 * N),
                                             as_bytes(as_global(la.actions) + (size_t)ce0 * N * AM), as_bytes(q_queue + (size_t)ce0 * Q),
                                             as_bytes(q_hw), as_bytes(q_cnt + ce0)};
