@@ -350,7 +350,7 @@ int rw_event_elapsed_ms(rw_engine *eng, int32_t slot_begin, int32_t slot_end, fl
 /* measurement aid (no reference counterpart): `n_launches` back-to-back launches of a kernel that only WRITES one step's
  * observations — the engine's launch geometry and store instruction, nothing else — timed with HIP events on the first / last launch:
  * the least any kernel producing this step's observations can take on this device (bench.py reports it beside the 8 TB/s roofline).
- * RW_BUF_OBS is refreshed afterwards (rw_refresh_obs). */
+ * RW_BUF_OBS is refreshed afterwards (rw_refresh_obs).  Uses the engine's timing-event slots 6 and 7 (rw_event_record). */
 int rw_debug_store_floor(rw_engine *eng, int32_t n_launches, float *ms_per_launch);
 
 /* profiling aid: runs ONE step (device actions) with per-workgroup phase stamps taken from the
