@@ -39,8 +39,9 @@ except Exception:  # pragma: no cover - exercised only where gymnasium is missin
 
 def _autoreset_metadata(mode):
     """`metadata["autoreset_mode"]`: a `gymnasium.vector.AutoresetMode` member when the real package is present (what
-    Gymnasium >= 1.0 wrappers compare against), the plain string otherwise.  Untested against real gymnasium: the build
-    image does not have it."""
+    Gymnasium >= 1.0 wrappers compare against), the plain string otherwise.  The build image has no gymnasium wheel: this branch
+    and `registry.register_gymnasium()` run in CI against a fake of the API (tests/test_gymnasium_boundary.py) and against the real
+    package wherever it is installed (tests/test_gymnasium_real.py)."""
     if _gym is not None:
         try:
             from gymnasium.vector import AutoresetMode
