@@ -15,6 +15,8 @@ The printed JSON line carries
   value / ms_per_step   exactly K steps after W warm-up steps, barrier + device sync on both sides
   sustained             the same launches for a fixed 2000 steps after 100 warm-up steps (SURVEY.md §8(d) protocol,
                         spans 4 mass resets) — the steady state, whatever K and W the caller chose
+  soak                  the same launches back to back for >= 3 s (steps, ms_per_step, wall_s): visible to a utilisation sampler outside
+                        this process, checkable against the caller's own clock
   roofline              bytes per launch / HIP-event time per launch on the engine's stream (the two events ride on the first
                         and the last launch of the timed region: rw_step_tape_device_timed) vs the 8 TB/s HBM peak.
                         `achieved` / `frac` are the PHYSICAL bandwidth: `traffic` (bytes per launch from the rocprofv3 PMC
@@ -66,6 +68,7 @@ def roofline_fields(a_bytes, e_bytes, traffic, k_ms):
     }
 TAPE_STEPS = int(os.environ.get("RWARE_BENCH_TAPE_STEPS", "256"))
 SUSTAINED_STEPS, SUSTAINED_WARMUP = 2000, 100
+SOAK_SECONDS = 3.2  # the `soak` leg: back-to-back launches for at least this long (an outside utilisation sampler can see the GPU busy)
 try:
     ORIG_AFFINITY = set(os.sched_getaffinity(0))  # before pin_rank() narrows it
 except AttributeError:
@@ -76,12 +79,40 @@ KERNEL_SOURCES = ("rware_kernels.h", "rware_phase_stage_in.h", "rware_phase_pipe
                   "rware_kernel_table.h", "rware_capi.hip")
 
 
+def strip_cxx_comments(text: str) -> str:
+    """C++ source without // and /* */ comments (string and character literals respected), runs of white space collapsed, blank lines
+    dropped: what the compiler sees.  A comment or layout edit leaves it unchanged."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":  # a literal: copy it through verbatim
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            while i < n and text[i] != "\n":
+                i += 2 if (text[i] == "\\" and i + 1 < n and text[i + 1] == "\n") else 1  # (a line comment continues behind a backslash-newline)
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    lines = (" ".join(ln.split()) for ln in "".join(out).splitlines())
+    return "\n".join(ln for ln in lines if ln)
+
+
 def kernel_sources_sha() -> str:
-    """Identifies the kernel a PMC traffic figure was measured on (profiles/pmc_traffic.json carries the same hash)."""
+    """Identifies the kernels a PMC traffic figure was measured on (profiles/pmc_traffic.json carries the same hash; a CPU test,
+    tests/test_host_layer.py, fails while the two differ).  Hashes the CODE of the kernel sources — comments and white space are
+    stripped first, so a comment edit behind the evidence pass does not orphan the evidence (round 5 lost `roofline.traffic` that way)."""
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "robotic-warehouse_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "robotic-warehouse_amd", "csrc", name), "r", encoding="utf-8") as f:
+            h.update(name.encode() + b"\0" + strip_cxx_comments(f.read()).encode() + b"\0")
     return h.hexdigest()[:16]
 
 
@@ -437,6 +468,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-rollout measurement (profiling runs)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the fixed 2000-step sustained leg (profiling runs)")
+    ap.add_argument("--no-soak", action="store_true", help="skip the >= 3 s soak leg (profiling runs)")
     ap.add_argument("--no-hbm-regime", action="store_true", help="skip the cache-exceeding leg (small-4ag x 262144 envs)")
     ap.add_argument("--no-api-loop", action="store_true", help="skip the Python closed-loop API leg")
     ap.add_argument("--no-submit-modes", action="store_true", help="skip the per-rank host-issue / HIP-graph side measurement")
@@ -576,6 +608,20 @@ def main():
         sus = timed(SUSTAINED_STEPS, t_next)
         t_next += SUSTAINED_STEPS
 
+    # Soak: the same per-step launches back to back for >= SOAK_SECONDS — long enough for a utilisation sampler outside this process
+    # (the driver's gpu_busy probe sees < 1 s of GPU work in the legs above) and for the clocks to settle.  Rank-local, no barrier.
+    soak = None
+    if not args.no_soak and args.many == 0:
+        per_step = (sus[0] / SUSTAINED_STEPS) if sus else (elapsed / args.steps)
+        n_soak = int(SOAK_SECONDS / max(per_step, 1e-7)) + 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.step_tape_device_timed(base, TAPE_STEPS, t_next % TAPE_STEPS, n_soak, 0, 1)
+        torch.cuda.synchronize()
+        soak = (time.perf_counter() - t0, eng.event_elapsed_ms(0, 1) / n_soak, n_soak)
+        t_next += n_soak
+        eng.sync()
+
     # Extra (reported beside the headline, never as `value`): the same K steps through the fused rollout
     # API, rw_step_many_device — one launch per 64 steps, env chunk resident in LDS (open-loop).
     fused = None
@@ -678,6 +724,14 @@ def main():
                 "roofline_frac_engine": s_rf["frac_engine"], "roofline_frac_physical": s_rf["frac_physical"],
                 "roofline_achieved_algorithmic": s_rf["achieved_algorithmic"], "roofline_frac_algorithmic": s_rf["frac_algorithmic"],
                 "what": "same launches as `value`, fixed length (SURVEY.md §8(d): 2000 steps after 100 warm-up, spans 4 mass resets)",
+            }
+        if soak:
+            k_rf = roofline_fields(per_launch, e_launch, traffic, soak[1])
+            out["soak"] = {
+                "what": "the same per-step launches as `value`, back to back for >= 3 s on rank 0 (steps x ms_per_step = wall_s: check it against "
+                        "the driver's clock; long enough for an outside GPU-utilisation sampler to see the device busy)",
+                "steps": soak[2], "ms_per_step": soak[0] / soak[2] * 1e3, "wall_s": soak[0], "kernel_ms_per_launch": soak[1],
+                "value": B * N * soak[2] / soak[0], "unit": "agent-steps/s (this rank)", "roofline_frac": k_rf["frac"], "roofline_basis": k_rf["basis"],
             }
         if fused_s:
             out["fused_rollout"] = {

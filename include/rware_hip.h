@@ -101,9 +101,12 @@ enum rw_stream_flags {
     RW_JIT_FORCE = 16,
     /* The chunk-pipelined persistent build of the per-step kernel (round 5): instead of one workgroup per chunk of envs, as many
      * workgroups as the GPU holds at once walk the chunks, the agent phases of the next chunk running beside the observation stores
-     * of the current one and the chunk after that already on its way into LDS.  Exists for the BASELINE shapes and the agent-count-
-     * static small / large warehouses (rware_static_table.h, group 18); rw_create uses it where it was measured faster
-     * (rw_info.pipe_workgroups != 0).  RW_PIPE_OFF: never.  RW_PIPE_ON: wherever a build exists.  (A/B runs: RWARE_PIPE=0|1 with RWARE_HOOKS=1.) */
+     * of the current one and the chunk after that already on its way into LDS.  Measured SLOWER than the classic launch on every
+     * configuration (profiles/EXPERIMENTS.md, round 5), so: rw_create NEVER picks it by itself, and the default library does not even
+     * contain it — only a `make PIPE=1` build does (rware_static_table.h, group 18: the BASELINE shapes and two agent-count-static
+     * ones).  RW_PIPE_ON: use it where such a build exists for the shape (FLATTENED, no messages, ahead-of-time kernels, batch a multiple of
+     * its chunk size), else the classic kernel runs and rw_jit_log() says why; rw_info.pipe_workgroups != 0 tells which one runs.
+     * RW_PIPE_OFF: never (the default).  (A/B runs: RWARE_PIPE=0|1 with RWARE_HOOKS=1.) */
     RW_PIPE_OFF = 32,
     RW_PIPE_ON = 64
 };

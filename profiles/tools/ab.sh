@@ -13,7 +13,7 @@ for r in 1 2; do
     echo -n "$v: "
     for spec in "$@"; do
       IFS=':' read -r b e t n <<< "$spec"
-      python bench.py --no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes --no-sustained --batch $b --steps $n --warmup 50 --envs-per-wg $e --threads-per-wg $t ${AB_ARGS:-} 2>/dev/null \
+      python bench.py --no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes --no-sustained --no-soak --batch $b --steps $n --warmup 50 --envs-per-wg $e --threads-per-wg $t ${AB_ARGS:-} 2>/dev/null \
         | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('B', d['config']['envs_per_gpu'], 'E', d['config']['envs_per_workgroup'], 'T', d['config']['threads_per_workgroup'], 'us/step %.3f' % (d['ms_per_step']*1e3), 'kernel %.3f |' % (d['roofline']['kernel_ms_per_launch']*1e3), end=' ')"
     done
     echo

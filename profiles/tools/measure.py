@@ -1,5 +1,5 @@
 """us per step of explicit (task, batch, geometry, observation-store) combinations, un-profiled, HIP events on the launches.
-    python profiles/tools/measure.py <env_id>:<B>[:<E>[:<stores>[:<sensor_range>[:<jit>[:<fused>[:<pipe>]]]]]] ...
+    python profiles/tools/measure.py <env_id>:<B>[:<E>[:<stores>[:<sensor_range>[:<jit>[:<fused>[:<pipe>[:<threads per workgroup>]]]]]]] ...
 E = 0: the engine's own geometry; stores = auto | cached | stream; jit = auto | off | force (run-time specialisation);
 fused = n: the fused rollout instead, n steps per launch (rw_step_many_device, wall clock around 32 launches);
 pipe = auto | off | on: the chunk-pipelined persistent per-step kernel (RWARE_PIPE_E / RWARE_PIPE_WGS_PER_CU pick its geometry).
@@ -33,12 +33,13 @@ for spec in sys.argv[1:]:
     jit = {"auto": None, "off": False, "force": True}[f[5]] if len(f) > 5 and f[5] else None
     fused = int(f[6]) if len(f) > 6 and f[6] else 0
     pipe = {"auto": None, "off": False, "on": True}[f[7]] if len(f) > 7 and f[7] else None
+    T_wg = int(f[8]) if len(f) > 8 and f[8] else 256
     kw = dict(CUSTOM[env_id]) if env_id in CUSTOM else rware_amd.env_kwargs(env_id)
     if sr:
         kw["sensor_range"] = sr
     N = kw["n_agents"]
     try:
-        env = rware_amd.WarehouseVecEnv(B, envs_per_workgroup=E, threads_per_workgroup=256 if E else 0, obs_stores=stores, jit=jit, pipe=pipe, **kw)
+        env = rware_amd.WarehouseVecEnv(B, envs_per_workgroup=E, threads_per_workgroup=T_wg if E else 0, obs_stores=stores, jit=jit, pipe=pipe, **kw)
     except Exception as exc:  # noqa: BLE001
         print(f"{spec:44s} FAILED {exc}")
         continue
@@ -69,7 +70,7 @@ for spec in sys.argv[1:]:
     eng.sync()
     i = eng.info
     eb = int(i.engine_bytes_per_env_step) * B
-    geom = f"pipe E {int(i.pipe_envs_per_workgroup):2d} x {int(i.pipe_workgroups):4d} wgs" if int(i.pipe_workgroups) else f"E {int(i.envs_per_workgroup):2d}"
+    geom = f"pipe E {int(i.pipe_envs_per_workgroup):2d} x {int(i.pipe_workgroups):4d} wgs" if int(i.pipe_workgroups) else f"E {int(i.envs_per_workgroup):2d}" + (f" T {int(i.threads_per_workgroup)}" if int(i.threads_per_workgroup) != 256 else "")
     print(f"{spec:44s} {KIND[int(i.build_kind)] + (' (jit)' if int(i.jit) > 0 else ''):18s} {geom} {'nt' if int(i.obs_stores_stream) else 'cached':6s} "
           f"{best:8.3f} us/step {B * N / best / 1e3:7.2f} G a-s/s  engine {eb / 1e6:7.1f} MB -> {eb / best / 1e6:5.2f} TB/s = {eb / best / 8e6:4.2f} of peak", flush=True)
     env.close()

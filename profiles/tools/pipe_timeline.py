@@ -15,7 +15,7 @@ import torch  # noqa: E402
 
 import rware_amd  # noqa: E402
 
-TL_PIPE = 16
+TL_PIPE = 24
 
 
 def main():

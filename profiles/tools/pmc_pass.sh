@@ -7,7 +7,7 @@ ROOT=$(pwd); OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 N=$(ls -d "$OUT"/pass* 2>/dev/null | wc -l)
-rocprofv3 --pmc $COUNTERS -d "$OUT/pass$N" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes --no-sustained --steps 30 --warmup 10 "$@" > "$OUT/pass$N.out" 2> "$OUT/pass$N.err"
+rocprofv3 --pmc $COUNTERS -d "$OUT/pass$N" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes --no-sustained --no-soak --steps 30 --warmup 10 "$@" > "$OUT/pass$N.out" 2> "$OUT/pass$N.err"
 cd "$ROOT"
 python profiles/tools/summarize_rocpd.py "$OUT" > "gpurun_out/${TAG}_pmc.txt" 2>&1
 find "$OUT" -name '*.db' -size +4M -delete

@@ -11,7 +11,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/sweep_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes --no-sustained"
+COMMON="--no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes --no-sustained --no-soak"
 # name | tape steps | trace steps | bench.py arguments
 # (small kernels get long trace runs: rocprofv3 slows the host's first few thousand launches down to ~10 us each, which
 #  leaves idle gaps in front of a ~8 us kernel; sweep_collect.py reports the back-to-back dispatches separately)

@@ -3,7 +3,7 @@
 TAG=${1:-r02}
 OUT=gpurun_out/${TAG}_unprofiled.jsonl
 : > $OUT
-COMMON="--no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes"
+COMMON="--no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes --no-soak"
 run() { name=$1; tape=$2; shift 2; RWARE_BENCH_TAPE_STEPS=$tape python bench.py $COMMON "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d['sweep_config']='$name'; print(json.dumps(d))" >> $OUT; }
 run headline_small4_B16384 256 --steps 6000 --warmup 200
 run cfg2_tiny2_B4096 256 --env-id rware-tiny-2ag-v1 --batch 4096 --steps 6000 --warmup 200
@@ -21,7 +21,7 @@ run msg2_small4_B16384 256 --msg-bits 2 --steps 6000 --warmup 200
 run small8_B16384 256 --env-id rware-small-8ag-v1 --steps 6000 --warmup 200
 run small10_B16384 256 --env-id rware-small-10ag-v1 --steps 3000 --warmup 200
 run large16_B16384 64 --env-id rware-large-16ag-v1 --steps 1500 --warmup 100
-RWARE_BENCH_TAPE_STEPS=256 python bench.py --no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes --no-sustained --many 64 --steps 4096 --warmup 64 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d['sweep_config']='fused64_small4_B16384'; print(json.dumps(d))" >> $OUT
+RWARE_BENCH_TAPE_STEPS=256 python bench.py --no-cpu-baseline --no-hbm-regime --no-api-loop --no-fused-extra --no-submit-modes --no-sustained --no-soak --many 64 --steps 4096 --warmup 64 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d['sweep_config']='fused64_small4_B16384'; print(json.dumps(d))" >> $OUT
 python - <<PY
 import json
 print("%-28s %10s %12s %12s" % ("config", "us/step", "sustained", "G agent-st/s"))

@@ -420,8 +420,11 @@ class MultiEngine:
             p[k] = v
         rc = self.lib.rw_multi_step_device(self._h, p)
         if rc != RW_OK:
-            # (engine 0's message names the engine that failed this round; older messages of the others are not this call's)
+            # (engine 0's message names the engine that failed this round — rw_multi_step_device writes it there on every path;
+            #  should it be empty all the same, the first engine that has one)
             msg = (self.lib.rw_last_error(self.engines[0]._h) or b"").decode()
+            if not msg:
+                msg = next((m for m in ((self.lib.rw_last_error(e._h) or b"").decode() for e in self.engines[1:]) if m), "")
             raise EngineError(rc, msg or "rw_multi_step_device failed")
 
     def close(self):

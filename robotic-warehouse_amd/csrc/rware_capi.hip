@@ -131,7 +131,12 @@ const StaticEntry *static_group(int group, int *n) {
     static const fn_t kGroups[kStaticGroups] = {static_group_0,  static_group_1,  static_group_2,  static_group_3,  static_group_4,  static_group_5,
                                                 static_group_6,  static_group_7,  static_group_8,  static_group_9,  static_group_10, static_group_11,
                                                 static_group_12, static_group_13, static_group_14, static_group_15, static_group_16, static_group_17,
+#if RW_WITH_PIPE
                                                 static_group_18};
+#else
+                                                nullptr};  // (group 18 — the chunk-pipelined persistent builds — is only in a `make PIPE=1` library)
+    if (!kGroups[group]) { *n = 0; return nullptr; }
+#endif
     return kGroups[group](n);
 }
 }  // namespace rw_tab
@@ -609,6 +614,18 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // (up to 12 agents: beyond, the workgroups are bound by their agent phases' instruction issue, there is little idle phase to
         //  fill and the sweep is a wash — large-16ag -3 % at 4 rounds, +4 % at 2)
         eng->stagger_ticks = (pow2 && N <= 12 && (long long)eng->n_wg >= 2 * per_cu * n_cu) ? 25 : 0;  // x 10 ns per slot (profiles/r04_stagger_sweep.txt)
+        // 13 .. 16 agents (round 6, profiles/r06_stagger_single_round.txt, r06_t128_stagger.txt): these launches gain from WIDER slots, and
+        // already when the launch is resident at once — eight workgroups per CU with two agent wavefronts each contend for the same
+        // SIMDs in their agent phases, and 0.55 us between their starts takes the phases apart (16384 envs: medium-13ag 17.7 -> 16.4 us,
+        // small-13ag 18.1 -> 17.0, small-15ag 20.4 -> 19.3, small-14ag 17.3 -> 17.0, large-16ag 18.0 -> 17.3; four rounds and more: small-14ag x
+        // 65536 55.1 -> 49.5, large-16ag x 65536 61.1 -> 59.3).  Exactly two rounds lose (large-16ag x 32768 30.8 -> 32.0, medium-16ag x 32768
+        // 31.2 -> 32.5): left alone.  9 .. 12 and 17 .. 19 agents lose or do not move at one round (small-10ag 13.1 -> 13.5, 19ag 21.2 -> 21.6).
+        // sensor_range 2 (BASELINE config 5, 4-env workgroups, two rounds at 16384 envs): 40 ticks, 35.1 -> 34.5; four rounds +-0.
+        if (pow2 && N >= 13 && N <= 16 && per_cu > 0) {
+            const long long resident = per_cu * n_cu, wg = (long long)eng->n_wg;
+            if (R == 1) eng->stagger_ticks = (wg <= resident || wg >= 4 * resident) ? 55 : 0;
+            else if (R == 2) eng->stagger_ticks = (wg <= 2 * resident) ? 40 : 0;
+        }
         const char *st = rw_hook("RWARE_STAGGER_TICKS");  // (A/B and test hook: 0 = off, n = ticks whatever the launch size)
         if (st && *st && pow2) eng->stagger_ticks = std::min(255, std::max(0, atoi(st)));
     }
@@ -666,6 +683,16 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
                 eng->pipe_grid = (int)grid;
                 eng->pipe_lds = lds;
             }
+        }
+        if (mode == 1 && !eng->pipe_kernel) {  // asked for and not available: say so where rw_get_info().pipe_workgroups == 0 sends the caller (rw_jit_log)
+            if (!eng->jit_log.empty()) eng->jit_log += " | ";
+            eng->jit_log += "pipe: RW_PIPE_ON requested, the classic kernel runs: ";
+#if RW_WITH_PIPE
+            eng->jit_log += pb ? "the pipelined build of this shape does not fit (LDS / occupancy)"
+                               : "no pipelined build for this shape (FLATTENED without messages, ahead-of-time builds, batch a multiple of its chunk size)";
+#else
+            eng->jit_log += "this library was built without the pipelined kernels (make PIPE=1)";
+#endif
         }
     }
 
@@ -960,7 +987,7 @@ int rw_debug_store_floor(rw_engine *eng, int32_t n_launches, float *ms_per_launc
     RW_HIP(eng, hipSetDevice(eng->cfg.device_id));
     const int per_wg = eng->E * eng->prm.N * eng->L;  // floats
     float *obs = (float *)eng->buf[RW_BUF_OBS].ptr;
-    const int total = eng->prm.B * eng->prm.N * eng->L;
+    const size_t total = (size_t)eng->prm.B * eng->prm.N * eng->L;  // (size_t, like the step kernel's offsets: past 2^31 floats for large batches)
     for (int k = 0; k < n_launches; ++k) {
         hipEvent_t a = k == 0 ? eng->events[6] : nullptr, b = k == n_launches - 1 ? eng->events[7] : nullptr;
         if (eng->prm.nt_obs)
@@ -1374,14 +1401,21 @@ int rw_multi_step_device(rw_multi *m, const int32_t *const *actions_dev) {
     if (!m || !actions_dev) return RW_ERR_INVALID_ARG;
     const int n = (int)m->engs.size();
     if (m->threads.empty()) {  // engines that share devices: one loop, this thread
+        // (whatever fails, and on whichever engine: the message goes to engine 0, the one callers of this entry point read)
+        rw_engine *e0 = m->engs[0];
         for (int k = 0; k < n; ++k) {
             rw_engine *e = m->engs[(size_t)k];
-            if (!actions_dev[k]) return fail(e, RW_ERR_INVALID_ARG, "rw_multi_step_device: no action array for engine %d", k);
-            RW_HIP(e, hipSetDevice(e->cfg.device_id));
-            rw::LaunchArgs la = e->la;
-            la.actions = actions_dev[k];
-            const int rc1 = launch(e, la, rw::OP_STEP);
-            if (rc1 != RW_OK) return rc1;
+            if (!actions_dev[k]) return fail(e0, RW_ERR_INVALID_ARG, "rw_multi_step_device: no action array for engine %d", k);
+            int rc1 = RW_OK;
+            const hipError_t he = hipSetDevice(e->cfg.device_id);
+            if (he != hipSuccess) {
+                rc1 = fail(e, RW_ERR_HIP, "hipSetDevice(%d): %s", e->cfg.device_id, hipGetErrorString(he));
+            } else {
+                rw::LaunchArgs la = e->la;
+                la.actions = actions_dev[k];
+                rc1 = launch(e, la, rw::OP_STEP);
+            }
+            if (rc1 != RW_OK) return k == 0 ? rc1 : fail(e0, rc1, "rw_multi_step_device: engine %d: %s", k, e->err.c_str());
         }
         return RW_OK;
     }
@@ -1393,8 +1427,12 @@ int rw_multi_step_device(rw_multi *m, const int32_t *const *actions_dev) {
         m->cv.notify_all();
     }
     rw_engine *e0 = m->engs[0];
-    int rc = RW_ERR_INVALID_ARG;
-    if (actions_dev[0] && hipSetDevice(e0->cfg.device_id) == hipSuccess) {
+    int rc;
+    if (!actions_dev[0]) {
+        rc = fail(e0, RW_ERR_INVALID_ARG, "rw_multi_step_device: no action array for engine 0");
+    } else if (const hipError_t he = hipSetDevice(e0->cfg.device_id); he != hipSuccess) {
+        rc = fail(e0, RW_ERR_HIP, "hipSetDevice(%d): %s", e0->cfg.device_id, hipGetErrorString(he));
+    } else {
         rw::LaunchArgs la = e0->la;
         la.actions = actions_dev[0];
         rc = launch(e0, la, rw::OP_STEP);

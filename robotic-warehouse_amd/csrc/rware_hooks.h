@@ -8,10 +8,31 @@
 //   RWARE_JIT_NO_CACHE=1   RWARE_PIPE=0|1   RWARE_PIPE_E=n   RWARE_PIPE_WGS_PER_CU=n   RWARE_PIPE_GRID=n   RWARE_MULTI_THREADS=0|1
 //   RWARE_SELFTEST_BREAK=1
 // (RWARE_JIT_CACHE — where compiled code objects are kept — is configuration, not a hook, and is read unconditionally.)
+// A hook variable that is set while RWARE_HOOKS is not is IGNORED — and says so once per variable on stderr, so that a script written
+// against an older library (which read e.g. RWARE_JIT=off unconditionally) does not change behaviour silently.
 #pragma once
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 inline const char *rw_hook(const char *name) {
     const char *on = getenv("RWARE_HOOKS");
-    return (on && on[0] == '1' && on[1] == '\0') ? getenv(name) : nullptr;
+    if (on && on[0] == '1' && on[1] == '\0') return getenv(name);
+    const char *v = getenv(name);
+    if (v && *v) {
+        // one note per variable and process (a small fixed table: the hooks are the dozen names above)
+        static std::atomic<const char *> noted[16];
+        for (auto &slot : noted) {
+            const char *seen = slot.load(std::memory_order_acquire);
+            if (seen && strcmp(seen, name) == 0) break;
+            const char *expect = nullptr;
+            if (!seen && slot.compare_exchange_strong(expect, name, std::memory_order_acq_rel)) {
+                fprintf(stderr, "librware_hip: %s=%s is ignored: the test / A-B hooks are honoured only with RWARE_HOOKS=1 (csrc/rware_hooks.h)\n", name, v);
+                break;
+            }
+            if (expect && strcmp(expect, name) == 0) break;
+        }
+    }
+    return nullptr;
 }

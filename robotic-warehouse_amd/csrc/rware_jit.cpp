@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -144,7 +145,10 @@ void cache_write(const std::string &file, const Result &r) {
 
 }  // namespace
 
-bool compile(const Shape &s, const char *arch, Result *out) {
+namespace {
+// the two name expressions of a shape and the cache file its code object is kept in
+struct Names { std::string expr_step, expr_roll, dir, file; };
+Names names_of(const Shape &s, const char *arch) {
     char cfg[256], expr_step[512], expr_roll[512];
     auto static_cfg = [&](int nt) {
         snprintf(cfg, sizeof cfg, "rw::StaticCfg<%d, %d, %d, %d, %d, %d, %d, %d, %d, %uu, %d, %d>", s.H, s.W, s.N, s.Q, s.S, s.E, s.T, s.M, s.NL,
@@ -159,7 +163,19 @@ bool compile(const Shape &s, const char *arch, Result *out) {
     char name[64];
     snprintf(name, sizeof name, "%016llx%016llx.hsaco", (unsigned long long)fnv1a(key, 0xcbf29ce484222325ULL),
              (unsigned long long)fnv1a(key, 0x84222325cbf29ce4ULL));
-    const std::string dir = cache_dir(), file = dir + "/" + name;
+    Names n;
+    n.expr_step = expr_step; n.expr_roll = expr_roll; n.dir = cache_dir();
+    n.file = n.dir.empty() ? std::string() : n.dir + "/" + name;
+    return n;
+}
+}  // namespace
+
+std::string cache_file(const Shape &s, const char *arch) { return names_of(s, arch).file; }
+
+bool compile(const Shape &s, const char *arch, Result *out) {
+    const Names nm = names_of(s, arch);
+    const char *expr_step = nm.expr_step.c_str(), *expr_roll = nm.expr_roll.c_str();
+    const std::string &dir = nm.dir, &file = nm.file;
     const char *nocache = rw_hook("RWARE_JIT_NO_CACHE");
     const bool use_cache = !dir.empty() && !(nocache && nocache[0] == '1');
     if (use_cache && dir_is_private(dir) && cache_read(file, out)) {
@@ -220,7 +236,10 @@ bool compile(const Shape &s, const char *arch, Result *out) {
             cache_write(file, *out);
             out->log += " -> " + file;
         } else {
-            out->log += " (not cached: " + dir + " is not a private directory of this user)";
+            out->log += " (NOT CACHED — every construction of this shape recompiles: " + dir + " is not a private directory of this user; chmod go-w it or point RWARE_JIT_CACHE elsewhere)";
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true))
+                fprintf(stderr, "librware_hip: run-time specialised kernels are not cached: %s is not a private directory of this user (group- or world-writable, or not yours)\n", dir.c_str());
         }
     } else {
         out->log += " (not cached: no HOME / RWARE_JIT_CACHE)";

@@ -33,6 +33,10 @@ struct Result {
     std::string log;                 // what happened (reason of a failure, hipRTC's log, cache path)
 };
 
+// where the code object of a shape is (or would be) cached: "" without a cache directory (no HOME / RWARE_JIT_CACHE) — for diagnostics and
+// for the tests that corrupt the file on purpose (oracle/sanitize.sh)
+std::string cache_file(const Shape &s, const char *arch);
+
 // false: no build (hipRTC missing, compile error, ...) — `out->log` says why; the caller keeps its ahead-of-time kernel
 bool compile(const Shape &s, const char *arch, Result *out);
 

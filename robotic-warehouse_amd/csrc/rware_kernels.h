@@ -90,7 +90,8 @@ enum : int { STATUS_INVALID_ACTION = 1,
              STATUS_IMAGE_INDEX = 2 };
 enum : int { MAX_GOALS = 16, MAX_IMAGE_LAYERS = 8 };
 enum : int { OBS_FLATTENED = 0, OBS_IMAGE = 1, OBS_FLATTENED_MSG = 2, OBS_IMAGE_MSG = 3 };  // _MSG: msg_bits > 0
-// ImageLayer values of the reference (rware/warehouse.py:59-70); 3 and 4 are rejected by the host
+// ImageLayer values of the reference (rware/warehouse.py:59-70); 3 and 4 are written with transposed indices there (:552, :558) and
+// reproduced as is, including the IndexError condition (STATUS_IMAGE_INDEX; include/rware_hip.h)
 enum : int { LAYER_SHELVES = 0, LAYER_REQUESTS = 1, LAYER_AGENTS = 2, LAYER_AGENT_DIRECTION = 3, LAYER_AGENT_LOAD = 4,
              LAYER_GOALS = 5, LAYER_ACCESSIBLE = 6 };
 
@@ -178,7 +179,8 @@ enum : int { TL_START = 0, TL_ZEROED, TL_DMA_ISSUED, TL_ENV_LOADED, TL_LOADED, T
              // the pipelined build, chunk it < 4 of the workgroup, slot TL_PIPE + 8 * it + ...: behind barrier A | wavefront 0 done gathering |
              // wavefront 3 done with self bits + write-back | behind barrier B | wavefront 0 done with the next chunk's agent phases |
              // wavefront 1 done expanding | wavefront 3 has issued the stage-in of chunk it + 2 | ... and has seen it land (next stage)
-             TL_PIPE = 16, TL_MARKS = 48 };
+             // (TL_PIPE sits behind the agent-phase slots: TL_AG_GOALS == 16)
+             TL_PIPE = 24, TL_MARKS = 56 };
 
 // LDS carve-up, in dwords.  Every sub-array starts on a 16-byte boundary.
 struct LdsLayout {
@@ -362,8 +364,10 @@ __global__ void rware_pack_counters_kernel(int32_t *cnt, const int32_t *steps, c
 // rw_debug_store_floor: writes `per_wg` floats per workgroup (one step's observation chunk) with the step kernel's store instruction and
 // nothing else — the floor of any kernel that has to produce those observations (measurement aid)
 template <bool kNT>
-__global__ void __launch_bounds__(256) rware_store_floor_kernel(float *obs, int per_wg, int total) {
-    const int base = (int)blockIdx.x * per_wg, n4 = min(per_wg, total - base) >> 2;
+__global__ void __launch_bounds__(256) rware_store_floor_kernel(float *obs, int per_wg, size_t total) {
+    const size_t base = (size_t)blockIdx.x * (size_t)per_wg;
+    if (base >= total) return;
+    const int n4 = (int)((total - base < (size_t)per_wg ? total - base : (size_t)per_wg) >> 2);
     float4 *o = reinterpret_cast<float4 *>(obs + base);
     for (int i = threadIdx.x; i < n4; i += blockDim.x) {
         const float4 v = float4{0.0f, 1.0f, 0.0f, 0.0f};
@@ -544,6 +548,8 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
 #define RW_MARK(k) do { if (RW_RARE(tl_on) && tid == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + (k)] = wall_clock64(); } while (0)
     // (the pipelined build: stamp k of chunk `it`, taken by the first lane of wavefront `w`)
 #define RW_PIPE_MARK(k, w) do { if (kPipe && RW_RARE(tl_on) && it < 4 && tid == 64 * (w)) la.timeline[(size_t)blockIdx.x * TL_MARKS + TL_PIPE + 8 * it + (k)] = wall_clock64(); } while (0)
+    // (... a stamp that belongs to the chunk BEFORE this one — work that ran one stage ago: slot k of chunk it - 1, for it = 1 .. 4)
+#define RW_PIPE_MARK_PREV(k, w) do { if (kPipe && RW_RARE(tl_on) && it >= 1 && it <= 4 && tid == 64 * (w)) la.timeline[(size_t)blockIdx.x * TL_MARKS + TL_PIPE + 8 * (it - 1) + (k)] = wall_clock64(); } while (0)
     // marks INSIDE the agent phases: only in a -DRW_TL_AG_MARKS build (profiles/tools/timeline_probe.py says how) — even
     // switched off each one is a scalar test and a branch on the one wavefront every other wavefront is waiting for
 #ifdef RW_TL_AG_MARKS
@@ -655,13 +661,13 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     } else {
 #include "rware_phase_agents_lds.h"
     }
-    RW_PIPE_MARK(4 - 8, 0);  // (the agent phases of this chunk ran one stage ago: slot 4 of chunk it - 1)
+    RW_PIPE_MARK_PREV(4, 0);  // (the agent phases of this chunk ran one stage ago: slot 4 of chunk it - 1)
     lds_barrier();  // (PIPE: barrier A)
     RW_MARK(TL_AGENTS);
     RW_PIPE_MARK(0, 0);
     // PIPE: the stage-in wavefront 3 issued one stage ago (chunk it + 1, for the agent phases that start behind barrier B) is waited
     // for HERE, behind barrier A and on wavefront 3 only: it has had a whole stage to land, and the gather does not wait for it
-    if constexpr (kPipe) { if (pipe_wave == 3) { dma_wait(); RW_PIPE_MARK(7 - 8, 3); } }
+    if constexpr (kPipe) { if (pipe_wave == 3) { dma_wait(); RW_PIPE_MARK_PREV(7, 3); } }
 
 #include "rware_phase_reset.h"
     RW_MARK(TL_RESET);
@@ -704,6 +710,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     }
 #undef RW_MARK
 #undef RW_PIPE_MARK
+#undef RW_PIPE_MARK_PREV
 #undef RW_AG_MARK
 }
 

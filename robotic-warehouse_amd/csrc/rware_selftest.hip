@@ -82,8 +82,11 @@ __global__ void selftest_dma_kernel(const uint32_t *src, uint32_t *dst, int piec
 extern "C" int rw_selftest(int32_t device_id, char *log, size_t log_len) {
     std::string msg;
     int failed = 0;
+    int caller_dev = -1;  // the caller's current HIP device is put back on every way out
+    if (hipGetDevice(&caller_dev) != hipSuccess) { caller_dev = -1; (void)hipGetLastError(); }
     auto done = [&](int rc) {
         if (log && log_len) snprintf(log, log_len, "%s", msg.c_str());
+        if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
         return rc;
     };
     int n_dev = 0;

@@ -113,6 +113,8 @@ namespace {
 //       14ag 20.75 / 19.79 | 16ag 22.81 / 21.60 | large-16ag 22.38 / 21.18 (E = 4: 20.8)   (from 14 agents on the budget spilled)
 //   per-cell agent phases (54 .. 62 VGPRs at every agent count), E = 8 vs 16:  10ag 13.0 / 13.9 | 14ag 16.9 / 17.5 | 16ag 18.0 / 18.8 |
 //       large-16ag 18.0 / 19.0 (E = 4: 17.4) | 17ag 19.6 | 19ag 21.3
+//   round 6, two-wavefront workgroups (T = 128, 16 per CU, register budget of 8 wavefronts): E = 4 / 8 — small-10ag 14.4 / 14.7 against 13.1,
+//       large-16ag 18.4 / 20.1 against 18.0, large-16ag r = 2 34.5 / 38.0 against 35.1 (profiles/r06_t128_stagger.txt): not kept
 // -> 8 envs per workgroup for every count; 16 (up to 16 agents: three agents' envs of 17 .. 19 fit a wavefront, 12 envs at most per
 //    4-wavefront workgroup) and 4 as explicit geometries and for batches that are no multiple of 8.
 #define RW_QRT_WIDE(H, W, S, N) RW_QRT_WIDE_##N(H, W, S, N)

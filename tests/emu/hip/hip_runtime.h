@@ -68,6 +68,7 @@ enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     memset(p, 0, sizeof *p);
     strcpy(p->name, "host-thread emulation (tests only)");

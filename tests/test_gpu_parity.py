@@ -589,7 +589,7 @@ def test_bench_two_ranks_self_spawned():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["RWARE_BENCH_SHARE_GPU"] = "1"
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "20", "--batch", "4096"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "20", "--batch", "4096", "--no-soak"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     _check_bench_line(out, 2, 200, 20, 4096)
 
@@ -606,7 +606,7 @@ def test_bench_graph_submit_mode():
     res = {}
     for mode in ("graph", "native"):
         cmd = [sys.executable, os.path.join(root, "bench.py"), "--submit", mode, "--steps", "700", "--warmup", "30", "--batch", "4096",
-               "--no-cpu-baseline", "--no-hbm-regime", "--no-api-loop", "--no-fused-extra", "--no-sustained"]
+               "--no-cpu-baseline", "--no-hbm-regime", "--no-api-loop", "--no-fused-extra", "--no-sustained", "--no-soak"]
         out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         res[mode] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -625,7 +625,7 @@ def test_bench_two_ranks_through_torchrun():
     env = dict(os.environ, RWARE_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "200", "--warmup", "20", "--batch", "4096"]
+           "--gpus", "2", "--steps", "200", "--warmup", "20", "--batch", "4096", "--no-soak"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     _check_bench_line(out, 2, 200, 20, 4096)
 
@@ -740,7 +740,7 @@ def test_bench_eight_ranks_report_placement_and_per_rank_times():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["RWARE_BENCH_SHARE_GPU"] = "1"
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "300", "--warmup", "20", "--batch", "2048"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "300", "--warmup", "20", "--batch", "2048", "--no-soak"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     d = _check_bench_line(out, 8, 300, 20, 2048)
     ranks = d["ranks"]
@@ -774,6 +774,9 @@ def test_bench_driver_invocation_carries_every_leg():
     assert h["regime"] == "hbm" and d["roofline"]["regime"] == "infinity-cache"   # 376 MB per step vs 23 MB
     _no_frac_above_one(d)
     assert d["ranks"][0]["graph_launches_per_replay"] == 20 and d["ranks"][0]["graph_ms_per_step"] > 0   # the 20-step graph replays
+    k = d["soak"]   # >= 3 s of back-to-back launches: an outside utilisation sampler can see the GPU busy; steps x ms = wall
+    assert k["wall_s"] >= 3.0 and abs(k["steps"] * k["ms_per_step"] * 1e-3 - k["wall_s"]) < 1e-6 * k["wall_s"] + 1e-9
+    assert 0.5 < k["kernel_ms_per_launch"] / d["sustained"]["kernel_ms_per_launch"] < 1.5
     a = d["api_closed_loop"]
     assert a["steps"] == 2000 and 3.0 < a["us_per_step"] < 100.0
     c = d["cpu_baseline"]
@@ -1193,6 +1196,35 @@ def test_start_stagger_only_for_launches_of_two_or_more_rounds(monkeypatch):
     a.close(); b.close()
 
 
+def test_start_stagger_rule_for_13_to_16_agents_matches_oracle():
+    """Round 6: launches of 13 .. 16 agents stagger their workgroups' starts by wider slots, already when the launch is resident at once
+    (one round) and from four rounds on, not at exactly two; sensor_range 2 (BASELINE config 5) up to two rounds.  The rule as
+    rw_info shows it, and — a delay, never a different result — the staggered launches against the oracle."""
+    for env_id, extra, B, want in (("rware-large-16ag-v1", {}, 16384, 55), ("rware-large-16ag-v1", {}, 32768, 0), ("rware-small-14ag-v1", {}, 65536, 55),
+                                   ("rware-large-16ag-v1", {"sensor_range": 2}, 16384, 40), ("rware-large-16ag-v1", {"sensor_range": 2}, 32768, 0),
+                                   ("rware-small-12ag-v1", {}, 16384, 0), ("rware-small-17ag-v1", {}, 16384, 0)):
+        env = rware_amd.WarehouseVecEnv(B, **dict(rware_amd.env_kwargs(env_id), **extra))
+        assert env.engines[0].info.stagger_ticks == want, (env_id, extra, B)
+        env.close()
+    for env_id, B in (("rware-medium-13ag-v1", 16384), ("rware-large-16ag-v1", 16384)):
+        kw = rware_amd.env_kwargs(env_id)
+        kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+        kw["max_steps"] = 20
+        env = rware_amd.WarehouseVecEnv(B, **kw)
+        assert env.engines[0].info.stagger_ticks == 55
+        orc = OracleVecEnv(B, **kw)
+        assert np.array_equal(env.reset(seed=9)[0], orc.reset(seed=9))
+        rng = np.random.default_rng(2)
+        for t in range(45):
+            a = rng.choice(5, size=(B, kw["n_agents"]), p=[0.1, 0.55, 0.1, 0.1, 0.15]).astype(np.int32)
+            obs, rew, term, _, _ = env.step(a)
+            o2, r2, d2 = orc.step_autoreset(a, "next_step")
+            assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), (env_id, t)
+        st, so = env.get_state(), orc.get_state()
+        assert all(np.array_equal(st[k], so[k]) for k in so)
+        env.close()
+
+
 def test_two_pipelines_on_one_device_match_the_single_engine():
     """Double-buffered sampling (bench.py's `two_pipelines`): the batch as two engines on one device, own streams, stepped
     CONCURRENTLY by one launcher thread each, against one engine over the whole batch — same observations and state."""
@@ -1307,10 +1339,50 @@ def test_capture_pipelines_replays_what_the_eager_pipelines_do():
     one.close()
 
 
+_HAS_PIPE = None
+
+
+def _library_has_pipelined_builds() -> bool:
+    """Does this librware_hip.so carry the chunk-pipelined persistent kernels?  Only a `make PIPE=1` build does (round 6: they were
+    measured slower than the classic launch on every configuration, so the default library leaves them out)."""
+    global _HAS_PIPE
+    if _HAS_PIPE is None:
+        env = rware_amd.WarehouseVecEnv(64, pipe=True, **rware_amd.env_kwargs("rware-small-4ag-v1"))
+        _HAS_PIPE = env.engines[0].info.pipe_workgroups > 0
+        env.close()
+    return _HAS_PIPE
+
+
+def test_pipe_request_on_the_default_library_runs_the_classic_kernel_and_says_so():
+    """RW_PIPE_ON (pipe=True) against a library without the pipelined kernels: the classic kernel runs (bit-exact), `rw_get_info()`
+    shows it and `rw_jit_log()` says why — nothing fails, nothing is silently different."""
+    if _library_has_pipelined_builds():
+        pytest.skip("this library was built with PIPE=1")
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    B = 256
+    env = rware_amd.WarehouseVecEnv(B, pipe=True, **kw)
+    eng = env.engines[0]
+    assert eng.info.pipe_workgroups == 0 and eng.info.specialised == 1
+    assert "make PIPE=1" in eng.jit_log()
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=3)[0], orc.reset(seed=3))
+    rng = np.random.default_rng(3)
+    for t in range(30):
+        a = rng.integers(0, 5, size=(B, 4)).astype(np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+    env.close()
+
+
 @pytest.mark.parametrize("name,tile,grid", [("small-4ag", 20, 2), ("medium-6ag-hard", 8, 2), ("large-16ag-sr2", 6, 2), ("tiny-2ag", 40, 3)])
 def test_pipelined_builds_replay_reference_golden(name, tile, grid, monkeypatch):
     """The reference's golden traces on the chunk-pipelined persistent builds (opt-in, pipe=True): a handful of persistent workgroups
-    (RWARE_PIPE_GRID) walk several chunks each — uneven shares included — so the two-buffer hand-over is what is being replayed."""
+    (RWARE_PIPE_GRID) walk several chunks each — uneven shares included — so the two-buffer hand-over is what is being replayed.
+    (Needs a `make PIPE=1` library; the host-thread emulation build always has the pipelined kernels: tests/test_engine_emulated.py.)"""
+    if not _library_has_pipelined_builds():
+        pytest.skip("librware_hip.so was built without the pipelined kernels (make PIPE=1): quarantined, measured slower everywhere")
     monkeypatch.setenv("RWARE_PIPE_GRID", str(grid))
     meta, z = gu.load_fixture(name)
     be = EngineBackend(meta["E"], tile=tile, pipe=True, **gu.ctor_kwargs(meta))
@@ -1332,6 +1404,8 @@ def test_pipelined_builds_match_oracle_full_batch(env_id, extra, B, T, mode):
     kw = rware_amd.env_kwargs(env_id)
     kw.update(extra)
     kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    if not _library_has_pipelined_builds():
+        pytest.skip("librware_hip.so was built without the pipelined kernels (make PIPE=1): quarantined, measured slower everywhere")
     env = rware_amd.WarehouseVecEnv(B, autoreset_mode=mode, pipe=True, **kw)
     assert env.engines[0].info.pipe_workgroups > 0
     orc = OracleVecEnv(B, **kw)

@@ -1,6 +1,8 @@
 """Host-side mirror of the reference interface: layout, observation length, registry ids/kwargs.
 Cross-checked against the oracle's independent restatement and, where /root/reference exists,
 against the reference itself."""
+import os
+
 import numpy as np
 import pytest
 
@@ -146,3 +148,35 @@ def test_make_pipelines_checks_its_arguments_before_touching_a_device():
         rware_amd.make_pipelines(16, 0, env_id="rware-tiny-2ag-v1")
     p = rware_amd.Pipeline(env="e", stream="s", lo=8, hi=16)
     assert (p.env, p.stream, p.lo, p.hi) == ("e", "s", 8, 16)
+
+
+def test_kernel_sources_hash_ignores_comments_and_layout():
+    """bench.kernel_sources_sha() identifies the CODE a PMC traffic figure was measured on: comments and white space do not count
+    (round 5: a comment-level edit behind the evidence pass orphaned profiles/pmc_traffic.json and `roofline.traffic` went null)."""
+    import bench
+
+    a = 'int f(int x) {  // add one\n    return x + 1; /* here */\n}\n\nconst char *s = "// kept /* kept */";\n'
+    b = 'int f(int x) {\n  return x + 1;\n}\nconst char *s = "// kept /* kept */"; // gone\n'
+    assert bench.strip_cxx_comments(a) == bench.strip_cxx_comments(b)
+    assert bench.strip_cxx_comments(a) != bench.strip_cxx_comments(a.replace("x + 1", "x + 2"))
+    assert '"// kept /* kept */"' in bench.strip_cxx_comments(a)
+    assert len(bench.kernel_sources_sha()) == 16
+
+
+def test_pmc_traffic_record_belongs_to_these_kernel_sources():
+    """profiles/pmc_traffic.json — the rocprofv3 FETCH_SIZE / WRITE_SIZE passes behind `roofline.traffic` — must have been measured on
+    the kernel sources in this tree, or bench.py reports `traffic: null` (`basis: "engine-bytes"`).  A kernel edit after the evidence
+    pass turns THIS test red instead of silently dropping the field: re-run profiles/tools/final_pass.sh and commit the new record.
+    (RWARE_ALLOW_STALE_PMC=1: development runs between two evidence passes.)"""
+    import json
+
+    import bench
+
+    rec = json.load(open(os.path.join(bench.ROOT, "profiles", "pmc_traffic.json")))
+    assert f"{bench.ENV_ID}:{bench.BATCH_PER_GPU}" in rec["entries"] and f"{bench.ENV_ID}:{bench.HBM_REGIME_BATCH}" in rec["entries"]
+    if os.environ.get("RWARE_ALLOW_STALE_PMC") == "1":
+        pytest.skip("RWARE_ALLOW_STALE_PMC=1")
+    assert rec["kernel_sources_sha"] == bench.kernel_sources_sha(), (
+        "profiles/pmc_traffic.json was measured on other kernel sources: run profiles/tools/final_pass.sh on the GPU box and commit its record")
+    traffic, note = bench.pmc_traffic(bench.ENV_ID, bench.BATCH_PER_GPU, bench.kernel_sources_sha())
+    assert note is None and 0.9 < traffic / (1433 * bench.BATCH_PER_GPU) < 1.15   # (engine bytes per env-step of small-4ag: DESIGN.md §4)
