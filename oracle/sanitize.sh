@@ -23,6 +23,7 @@ BUILT_GROUPS="0 10 16 17 18"   # BASELINE shapes | small 9..14 agents (kCell) | 
 for r in 1 2; do g++ $FLAGS -DRW_GENERIC_R=$r -c -x c++ $CSRC/rware_generic.hip -o $OUT/g$r.o 2>/dev/null & done
 g++ $FLAGS -c -x c++ $CSRC/rware_capi.hip -o $OUT/capi.o 2>/dev/null &
 g++ $FLAGS -c tests/emu/emu_globals.cpp -o $OUT/glob.o &
+g++ $FLAGS -c -x c++ $CSRC/rware_selftest.hip -o $OUT/selftest.o 2>/dev/null &
 wait
 for g in $BUILT_GROUPS; do g++ $FLAGS -DRW_STATIC_GROUP=$g -c -x c++ $CSRC/rware_static.hip -o $OUT/s$g.o 2>/dev/null & done
 wait
@@ -34,8 +35,8 @@ wait
   for g in $(seq 0 18); do case " $BUILT_GROUPS " in *" $g "*) ;; *) echo "const StaticEntry *static_group_$g(int *n) { *n = 0; return nullptr; }";; esac; done
   echo '}'
 } > $OUT/stub.cpp
-g++ $FLAGS -I$CSRC -c $OUT/stub.cpp -o $OUT/stub.o || exit 1
-OBJS="$OUT/capi.o $OUT/g1.o $OUT/g2.o $OUT/glob.o $OUT/stub.o"; for g in $BUILT_GROUPS; do OBJS="$OBJS $OUT/s$g.o"; done
+g++ $FLAGS -I$CSRC -c $OUT/stub.cpp -o $OUT/stub.o 2> $OUT/stub.err || { cat $OUT/stub.err; exit 1; }
+OBJS="$OUT/capi.o $OUT/selftest.o $OUT/g1.o $OUT/g2.o $OUT/glob.o $OUT/stub.o"; for g in $BUILT_GROUPS; do OBJS="$OBJS $OUT/s$g.o"; done
 g++ -shared -pthread -fsanitize=thread -o $OUT/librware_emu_tsan.so $OBJS || exit 1
 LD_PRELOAD=$(gcc -print-file-name=libtsan.so) TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:history_size=2" RWARE_HOOKS=1 timeout 5400 python - <<'EOP' 2>&1 | grep -E "WARNING: ThreadSanitizer|SUMMARY|tsan-run|Error|Traceback|assert" | sort | uniq -c | head -40
 import os, sys

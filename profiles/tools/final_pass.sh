@@ -1,6 +1,7 @@
 #!/bin/bash
-# End-of-round evidence pass, ONE gpurun call (run on the GPU box from the repo root, ≈6 GPU-minutes):
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/tools/final_pass.sh r03'
+# End-of-round evidence pass, ONE gpurun call (run on the GPU box from the repo root, ≈12 GPU-minutes):
+#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash profiles/tools/final_pass.sh r06'
+# THE LAST SOURCE-TOUCHING ACT OF A ROUND: tests/test_host_layer.py fails while profiles/pmc_traffic.json and the kernel sources disagree.
 # Order matters: the GPU suite first (a red suite voids everything after it), then the sweep (which writes
 # gpurun_out/pmc_traffic.json), then THAT file into profiles/ BEFORE bench.py runs (bench.py reports `roofline.traffic`
 # only when the file's kernel_sources_sha matches the sources it is running), then the un-profiled lines.
@@ -36,18 +37,8 @@ I2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_
 I3="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQC_DCACHE_REQ SQC_DCACHE_MISSES"
 for c in "$I1" "$I2" "$I3"; do bash profiles/tools/pmc_pass.sh ${TAG}_headline "$c"; done
 for c in "$I1" "$I2"; do bash profiles/tools/pmc_pass.sh ${TAG}_small10 "$c" --env-id rware-small-10ag-v1; bash profiles/tools/pmc_pass.sh ${TAG}_cfg5 "$c" --env-id rware-large-16ag-v1 --sensor-range 2; done
-# round 5: the chunk-pipelined persistent build against the classic launch (same box, alternating), its stage timeline, and what a
-# device-side mailbox costs per step (the resident-kernel question)
-{
-for cfg in "rware-small-4ag-v1:16384" "rware-small-4ag-v1:65536" "rware-small-4ag-v1:262144" "rware-medium-6ag-hard-v1:8192" "rware-large-16ag-v1:16384:0:auto:2" \
-           "rware-large-16ag-v1:32768:0:auto:2" "rware-small-10ag-v1:16384" "rware-large-16ag-v1:16384" "rware-tiny-2ag-v1:4096"; do
-  IFS=: read -r id B E st sr <<< "$cfg"
-  python profiles/tools/measure.py "$id:$B:0:${st:-auto}:${sr}:::off" "$id:$B:0:${st:-auto}:${sr}:::on"
-done
-} 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_pipe_ab.txt
-{ python profiles/tools/pipe_timeline.py rware-small-4ag-v1 65536; RWARE_PIPE_WGS_PER_CU=1 python profiles/tools/pipe_timeline.py rware-small-4ag-v1 65536;
-  python profiles/tools/pipe_timeline.py rware-large-16ag-v1 16384 2; python profiles/tools/pipe_timeline.py rware-small-10ag-v1 16384; } 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_pipe_timeline.txt
-[ -x profiles/tools/resident_probe ] && timeout 200 ./profiles/tools/resident_probe > gpurun_out/${TAG}_resident_probe.txt 2>&1
+# (round 5's pipelined-build A/B and resident-mailbox probe are history: profiles/r05_pipe_*.txt, r05_resident_probe.txt; the pipelined kernels
+#  are only in a `make PIPE=1` library since round 6)
 python profiles/tools/k20_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_k20_probe.txt
 python profiles/tools/api_rates.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_api_rates.txt
 bash profiles/tools/unprofiled.sh $TAG > gpurun_out/${TAG}_unprofiled.txt
