@@ -15,7 +15,7 @@ import torch  # noqa: E402
 
 import rware_amd  # noqa: E402
 
-TL_PIPE = 24
+TL_PIPE = 24   # (rware_kernels.h; slot 17 = TL_PIPE_FIRST_AG: the agent phases of chunk 0, which run in the prologue)
 
 
 def main():
@@ -39,7 +39,7 @@ def main():
     print(f"{env_id} B={B} pipe E={i.pipe_envs_per_workgroup} wgs={i.pipe_workgroups} ({i.pipe_workgroups / i.compute_units:.1f} per CU), "
           f"{n_chunks / i.pipe_workgroups:.2f} chunks per workgroup, lds {2 * 0} ")
     med = lambda a: f"{np.median(a):6.2f} (p90 {np.percentile(a, 90):6.2f})"  # noqa: E731
-    print(f"start {med(us(0))}   staged (prologue) {med(us(4))}   agent phases of chunk 0 done {med(us(12))}   end {med(us(9))}  kernel span {us(9).max():.2f}")
+    print(f"start {med(us(0))}   staged (prologue) {med(us(4))}   agent phases of chunk 0 done {med(us(17))}   end {med(us(9))}  kernel span {us(9).max():.2f}")
     for it in range(4):
         b = TL_PIPE + 8 * it
         if raw[:, b].max() == 0:

@@ -179,8 +179,9 @@ enum : int { TL_START = 0, TL_ZEROED, TL_DMA_ISSUED, TL_ENV_LOADED, TL_LOADED, T
              // the pipelined build, chunk it < 4 of the workgroup, slot TL_PIPE + 8 * it + ...: behind barrier A | wavefront 0 done gathering |
              // wavefront 3 done with self bits + write-back | behind barrier B | wavefront 0 done with the next chunk's agent phases |
              // wavefront 1 done expanding | wavefront 3 has issued the stage-in of chunk it + 2 | ... and has seen it land (next stage)
-             // (TL_PIPE sits behind the agent-phase slots: TL_AG_GOALS == 16)
-             TL_PIPE = 24, TL_MARKS = 56 };
+             // (TL_PIPE sits behind the agent-phase slots: TL_AG_GOALS == 16.  Two stamps belong to the stage BEFORE chunk 0's — its agent
+             //  phases ran in the prologue, the stage-in of chunk 1 was issued there — and get slots of their own)
+             TL_PIPE_FIRST_AG = 17, TL_PIPE_FIRST_DMA = 18, TL_PIPE = 24, TL_MARKS = 56 };
 
 // LDS carve-up, in dwords.  Every sub-array starts on a 16-byte boundary.
 struct LdsLayout {
@@ -548,8 +549,8 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
 #define RW_MARK(k) do { if (RW_RARE(tl_on) && tid == 0) la.timeline[(size_t)blockIdx.x * TL_MARKS + (k)] = wall_clock64(); } while (0)
     // (the pipelined build: stamp k of chunk `it`, taken by the first lane of wavefront `w`)
 #define RW_PIPE_MARK(k, w) do { if (kPipe && RW_RARE(tl_on) && it < 4 && tid == 64 * (w)) la.timeline[(size_t)blockIdx.x * TL_MARKS + TL_PIPE + 8 * it + (k)] = wall_clock64(); } while (0)
-    // (... a stamp that belongs to the chunk BEFORE this one — work that ran one stage ago: slot k of chunk it - 1, for it = 1 .. 4)
-#define RW_PIPE_MARK_PREV(k, w) do { if (kPipe && RW_RARE(tl_on) && it >= 1 && it <= 4 && tid == 64 * (w)) la.timeline[(size_t)blockIdx.x * TL_MARKS + TL_PIPE + 8 * (it - 1) + (k)] = wall_clock64(); } while (0)
+    // (... a stamp that belongs to the chunk BEFORE this one — work that ran one stage ago: slot k of chunk it - 1, for it = 1 .. 4; it == 0: `first`)
+#define RW_PIPE_MARK_PREV(k, w, first) do { if (kPipe && RW_RARE(tl_on) && it <= 4 && tid == 64 * (w)) la.timeline[(size_t)blockIdx.x * TL_MARKS + (it == 0 ? (first) : TL_PIPE + 8 * (it - 1) + (k))] = wall_clock64(); } while (0)
     // marks INSIDE the agent phases: only in a -DRW_TL_AG_MARKS build (profiles/tools/timeline_probe.py says how) — even
     // switched off each one is a scalar test and a branch on the one wavefront every other wavefront is waiting for
 #ifdef RW_TL_AG_MARKS
@@ -661,13 +662,13 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     } else {
 #include "rware_phase_agents_lds.h"
     }
-    RW_PIPE_MARK_PREV(4, 0);  // (the agent phases of this chunk ran one stage ago: slot 4 of chunk it - 1)
+    RW_PIPE_MARK_PREV(4, 0, TL_PIPE_FIRST_AG);  // (the agent phases of this chunk ran one stage ago: slot 4 of chunk it - 1)
     lds_barrier();  // (PIPE: barrier A)
     RW_MARK(TL_AGENTS);
     RW_PIPE_MARK(0, 0);
     // PIPE: the stage-in wavefront 3 issued one stage ago (chunk it + 1, for the agent phases that start behind barrier B) is waited
     // for HERE, behind barrier A and on wavefront 3 only: it has had a whole stage to land, and the gather does not wait for it
-    if constexpr (kPipe) { if (pipe_wave == 3) { dma_wait(); RW_PIPE_MARK_PREV(7, 3); } }
+    if constexpr (kPipe) { if (pipe_wave == 3) { dma_wait(); RW_PIPE_MARK_PREV(7, 3, TL_PIPE_FIRST_DMA); } }
 
 #include "rware_phase_reset.h"
     RW_MARK(TL_RESET);
