@@ -4,6 +4,7 @@
 // enqueues the fused step kernel (rware_kernels.h) on one stream.  No CPU fallback exists:
 // without a usable HIP device rw_create fails with RW_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -553,11 +554,15 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
                 sh.directional = eng->image ? (cfg->image_directional ? 1 : 0) : -1;
                 for (int l = 0; l < n_layers && l < 8 && eng->image; ++l) sh.layers |= (uint32_t)layers[l] << (4 * l);
                 sh.nt = nt_rule(je_) ? 1 : 0;
+                // (two attempts: a CACHED code object the runtime refuses — a truncated or foreign file behind a well-formed header — is
+                //  dropped from the cache and the shape compiled afresh, once; otherwise every later construction would trip over it)
+                for (int attempt = 0; attempt < 2 && eng->jit_state != 1 && eng->jit_state != 2; ++attempt) {
                 rw_jit::Result res;
                 const bool built = rw_jit::compile(sh, eng->prop.gcnArchName, &res);
-                eng->jit_log = res.log;
+                eng->jit_log = (attempt ? eng->jit_log + " | retry: " : std::string()) + res.log;
                 eng->jit_state = -1;
-                if (built) {
+                if (!built) break;
+                {
                     hipError_t me = hipModuleLoadData(&eng->jit_module, res.code.data());
                     if (me == hipSuccess) me = hipModuleGetFunction(&eng->jit_step, eng->jit_module, res.step_name.c_str());
                     if (me == hipSuccess) me = hipModuleGetFunction(&eng->jit_rollout, eng->jit_module, res.rollout_name.c_str());
@@ -575,7 +580,12 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
                         eng->jit_step = eng->jit_rollout = nullptr;
                         if (eng->jit_module) { (void)hipModuleUnload(eng->jit_module); eng->jit_module = nullptr; }
                         (void)hipGetLastError();
+                        if (!res.from_cache) break;   // (a fresh build that does not load: nothing a second compile would change)
+                        const std::string stale = rw_jit::cache_file(sh, eng->prop.gcnArchName);
+                        if (stale.empty() || unlink(stale.c_str()) != 0) break;
+                        eng->jit_log += " | dropped the cached file";
                     }
+                }
                 }
             } else {
                 eng->jit_log = "no workgroup geometry of an exact-shape build fits this batch / shape";

@@ -157,6 +157,8 @@ const StaticEntry kEntries[] = {
     //  a multiple of 8 but not of 16, or an explicit geometry)
     RW_STATIC(20, 10, 4, 4, 80, 1, 8, 256, 0),
     RW_STATIC(20, 16, 6, 3, 144, 1, 16, 256, 0),   // rware-medium-6ag-hard
+    // (round 6: still smaller workgroups for the small BASELINE launches lose — medium-6ag-hard x 8192 with 4 envs 8.45 us against 6.28,
+    //  x 4096 5.88 against 5.65; tiny-2ag x 4096 with 8 envs 4.55 against 4.42, x 2048 4.24 against 4.19: profiles/r06_small_geom.txt)
     // (large-16ag r=2.  Round 3, same box: E = 8 36.2 us at B = 16384 vs 38.4 with E = 4 and 37.1 with E = 16; B = 4096: 14.6 vs 13.8
     //  with E = 4.  Round 4, agents in registers, same box: B = 16384 37.27 (E = 8) vs 37.29 (E = 4), both cached; B = 32768, past
     //  the Infinity Cache, non-temporal: 79.0 vs 75.3 -> 4 envs per workgroup in front)

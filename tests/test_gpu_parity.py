@@ -1065,6 +1065,44 @@ def test_runtime_specialised_builds_replay_reference_golden(name, tile, tmp_path
     again.env.close()
 
 
+def test_corrupt_cached_code_object_is_dropped_and_recompiled(tmp_path, monkeypatch):
+    """A cached code object the runtime refuses to load (junk behind a well-formed cache header — a truncated copy, a disk error):
+    rw_create drops the file, compiles the shape afresh, runs the specialised build and says what happened; the NEXT construction finds
+    a good cache again.  (rware_jit.cpp's own handling of malformed cache files runs under ASAN in oracle/sanitize.sh.)"""
+    monkeypatch.setenv("RWARE_JIT_CACHE", str(tmp_path))
+    kw = dict(rware_amd.env_kwargs("rware-tiny-2ag-v1"), n_agents=3, request_queue_size=3, column_height=5, max_steps=30)
+    okw = dict(kw, reward_type=rware_amd.enums.enum_value(kw["reward_type"]))
+    B = 512
+    env = rware_amd.WarehouseVecEnv(B, jit="force", **kw)
+    assert env.engines[0].info.jit == 1, env.engines[0].jit_log()
+    env.close()
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    assert len(files) == 1
+    path = os.path.join(tmp_path, files[0])
+    blob = open(path, "rb").read()
+    head = blob.split(b"\n", 3)
+    assert head[0] == b"RWJIT1" and len(head) == 4
+    with open(path, "wb") as f:   # the header stays, the code object becomes noise of the same length
+        f.write(b"\n".join(head[:3]) + b"\n" + np.random.default_rng(1).integers(0, 256, size=len(head[3]), dtype=np.uint8).tobytes())
+    env = rware_amd.WarehouseVecEnv(B, jit="force", **kw)
+    eng = env.engines[0]
+    log = eng.jit_log()
+    assert eng.info.jit == 1 and eng.info.build_kind == 1, log                      # compiled afresh, not the generic kernel
+    assert "loading the code object failed" in log and "dropped the cached file" in log and "retry" in log, log
+    orc = OracleVecEnv(B, **okw)
+    assert np.array_equal(env.reset(seed=5)[0], orc.reset(seed=5))
+    rng = np.random.default_rng(6)
+    for t in range(40):
+        a = rng.integers(0, 5, size=(B, 3)).astype(np.int32)
+        obs, rew, term, _, _ = env.step(a)
+        o2, r2, d2 = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), t
+    env.close()
+    env = rware_amd.WarehouseVecEnv(B, jit="force", **kw)
+    assert env.engines[0].info.jit == 2, env.engines[0].jit_log()                    # the cache is good again
+    env.close()
+
+
 def test_runtime_specialisation_policy(tmp_path, monkeypatch):
     """Default policy: a shape without an exact / agent-count-static build is specialised at construction when the batch has at
     least 4096 envs; small batches, registered shapes and jit=False keep the ahead-of-time kernels.  The specialised build
