@@ -6,6 +6,8 @@
 #     under ThreadSanitizer: an exact-shape build on a golden trace, the generic kernel, a per-cell (kCell) agent-phase build with 10 and
 #     16 agents in crowded warehouses, a chunk-pipelined (PIPE=1) build walking several chunks per workgroup, and rw_multi's launcher
 #     threads: 8 engines, >= 1000 rounds, create / destroy cycles (the sleep / wake handshake);
+#  2b. the WHOLE emulation library under AddressSanitizer + UBSan (heap redzones around every device buffer, the LDS behind a launch's dynamic
+#     shared memory poisoned): the emulated engine tests and the reference's KATs;
 #  3. rware_jit.cpp under AddressSanitizer + UBSan: no hipRTC library, a library without the entry points, corrupt / truncated / foreign
 #     cache files, a cache directory that is not private.
 set -u
@@ -118,6 +120,20 @@ for cycle in range(6):
 print(f"tsan-run rw_multi, 8 engines, launcher threads: {rounds} rounds over 6 create / destroy cycles bit-exact", flush=True)
 EOP
 echo "(a ThreadSanitizer WARNING line above = a reported race; none = clean)"
+
+echo "== 2b. the whole emulation library (every table group, all generic kernels, the C-ABI host code) under -fsanitize=address,undefined: the emulated engine tests + the reference's KATs"
+echo "   (device buffers are heap blocks with redzones; the LDS behind each launch's dynamic shared memory is poisoned: an out-of-bounds index in a kernel or in the host code faults)"
+AFLAGS="-DRW_NO_JIT -DRW_WITH_PIPE=1 -O1 -g -std=c++17 -fPIC -pthread -Itests/emu -Wno-unknown-pragmas -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer"
+A=$OUT/asan; mkdir -p $A
+( for g in $(seq 0 18); do echo "g++ $AFLAGS -DRW_STATIC_GROUP=$g -c -x c++ $CSRC/rware_static.hip -o $A/s$g.o"; done
+  for r in 1 2 3 4 5; do echo "g++ $AFLAGS -DRW_GENERIC_R=$r -c -x c++ $CSRC/rware_generic.hip -o $A/g$r.o"; done
+  echo "g++ $AFLAGS -c -x c++ $CSRC/rware_capi.hip -o $A/capi.o"; echo "g++ $AFLAGS -c -x c++ $CSRC/rware_selftest.hip -o $A/selftest.o"
+  echo "g++ $AFLAGS -c tests/emu/emu_globals.cpp -o $A/glob.o" ) | xargs -P 8 -I{} sh -c "{} 2>/dev/null"
+g++ -shared -pthread -fsanitize=address,undefined -o $A/librware_emu_asan.so $A/*.o || exit 1
+LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:allow_user_poisoning=1 UBSAN_OPTIONS=print_stacktrace=1 RWARE_ALLOW_STALE_PMC=1 \
+  RWARE_EMU_LIB=$A/librware_emu_asan.so timeout 5400 python -m pytest tests/test_engine_emulated.py tests/test_reference_kats.py tests/test_gymnasium_boundary.py -q -x -p no:cacheprovider -n 6 \
+  --deselect tests/test_engine_emulated.py::test_rw_multi_launcher_threads_overlap_the_enqueues 2>&1 | tail -6
+echo "   (deselected: the one wall-clock comparison of the suite — launcher threads against the in-call loop — which a sanitizer build distorts)"
 
 echo "== 3. rware_jit.cpp under -fsanitize=address,undefined: no hipRTC, a library without the entry points, corrupt / truncated / foreign cache files, a cache directory that is not private"
 make -s -C $CSRC rware_jit_sources.inc   # (the device headers as string literals: rware_jit.cpp includes them)

@@ -3,10 +3,15 @@
 // way of passing them that was tried — lambdas, always_inline or not — reschedules the kernels around it (round 5: +-10
 // instructions per kernel, two 13/14-agent builds over a register cliff).  Splitting the text keeps every build's ISA.
     // ---------------------------------------------------------------- ST: obs, float4 #q == nibble #q
+    // The chunk's first float sits on a 16-byte boundary whenever the chunk size is a multiple of 4 envs — every specialised build (a
+    // compile-time fact there) and the default geometries of the generic kernel.  An odd run-time geometry (envs_per_workgroup 3, 5, ...) may
+    // start a chunk on a 4- or 8-byte boundary: the hardware's dwordx4 stores do not mind, but a float4 store through a misaligned pointer
+    // is undefined in C++ (UBSan on the host-thread build, round 6) — such a chunk takes the scalar tail loops below for all of its floats.
+    constexpr bool kChunkAligned = Cfg::kE != 0 && Cfg::kE % 4 == 0;
     if constexpr (!kImage) {
         const int nf = nea * L;
-        const int nf4 = nf >> 2;
-        float *out = obs_t + (size_t)e0 * N * L;  // 16-byte aligned: e0 is a multiple of 4
+        float *out = obs_t + (size_t)e0 * N * L;  // 16-byte aligned when e0 is a multiple of 4 (kChunkAligned), else checked
+        const int nf4 = (kChunkAligned || (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? nf >> 2 : 0;
         float4 *out4 = reinterpret_cast<float4 *>(out);
         auto spread = [&](uint32_t nib) -> float4 {  // 4 bits -> 4 floats
             // one multiply spreads the bits into 4 bytes (0 or 1 each); hidden from the optimiser so that each
@@ -151,8 +156,9 @@
     }
     else {  // IMAGE: every element is a bit of the string; no coordinate slots
         const int Limg = k_n_layers * CELLS;
-        const int nf = nea * Limg, nf4 = nf >> 2;
-        float *out = obs_t + (size_t)e0 * N * Limg;  // 16-byte aligned: e0 is a multiple of 4
+        const int nf = nea * Limg;
+        float *out = obs_t + (size_t)e0 * N * Limg;  // 16-byte aligned when e0 is a multiple of 4 (kChunkAligned), else checked
+        const int nf4 = (kChunkAligned || (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? nf >> 2 : 0;
         if (worker) {
             const int shift = (tid & 7) << 2, words_per_pass = TW >> 3;  // (see the FLATTENED bulk pass)
             const uint32_t *wp = s_obits + (tid >> 3);

@@ -12,6 +12,28 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 os.environ["RWARE_HOOKS"] = "1"
 
 
+import pytest  # noqa: E402
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """`pytest tests -m "not gpu"` — the CPU suite, ~400 tests, most of them the product's kernels on host threads (every workgroup
+    = 256 OS threads): ≈ 25 min on one core, ≈ 5 min on six.  When pytest-xdist is installed and the caller did not say otherwise
+    (no -n, not --collect-only / --pdb, RWARE_TESTS_NO_AUTO_XDIST unset), the CPU suite spreads itself over the cores.  The GPU suite
+    (`-m gpu`) is never touched: one device, one process."""
+    opt = config.option
+    if os.environ.get("RWARE_TESTS_NO_AUTO_XDIST") == "1" or not config.pluginmanager.hasplugin("xdist"):
+        return None
+    if os.environ.get("PYTEST_XDIST_WORKER") or hasattr(config, "workerinput"):   # (an xdist worker runs this hook too: never nest)
+        return None
+    if getattr(opt, "numprocesses", None) is not None or (getattr(opt, "markexpr", "") or "").replace(" ", "") != "notgpu":
+        return None
+    if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
+        return None
+    opt.numprocesses = max(1, min(6, (os.cpu_count() or 2) - 1))   # (xdist's own hook, next in line, turns this into workers)
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver via gpurun)")
 

@@ -13,6 +13,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+#endif
+
 #include <algorithm>
 #include <chrono>
 #include <thread>
@@ -122,6 +126,13 @@ void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t 
         return;
     }
     std::lock_guard<std::mutex> emu_launch_lock(emu_launch_mutex);
+#if defined(__SANITIZE_ADDRESS__)
+    // AddressSanitizer build (oracle/sanitize.sh): the "LDS" behind what this launch asked for is poisoned, so a kernel that indexes past
+    // its dynamic shared memory faults here the way it would corrupt a neighbour workgroup's LDS on the GPU
+    const size_t emu_lds_all = 160 * 1024, emu_lds_used = std::min(emu_lds_all, (lds_bytes + 7) & ~(size_t)7);
+    __asan_poison_memory_region((char *)rw::smem + emu_lds_used, emu_lds_all - emu_lds_used);
+    struct EmuUnpoison { ~EmuUnpoison() { __asan_unpoison_memory_region((char *)rw::smem, 160 * 1024); } } emu_unpoison;
+#endif
     for (unsigned b = 0; b < grid.x; ++b) {
         pthread_barrier_t bar;
         pthread_barrier_init(&bar, nullptr, block.x);

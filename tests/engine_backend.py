@@ -13,6 +13,10 @@ EMU_LIB = os.path.join(EMU_DIR, "librware_emu.so")
 
 
 def build_emu() -> str:
+    # RWARE_EMU_LIB: a prebuilt emulation library to use instead (oracle/sanitize.sh points the emulated tests at its ASAN build)
+    other = os.environ.get("RWARE_EMU_LIB")
+    if other:
+        return other
     subprocess.check_call(["make", "-s", "-j8", "-C", EMU_DIR], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return EMU_LIB
 
