@@ -66,6 +66,16 @@ def roofline_fields(a_bytes, e_bytes, traffic, k_ms):
         "algorithmic_bytes_per_launch": a_bytes, "engine_bytes_per_launch": e_bytes,
         "peak": HBM_PEAK_GBPS, "peak_measured": HBM_MEASURED_GBPS,
     }
+def floor_fraction(floor_ms, k_ms):
+    """store-only kernel time / step kernel time.  A kernel that only writes the observations cannot take longer than the one that also
+    computes them: a ratio above 1 means the two measurements were disturbed differently (ranks sharing one device in the rehearsal tests, a
+    clock step between the two legs) — reported as None rather than as a fraction above 1."""
+    if not floor_ms or not k_ms:
+        return None
+    f = floor_ms / k_ms
+    return f if f <= 1.0 else None
+
+
 TAPE_STEPS = int(os.environ.get("RWARE_BENCH_TAPE_STEPS", "256"))
 SUSTAINED_STEPS, SUSTAINED_WARMUP = 2000, 100
 SOAK_SECONDS = 3.2  # the `soak` leg: back-to-back launches for at least this long (an outside utilisation sampler can see the GPU busy)
@@ -281,7 +291,7 @@ def hbm_regime_leg(torch, rware_amd, local_rank, env_id, sha):
             "value": B * N * K / wall, "unit": "agent-steps/s",
             # (`achieved` / `frac`: physical bytes / time; `*_algorithmic`: SURVEY.md §8(d)'s bytes, a work rate — see roofline_fields)
             **roofline_fields(a_bytes, e_bytes, traffic, k_ms), "unit_bw": "GB/s",
-            "store_only_kernel_ms_per_launch": floor_ms, "frac_of_store_only_kernel": (floor_ms / k_ms) if floor_ms else None,
+            "store_only_kernel_ms_per_launch": floor_ms, "frac_of_store_only_kernel": floor_fraction(floor_ms, k_ms),
             "envs_per_workgroup": int(info.envs_per_workgroup), "kernel_specialised": bool(info.specialised),
             "start_stagger_ns_per_slot": 10 * int(info.stagger_ticks),   # launches of two or more rounds of workgroups (rw_info.stagger_ticks)
             "observation_stores": "non-temporal" if int(info.obs_stores_stream) else "cached",
@@ -707,7 +717,7 @@ def main():
                 # a kernel that does nothing but write this step's observations, same launch geometry and store instruction, launched
                 # back to back: what ANY kernel producing these observations takes at the least on this device, and the step kernel's
                 # time as a multiple of it (the simulation, the window gather and the state traffic are what is on top)
-                "store_only_kernel_ms_per_launch": floor_ms, "frac_of_store_only_kernel": (floor_ms / k_ms) if floor_ms else None,
+                "store_only_kernel_ms_per_launch": floor_ms, "frac_of_store_only_kernel": floor_fraction(floor_ms, k_ms),
                 "kernel_sources_sha": sha,
             },
         }
