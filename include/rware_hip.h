@@ -318,9 +318,11 @@ typedef struct rw_info {
                                   cell) + packed agent records r/w + actions + queue + counters / flags + observation + rewards +
                                   terminated (+ messages r/w, IMAGE_DICT features).  The PMC traffic of a step is checked against
                                   it; bench.py prices `frac_engine` on it (<= 1 by construction)                               */
-    int32_t stagger_ticks;     /* > 0: the launch is two or more rounds of workgroups (and <= 12 agents) and the k-th of the first eight workgroups a CU
-                                  receives starts k * stagger_ticks * 10 ns late, so that the rounds do not run their load / compute /
-                                  store phases in lock-step (A/B runs: RWARE_STAGGER_TICKS=n with RWARE_HOOKS=1; 0 = off) */
+    int32_t stagger_ticks;     /* > 0: the k-th of the first eight workgroups a CU receives starts k * stagger_ticks * 10 ns late, so that
+                                  the workgroups of a CU do not run their load / agent / store phases in lock-step.  rw_create's measured rule:
+                                  <= 12 agents — 250 ns from two rounds of workgroups on; 13 .. 16 agents — 550 ns at one round and from four
+                                  rounds on (400 ns up to two rounds with sensor_range 2); else 0 (A/B runs: RWARE_STAGGER_TICKS=n with
+                                  RWARE_HOOKS=1; 0 = off).  A delay, never a different result */
     int32_t pipe_envs_per_workgroup; /* != 0: rw_step* launches run the chunk-pipelined persistent build with chunks of this many envs ... */
     int32_t pipe_workgroups;         /* ... on this many persistent workgroups (rw_stream_flags RW_PIPE_ON / RW_PIPE_OFF)              */
     int32_t reserved[1];

@@ -193,3 +193,15 @@ def test_runtime_specialisation_keeps_no_cache_in_shared_directories(tmp_path):
     out = pr.stdout.strip().splitlines()
     assert pr.returncode == 0 and int(out[0]) > 10000 and "not a private directory" in out[1], (out, pr.stderr[-400:])
     assert not list(shared.glob("*.hsaco"))
+
+
+def test_header_and_c_example_compile_as_plain_c11():
+    """include/rware_hip.h is a C header (the boundary a cgo / JNI / ctypes binding reads): it and examples/rware_c_example.c — the
+    boundary used from plain C, no Python, no torch — go through `gcc -std=c11 -pedantic` without a diagnostic."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for args in (["-x", "c", os.path.join(root, "include", "rware_hip.h")], [os.path.join(root, "examples", "rware_c_example.c")]):
+        out = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include")] + args,
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr

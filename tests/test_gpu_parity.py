@@ -1543,3 +1543,43 @@ def test_largest_single_gpu_configurations_every_step(env_id, extra, B, T, shard
         assert np.array_equal(st[k], so[k]), k
     orc.close()
     env.close()
+
+
+def test_c_example_program_matches_the_oracle(tmp_path):
+    """examples/rware_c_example.c — the C-ABI from plain C: layout arrays, rw_config, rw_create, rw_reset with seeds, rw_step with HOST
+    actions, rw_read_outputs — compiled with gcc against librware_hip.so and run as its own process; its checksum over every step's
+    observations, rewards and flags equals the oracle's on the same seeds and (LCG) actions, across autoresets."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "robotic-warehouse_amd", "csrc")
+    exe = str(tmp_path / "rware_c_example")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "rware_c_example.c"),
+                           "-L", csrc, "-lrware_hip", f"-Wl,-rpath,{csrc}", "-o", exe])
+    B, steps, seed = 96, 75, 11
+    out = subprocess.run([exe, str(B), str(steps), str(seed)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    fields = dict(f.split("=", 1) for f in out.stdout.split() if "=" in f)
+    assert int(fields["envs"]) == B and int(fields["obs_length"]) == 71 and int(fields["build_kind"]) == 1
+
+    def fnv(h, a):
+        for b in np.ascontiguousarray(a).view(np.uint8).ravel().tolist():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    kw = dict(rware_amd.env_kwargs("rware-tiny-2ag-v1"), max_steps=30)
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    orc = OracleVecEnv(B, **kw)
+    h = fnv(14695981039346656037, orc.reset(seed=seed))
+    lcg, reward_sum, ends = (seed * 2654435761 + 12345) & 0xFFFFFFFF, 0.0, 0
+    for t in range(steps):
+        a = np.empty(B * 2, np.int32)
+        for i in range(B * 2):
+            lcg = (lcg * 1664525 + 1013904223) & 0xFFFFFFFF
+            r = (lcg >> 16) % 10
+            a[i] = 1 if r < 5 else r - 5
+        o2, r2, d2 = orc.step_autoreset(a.reshape(B, 2), "next_step")
+        h = fnv(fnv(fnv(h, o2.astype(np.float32)), r2.astype(np.float32)), d2.astype(np.uint8))
+        reward_sum += float(r2.sum()); ends += int(d2.sum())
+    assert fields["checksum"] == f"{h:016x}", (fields, f"{h:016x}")
+    assert float(fields["reward_sum"]) == reward_sum and int(fields["episode_ends"]) == ends and ends >= 2 * B
