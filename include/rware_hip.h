@@ -108,7 +108,12 @@ enum rw_stream_flags {
      * its chunk size), else the classic kernel runs and rw_jit_log() says why; rw_info.pipe_workgroups != 0 tells which one runs.
      * RW_PIPE_OFF: never (the default).  (A/B runs: RWARE_PIPE=0|1 with RWARE_HOOKS=1.) */
     RW_PIPE_OFF = 32,
-    RW_PIPE_ON = 64
+    RW_PIPE_ON = 64,
+    /* Event counters (SURVEY.md §5 "metrics"): with RW_STATS_ON the engine keeps two running totals per env in RW_BUF_STAT_DELIVERIES and
+     * RW_BUF_STAT_FAILED_MOVES (below) — off by default, and the reference's `info` stays {} either way (rware/warehouse.py:746-747).
+     * Counted by the service wavefront beside the observation stores (re-derived from what the state write-back holds; nothing is added
+     * to the agent phases), in every launch form: rw_step*, fused rollouts, tapes, HIP graphs, rw_multi. */
+    RW_STATS_ON = 128
 };
 
 /* Device buffers (all env-major, C-contiguous).  Replaces the attributes callers read off the
@@ -151,7 +156,14 @@ enum rw_buffer_kind {
                                                    other envs keep older contents); the reset observation goes to RW_BUF_OBS.  Empty in
                                                    the other autoreset modes                                              */
     RW_BUF_FINAL_FEATURES = 19, /* float32 [B][N][6] ... and, IMAGE_DICT, the feature vectors of that observation (:727-742)   */
-    RW_BUF_KIND_COUNT = 20
+    /* RW_STATS_ON only (empty otherwise): running totals per env since rw_create — steps add to them, NOTHING resets them (not reset(),
+     * not autoreset: an episode's figure is the difference between two reads, and SAME_STEP's terminating step is counted before its
+     * reset); rw_write zeroes or seeds them, snapshots carry them; int32, wrapping.  What is counted, in the reference's terms: */
+    RW_BUF_STAT_DELIVERIES = 20,   /* int32 [B]  requested shelves brought to a goal: one per queue slot replaced (:907-917)             */
+    RW_BUF_STAT_FAILED_MOVES = 21, /* int32 [B]  (agent, step) pairs whose FORWARD the step turned into NOOP: a loaded agent facing a
+                                                 standing shelf (:836-846) or a mover that lost the collision resolution (:871-876).
+                                                 A FORWARD into a wall is clamped to a self-target (:105-112) and is NOT one            */
+    RW_BUF_KIND_COUNT = 22
 };
 
 /* Mirrors the constructor of rware.warehouse.Warehouse (rware/warehouse.py:146-170).  The
@@ -302,8 +314,11 @@ typedef struct rw_info {
     int32_t envs_per_workgroup, threads_per_workgroup, n_workgroups, lds_bytes;
     int32_t device_id, compute_units;
     int32_t specialised;  /* 1: a kernel build with this task's shapes folded in at compile time is in use */
-    int32_t state_layout; /* always 0 since round 3 (a per-shelf position layout for big batches existed in between: obsolete with
-                             non-temporal observation stores) */
+    int32_t wave_priority; /* 1: the per-step launches raise their wavefronts' priority (s_setprio 3) from the start of the kernel to
+                             the barrier behind the agent phases, so that the dependent chain in front of the first observation store is
+                             not queued behind the neighbours' store phase on the same CU.  rw_create's measured rule: on, except 13 .. 16
+                             agents at sensor_range 1 and batches far past the Infinity Cache (A/B runs: RWARE_PRIO=0|1 with RWARE_HOOKS=1).
+                             A scheduling hint, never a different result.  (The slot was `state_layout`, 0 since round 3.) */
     int32_t build_kind;   /* which build of the step kernel runs: 0 generic (every shape at run time), 1 exact-shape, 2 agent-count-
                              static (shapes + agent count folded in, request-queue length at run time), 3 size-static (grid folded in,
                              agent count and queue length at run time).  (Occupies what was alignment padding: same struct size.) */
@@ -325,7 +340,7 @@ typedef struct rw_info {
                                   RWARE_HOOKS=1; 0 = off).  A delay, never a different result */
     int32_t pipe_envs_per_workgroup; /* != 0: rw_step* launches run the chunk-pipelined persistent build with chunks of this many envs ... */
     int32_t pipe_workgroups;         /* ... on this many persistent workgroups (rw_stream_flags RW_PIPE_ON / RW_PIPE_OFF)              */
-    int32_t reserved[1];
+    int32_t stats;                   /* 1: RW_STATS_ON — RW_BUF_STAT_* are kept (was `reserved[1]`: same struct size)                 */
 } rw_info;
 int rw_get_info(const rw_engine *eng, rw_info *out);
 /* what the run-time specialisation did for this engine: cache file / compile time, or why it is not in use ("" if not tried) */

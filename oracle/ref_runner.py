@@ -156,6 +156,40 @@ def ref_step(env, actions):
         return env.step(list(actions))
 
 
+class _CountingGenerator:
+    """Stands in front of the env's numpy Generator for ONE step and counts its `choice` calls: `Warehouse.step` draws exactly one
+    replacement request per delivered shelf (`rware/warehouse.py:916`) and nothing else.  Every other attribute is the Generator's."""
+
+    def __init__(self, gen):
+        self._gen, self.choice_calls = gen, 0
+
+    def choice(self, *args, **kwargs):
+        self.choice_calls += 1
+        return self._gen.choice(*args, **kwargs)
+
+    def __getattr__(self, name):
+        return getattr(self._gen, name)
+
+
+def ref_step_events(env, actions):
+    """`ref_step` plus the two event counts the engine can keep per env (RW_BUF_STAT_*), read off the unmodified reference as it runs:
+    deliveries = replacement draws of this step (`rware/warehouse.py:907-917`: one `np_random.choice` per delivered shelf — counting
+    changed queue slots instead would miss a slot that is refilled twice in one step, when the second goal holds the shelf the first
+    delivery has just requested), failed moves = agents that asked for FORWARD and whose `req_action` the step turned into NOOP
+    (`:843-846` shelf-block cancel, `:871-876` collision resolution).  Returns (step result, deliveries, failed moves)."""
+    wh = load_reference()
+    asked = [wh.Action(a[0] if env.msg_bits > 0 else a) for a in actions]
+    gen = env.np_random
+    counting = _CountingGenerator(gen)
+    env.np_random = counting
+    try:
+        out = ref_step(env, actions)
+    finally:
+        env.np_random = gen
+    failed = sum(1 for ag, a in zip(env.agents, asked) if a == wh.Action.FORWARD and ag.req_action == wh.Action.NOOP)
+    return out, counting.choice_calls, failed
+
+
 # --------------------------------------------------------------------------------------
 # registry kwargs (read from the reference's own register() calls) and construction
 # --------------------------------------------------------------------------------------

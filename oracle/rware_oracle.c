@@ -302,7 +302,12 @@ static int in_queue(const int32_t *q, int Q, int sid) {
 }
 
 /* returns 0 ok, -2 invalid action */
-static int step_one(const orc_cfg *c, env_view v, const int32_t *act, float *rew, uint8_t *done) {
+/* n_deliv / n_failed (optional): this step's count of shelf deliveries (:907-927) and of agents whose FORWARD the reference
+ * turned into NOOP — the shelf-block cancel (:843-846) and the agents that fail the collision resolution (:871-876).  The
+ * reference keeps no such counters (`info` is {}, :746-747); oracle/ref_runner.py derives the same two numbers from the
+ * reference's own objects (request_queue before / after, agent.req_action after the step) to pin these. */
+static int step_one(const orc_cfg *c, env_view v, const int32_t *act, float *rew, uint8_t *done, int32_t *n_deliv,
+                    int32_t *n_failed) {
     const int H = c->H, W = c->W, N = c->N, Q = c->Q, HW = H * W;
     int32_t *gA = v.grid, *gS = v.grid + HW;
     int req[MAXN], start[MAXN], target[MAXN], commit[MAXN];
@@ -336,6 +341,7 @@ static int step_one(const orc_cfg *c, env_view v, const int32_t *act, float *rew
             !(gA[target[i]] && v.acarry[gA[target[i]] - 1])) {
             req[i] = A_NOOP;
             target[i] = start[i];
+            if (n_failed) *n_failed += 1;
         }
     }
     /* G: nodes = cells, one out-edge per agent.  out[cell] = target cell, or -1 (no agent). */
@@ -418,7 +424,10 @@ static int step_one(const orc_cfg *c, env_view v, const int32_t *act, float *rew
     }
     free(out);
     for (int i = 0; i < N; ++i)
-        if (!commit[i]) req[i] = A_NOOP; /* failed agents :871-876 */
+        if (!commit[i]) { /* failed agents :871-876 (all of them asked for FORWARD, :875) */
+            req[i] = A_NOOP;
+            if (n_failed) *n_failed += 1;
+        }
 
     for (int i = 0; i < N; ++i) rew[i] = 0.0f;
     double r64[MAXN];
@@ -478,6 +487,7 @@ static int step_one(const orc_cfg *c, env_view v, const int32_t *act, float *rew
         int slot = in_queue(v.queue, Q, sid);
         if (slot < 0) continue;
         delivered = 1;
+        if (n_deliv) *n_deliv += 1;
         /* candidates = shelves not in the queue, id order; one bounded draw in [0, n_cand) :915-917 */
         int n_cand = S - Q;
         pcg64 g;
@@ -517,15 +527,23 @@ static int step_one(const orc_cfg *c, env_view v, const int32_t *act, float *rew
     return 0;
 }
 
-int orc_step(const orc_cfg *c, int B, orc_state *s, const int32_t *actions, float *rewards,
-             uint8_t *done, const uint8_t *mask) {
+/* orc_step with the two per-env event counters: stat_deliveries[e] / stat_failed_moves[e] (either may be NULL) grow by this
+ * step's counts; the caller zeroes them when it resets an env. */
+int orc_step_stats(const orc_cfg *c, int B, orc_state *s, const int32_t *actions, float *rewards, uint8_t *done,
+                   const uint8_t *mask, int32_t *stat_deliveries, int32_t *stat_failed_moves) {
     for (int e = 0; e < B; ++e) {
         if (mask && !mask[e]) continue;
         int rc = step_one(c, view(c, s, e), actions + (size_t)e * c->N * (1 + c->msg_bits),
-                          rewards + (size_t)e * c->N, done + e);
+                          rewards + (size_t)e * c->N, done + e, stat_deliveries ? stat_deliveries + e : NULL,
+                          stat_failed_moves ? stat_failed_moves + e : NULL);
         if (rc) return rc;
     }
     return 0;
+}
+
+int orc_step(const orc_cfg *c, int B, orc_state *s, const int32_t *actions, float *rewards,
+             uint8_t *done, const uint8_t *mask) {
+    return orc_step_stats(c, B, s, actions, rewards, done, mask, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------------------ */

@@ -60,7 +60,7 @@ def lib():
         _lib.orc_rng_bounded.restype = C.c_uint32
         _lib.orc_rng_choice.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib.orc_rng_choice.restype = None
-        for f in ("orc_reset", "orc_step", "orc_obs", "orc_recalc_grid", "orc_obs_image"):
+        for f in ("orc_reset", "orc_step", "orc_step_stats", "orc_obs", "orc_recalc_grid", "orc_obs_image"):
             getattr(_lib, f).restype = C.c_int
     return _lib
 
@@ -146,6 +146,11 @@ class OracleVecEnv:
         self.inactive = np.zeros(B, np.int32)
         self.rng = np.zeros((B, 6), np.uint64)
         self.agent_msg = np.zeros((B, N), np.int32)
+        # event counters, running totals since construction — what the engine's RW_BUF_STAT_* buffers hold (reset() leaves them
+        # alone): shelf deliveries (:907-927) and FORWARD requests the reference turned into NOOP (:843-846, :871-876).  Not state:
+        # the reference has no such attributes (oracle/ref_runner.py ref_step_events reads the same figures off its objects).
+        self.stat_deliveries = np.zeros(B, np.int32)
+        self.stat_failed_moves = np.zeros(B, np.int32)
         self._st = None
 
     FIELDS = ("grid", "agent_x", "agent_y", "agent_dir", "agent_carry", "agent_delivered",
@@ -188,9 +193,10 @@ class OracleVecEnv:
         done = np.zeros(self.B, np.uint8)
         st = self._state()
         m = None if mask is None else np.ascontiguousarray(np.asarray(mask, np.uint8))
-        rc = lib().orc_step(C.byref(self.cfg), self.B, C.byref(st), a.ctypes.data_as(C.c_void_p),
-                            rew.ctypes.data_as(C.c_void_p), done.ctypes.data_as(C.c_void_p),
-                            None if m is None else m.ctypes.data_as(C.c_void_p))
+        rc = lib().orc_step_stats(C.byref(self.cfg), self.B, C.byref(st), a.ctypes.data_as(C.c_void_p),
+                                  rew.ctypes.data_as(C.c_void_p), done.ctypes.data_as(C.c_void_p),
+                                  None if m is None else m.ctypes.data_as(C.c_void_p),
+                                  self.stat_deliveries.ctypes.data_as(C.c_void_p), self.stat_failed_moves.ctypes.data_as(C.c_void_p))
         if rc == -2:
             raise ValueError("invalid action")
         assert rc == 0, rc

@@ -20,6 +20,7 @@ BUF = {
     "obs": 0, "rewards": 1, "terminated": 2, "truncated": 3, "grid": 4, "agent_x": 5, "agent_y": 6,
     "agent_dir": 7, "agent_carry": 8, "agent_delivered": 9, "queue": 10, "steps": 11, "inactive": 12,
     "rng": 13, "need_reset": 14, "actions": 15, "features": 16, "agent_msg": 17, "final_obs": 18, "final_features": 19,
+    "stat_deliveries": 20, "stat_failed_moves": 21,  # RW_STATS_ON only (empty otherwise)
 }
 BUF_DTYPE = {
     "obs": np.float32, "rewards": np.float32, "terminated": np.uint8, "truncated": np.uint8,
@@ -30,6 +31,7 @@ RW_STREAM_USE_GIVEN = 1  # rw_stream_flags: `stream` is taken literally, NULL ==
 RW_OBS_STORES_CACHED, RW_OBS_STORES_STREAM = 2, 4  # rw_stream_flags: keep the observation lines cached / force the non-temporal hint
 RW_JIT_OFF, RW_JIT_FORCE = 8, 16  # rw_stream_flags: run-time specialisation (hipRTC) never / always; default: shapes without an exact build, B >= 4096
 RW_PIPE_OFF, RW_PIPE_ON = 32, 64  # rw_stream_flags: the chunk-pipelined persistent per-step kernel never / wherever a build exists; default: the engine's measured rule
+RW_STATS_ON = 128  # rw_stream_flags: keep the per-env event counters RW_BUF_STAT_DELIVERIES / _FAILED_MOVES (off by default)
 
 AUTORESET = {"disabled": 0, None: 0, "next_step": 1, "same_step": 2}
 
@@ -48,11 +50,11 @@ class RwInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "num_envs", "grid_h", "grid_w", "n_agents", "request_queue_size", "n_shelves", "obs_length",
         "envs_per_workgroup", "threads_per_workgroup", "n_workgroups", "lds_bytes", "device_id",
-        "compute_units", "specialised", "state_layout", "build_kind")] + [
+        "compute_units", "specialised", "wave_priority", "build_kind")] + [
         ("algorithmic_bytes_per_env_step", C.c_int64),
         ("device_name", C.c_char * 128), ("arch_name", C.c_char * 64), ("obs_stores_stream", C.c_int32), ("jit", C.c_int32),
         ("engine_bytes_per_env_step", C.c_int64), ("stagger_ticks", C.c_int32), ("pipe_envs_per_workgroup", C.c_int32),
-        ("pipe_workgroups", C.c_int32), ("reserved", C.c_int32 * 1)]
+        ("pipe_workgroups", C.c_int32), ("stats", C.c_int32)]
 
 
 EXPORTS = (
@@ -185,7 +187,7 @@ class Engine:
                  max_inactivity_steps, max_steps, reward_type, normalised_coordinates=False,
                  autoreset_mode="next_step", device_id=0, envs_per_workgroup=0,
                  threads_per_workgroup=0, stream=None, library=None, observation_type=1,
-                 image_layers=(), image_directional=True, msg_bits=0, use_given_stream=False, obs_stores=None, jit=None, pipe=None):
+                 image_layers=(), image_directional=True, msg_bits=0, use_given_stream=False, obs_stores=None, jit=None, pipe=None, stats=False):
         self.lib = load(library)
         self._h = C.c_void_p()
         self._arena, self.arena_allocations = {}, 0  # rollout_host's device tapes (grow-only; freed in close())
@@ -200,7 +202,8 @@ class Engine:
             (C.c_int32 * 8)(*[int(l) for l in image_layers]), int(msg_bits),
             (RW_STREAM_USE_GIVEN if use_given_stream else 0) | {None: 0, "auto": 0, "cached": RW_OBS_STORES_CACHED, "stream": RW_OBS_STORES_STREAM}[obs_stores]
             | {None: 0, "auto": 0, False: RW_JIT_OFF, "off": RW_JIT_OFF, True: RW_JIT_FORCE, "force": RW_JIT_FORCE}[jit]
-            | {None: 0, "auto": 0, False: RW_PIPE_OFF, "off": RW_PIPE_OFF, True: RW_PIPE_ON, "on": RW_PIPE_ON}[pipe],
+            | {None: 0, "auto": 0, False: RW_PIPE_OFF, "off": RW_PIPE_OFF, True: RW_PIPE_ON, "on": RW_PIPE_ON}[pipe]
+            | (RW_STATS_ON if stats else 0),
             hw.ctypes.data, goals.ctypes.data, C.c_void_p(stream or 0))
         rc = self.lib.rw_create(C.byref(cfg), C.byref(self._h))
         if rc != RW_OK:
@@ -221,7 +224,9 @@ class Engine:
             "agent_delivered": (self.B, self.N), "queue": (self.B, self.Q), "steps": (self.B,),
             "inactive": (self.B,), "rng": (6, self.B), "need_reset": (self.B,),
             "actions": (self.B, self.N, 1 + self.M) if self.M else (self.B, self.N), "agent_msg": (self.B, self.N),
+            "stat_deliveries": (self.B,), "stat_failed_moves": (self.B,),
         }
+        self.stats = bool(i.stats)
 
     def _check(self, rc):
         if rc != RW_OK:

@@ -47,6 +47,7 @@ struct rw_engine {
     int S = 0, L = 0, OW = 0;
     int E = 0, T = 0, n_wg = 0;
     int stagger_ticks = 0, stagger_shift = 0;  // start stagger of a CU's first eight workgroups (multi-round launches: see the kernel's prologue)
+    bool prio = false;         // per-step launches carry OP_FLAG_PRIO: raised wavefront priority up to the agent-phase barrier (rw_info::wave_priority)
     size_t lds_bytes = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -91,6 +92,7 @@ struct rw_engine {
     bool q_runtime = false;    // the chosen build reads the request-queue length at run time (StaticEntry::Q == -1)
     bool wide = false;
     bool image = false;        // IMAGE / IMAGE_DICT observation kernels
+    bool stats = false;        // RW_STATS_ON: every launch carries OP_FLAG_STATS, RW_BUF_STAT_* are allocated
     int msg_bits = 0;          // communication bits per agent (FLATTENED only)
     int32_t *d_status = nullptr;
     hipEvent_t events[8]{};
@@ -147,6 +149,8 @@ int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false, hipE
     la.op = op | (la.timeline ? rw::OP_FLAG_TIMELINE : 0);
     const bool pipe = eng->pipe_kernel && op == rw::OP_STEP && !rollout;  // (persistent workgroups: no start stagger)
     if (!pipe) la.op |= (eng->stagger_ticks & 0xff) << 16 | (eng->stagger_shift & 0xf) << 24;
+    if (eng->stats) la.op |= rw::OP_FLAG_STATS;
+    if (eng->prio && !rollout) la.op |= rw::OP_FLAG_PRIO;
     if (op != rw::OP_OBS) eng->grid_stale = eng->agents_stale = eng->counters_stale = true;  // the kernels keep the shadow and the packed agent records current, not the int32 views
     if (!eng->own_stream && !eng->captured) {  // (a stream of the caller's may be capturing; the engine's own stream never is)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -449,6 +453,11 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             return bail(RW_ERR_INVALID_ARG);
         }
     }
+    const bool want_stats = (cfg->stream_flags & RW_STATS_ON) != 0;
+    if (want_stats && !rw_tab::generic_has_stats()) {
+        fail(eng, RW_ERR_UNSUPPORTED, "RW_STATS_ON: this library was built without the event-counter code (RW_STATS_BUILD)");
+        return bail(RW_ERR_UNSUPPORTED);
+    }
     {   // the generic build for this sensor range (rware_generic.hip); an exact-shape build may replace it below
         using pick_t = step_kernel_t (*)(bool, bool, bool, bool);
         static const pick_t kGeneric[5] = {rw_tab::generic_r1, rw_tab::generic_r2, rw_tab::generic_r3, rw_tab::generic_r4,
@@ -484,6 +493,12 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
                 if (geom_default ? (se.max_B == 0 || B <= se.max_B) : (E == se.E && T == se.T)) { best = &se; break; }
             }
             }
+        // event counters (RW_STATS_ON): only kernels compiled with the counting code (RW_STATS_BUILD) will do — the generic ones, a run-time
+        // compiled exact-shape build (below), and — in a library whose specialised builds were made with the switch — those
+        if (best && want_stats && !rw_tab::static_has_stats()) {
+            best = nullptr;
+            eng->jit_log = "event counters: the ahead-of-time exact-shape builds do not carry the counting code";
+        }
         if (best) {
             E = best->E;
             T = best->T;
@@ -554,12 +569,13 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
                 sh.directional = eng->image ? (cfg->image_directional ? 1 : 0) : -1;
                 for (int l = 0; l < n_layers && l < 8 && eng->image; ++l) sh.layers |= (uint32_t)layers[l] << (4 * l);
                 sh.nt = nt_rule(je_) ? 1 : 0;
+                sh.stats = want_stats ? 1 : 0;
                 // (two attempts: a CACHED code object the runtime refuses — a truncated or foreign file behind a well-formed header — is
                 //  dropped from the cache and the shape compiled afresh, once; otherwise every later construction would trip over it)
                 for (int attempt = 0; attempt < 2 && eng->jit_state != 1 && eng->jit_state != 2; ++attempt) {
                 rw_jit::Result res;
                 const bool built = rw_jit::compile(sh, eng->prop.gcnArchName, &res);
-                eng->jit_log = (attempt ? eng->jit_log + " | retry: " : std::string()) + res.log;
+                eng->jit_log = (attempt ? eng->jit_log + " | retry: " : eng->jit_log.empty() ? std::string() : eng->jit_log + " | ") + res.log;
                 eng->jit_state = -1;
                 if (!built) break;
                 {
@@ -638,6 +654,15 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         }
         const char *st = rw_hook("RWARE_STAGGER_TICKS");  // (A/B and test hook: 0 = off, n = ticks whatever the launch size)
         if (st && *st && pow2) eng->stagger_ticks = std::min(255, std::max(0, atoi(st)));
+        // Wavefront priority up to the agent-phase barrier (round 6, rware_kernels.h; same-box A/B of library variants and of this
+        // switch: profiles/r06_prio_ab.txt, r06_prio_ab2.txt, r06_prio_wide.txt, r06_prio_sweep.txt).  On for every launch except the
+        // 13 .. 16-agent ones at sensor_range 1 — the family that runs start-staggered: with the priority on top they lose (medium-13ag x
+        // 16384 16.3 -> 17.7 us, small-15ag 19.3 -> 20.0, small-14ag x 65536 48.5 -> 52.2) — and except steps whose observations approach
+        // the Infinity Cache size (200 MB of them and more: small-12ag x 65536 42.3 -> 42.9, small-19ag x 65536 81.2 -> 83.0, small-4ag x
+        // 262144 58.9 -> 59.6), which do not move or lose a per cent or two.
+        eng->prio = !(R == 1 && N >= 13 && N <= 16) && (double)B * N * eng->L * 4 <= 200e6;
+        const char *pr = rw_hook("RWARE_PRIO");  // (A/B and test hook: 0 = off, 1 = on whatever the shape)
+        if (pr && (pr[0] == '0' || pr[0] == '1')) eng->prio = pr[0] == '1';
     }
 
     {
@@ -653,7 +678,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         const char *pee = rw_hook("RWARE_PIPE_E");
         const int want_e = pee ? atoi(pee) : 0;
         const StaticEntry *pb = nullptr;
-        if (mode >= 0 && !eng->image && eng->msg_bits == 0 && !eng->jit_step)
+        if (mode >= 0 && !eng->image && eng->msg_bits == 0 && !eng->jit_step && !(want_stats && !rw_tab::static_has_stats()))
             for (int grp = 0; grp < rw_tab::kStaticGroups && !pb; ++grp) {
                 int n_se = 0;
                 const StaticEntry *tab = rw_tab::static_group(grp, &n_se);
@@ -727,13 +752,16 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     const bool want_final = cfg->autoreset_mode == RW_AUTORESET_SAME_STEP;
     n_elems[RW_BUF_FINAL_OBS] = want_final ? szB * N * eng->L : 0;
     n_elems[RW_BUF_FINAL_FEATURES] = want_final && obs_type == RW_OBS_IMAGE_DICT ? szB * N * 6 : 0;
+    // the event counters: allocated (and counted into) only on request
+    eng->stats = want_stats;
+    n_elems[RW_BUF_STAT_DELIVERIES] = n_elems[RW_BUF_STAT_FAILED_MOVES] = eng->stats ? szB : 0;
     // One slab for every buffer: the per-step working set (agent SoA, queue, counters, flags, rewards,
     // shelf shadow) sits in a few contiguous MiB, so a workgroup's ~15 streams share TLB entries
     // instead of touching 15 separate allocations.  Order = hot and small first.
     static const int order[RW_BUF_KIND_COUNT] = {
         RW_BUF_AGENT_X, RW_BUF_AGENT_Y, RW_BUF_AGENT_DIR, RW_BUF_AGENT_CARRY, RW_BUF_AGENT_DELIVERED, RW_BUF_QUEUE,
         RW_BUF_AGENT_MSG, RW_BUF_STEPS, RW_BUF_INACTIVE, RW_BUF_NEED_RESET, RW_BUF_REWARDS, RW_BUF_TERMINATED, RW_BUF_TRUNCATED,
-        RW_BUF_ACTIONS, RW_BUF_RNG, RW_BUF_FEATURES, RW_BUF_OBS, RW_BUF_FINAL_OBS, RW_BUF_FINAL_FEATURES, RW_BUF_GRID};
+        RW_BUF_STAT_DELIVERIES, RW_BUF_STAT_FAILED_MOVES, RW_BUF_ACTIONS, RW_BUF_RNG, RW_BUF_FEATURES, RW_BUF_OBS, RW_BUF_FINAL_OBS, RW_BUF_FINAL_FEATURES, RW_BUF_GRID};
     auto up = [](size_t x) { return (x + 4095) & ~(size_t)4095; };
     size_t slab_bytes = 0, off[RW_BUF_KIND_COUNT];
     eng->rec_off = 0;  // the packed agent records lead the hot set, the counter records follow
@@ -826,6 +854,8 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     p.amsg = (int32_t *)eng->buf[RW_BUF_AGENT_MSG].ptr;
     p.final_obs = want_final ? (float *)eng->buf[RW_BUF_FINAL_OBS].ptr : nullptr;
     p.final_features = n_elems[RW_BUF_FINAL_FEATURES] ? (float *)eng->buf[RW_BUF_FINAL_FEATURES].ptr : nullptr;
+    p.stat_deliveries = eng->stats ? (int32_t *)eng->buf[RW_BUF_STAT_DELIVERIES].ptr : nullptr;
+    p.stat_failed_moves = eng->stats ? (int32_t *)eng->buf[RW_BUF_STAT_FAILED_MOVES].ptr : nullptr;
     rw::LaunchArgs &la = eng->la;
     la.actions = (const int32_t *)eng->buf[RW_BUF_ACTIONS].ptr;
     la.reset_mask = eng->d_mask;
@@ -1054,7 +1084,7 @@ struct rw_snapshot {
 namespace {
 // the state that reset()/step() evolve: (device pointer, size) pieces in a fixed order
 std::vector<std::pair<void *, size_t>> state_pieces(rw_engine *eng) {
-    static const int kinds[] = {RW_BUF_QUEUE, RW_BUF_RNG, RW_BUF_AGENT_MSG};
+    static const int kinds[] = {RW_BUF_QUEUE, RW_BUF_RNG, RW_BUF_AGENT_MSG, RW_BUF_STAT_DELIVERIES, RW_BUF_STAT_FAILED_MOVES};  // (the last two: empty without RW_STATS_ON)
     std::vector<std::pair<void *, size_t>> v;
     v.emplace_back(eng->d_rec, (size_t)eng->prm.B * eng->prm.N * sizeof(uint32_t));  // the agents: their packed records
     v.emplace_back(eng->d_cnt, (size_t)eng->prm.B * 2 * sizeof(int32_t));            // steps, inactive, pending resets: the counter records
@@ -1293,8 +1323,9 @@ int rw_get_info(const rw_engine *eng, rw_info *out) {
     out->stagger_ticks = eng->stagger_ticks;
     out->pipe_envs_per_workgroup = eng->pipe_kernel ? eng->pipe_E : 0;
     out->pipe_workgroups = eng->pipe_kernel ? eng->pipe_grid : 0;
+    out->stats = eng->stats ? 1 : 0;
+    out->wave_priority = eng->prio ? 1 : 0;
     out->specialised = eng->specialised ? 1 : 0;
-    out->state_layout = 0;  // (the per-shelf position layout of round 2/3 is gone: with non-temporal observation stores the shadow wins at every batch size)
     out->build_kind = eng->build_kind;
     out->obs_stores_stream = p.nt_obs;
     out->jit = eng->jit_state;

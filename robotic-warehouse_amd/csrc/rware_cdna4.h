@@ -45,6 +45,8 @@ template <typename T>
 __device__ __forceinline__ const RW_GLOBAL char *as_bytes(const RW_GLOBAL T *p) { return (const RW_GLOBAL char *)p; }
 // HW_ID (hwreg 4): wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]; XCC_ID (hwreg 20): xcc[3:0]
 __device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(2); }  // ~128 cycles off the issue slots
+// wave_priority<P>(): s_setprio P — user priority of this wavefront for the SIMD's issue arbiter, 0 (the launch default) .. 3
+template <int P> __device__ __forceinline__ void wave_priority() { __builtin_amdgcn_s_setprio(P); }
 __device__ __forceinline__ uint32_t hw_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 4); }
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20); }
 // wave_any(v): true in every lane iff v holds in some active lane of the wavefront (one s_cmp on the ballot)

@@ -2,6 +2,11 @@
 // Compiled five times (see the Makefile); the exact-shape builds live in rware_capi.hip.
 #include <hip/hip_runtime.h>
 
+// The generic kernels carry the event-counter code (RW_STATS_ON; dead and compiled out of the exact-shape builds — rware_kernels.h):
+// an engine that is asked for counters runs on these, or on a run-time compiled exact-shape build made with the same switch.
+#ifndef RW_STATS_BUILD
+#define RW_STATS_BUILD 1
+#endif
 #include "rware_kernel_table.h"
 
 #ifndef RW_GENERIC_R
@@ -28,6 +33,10 @@ step_kernel_t RW_CAT(generic_r, RW_GENERIC_R)(bool rollout, bool wide, bool imag
     if (rollout) return wide ? pick<true, uint16_t>(image, msg) : pick<true, uint8_t>(image, msg);
     return wide ? pick<false, uint16_t>(image, msg) : pick<false, uint8_t>(image, msg);
 }
+
+#if RW_GENERIC_R == 1
+bool generic_has_stats() { return RW_STATS_BUILD != 0; }
+#endif
 
 }  // namespace rw_tab
 #undef RW_CAT

@@ -158,7 +158,7 @@ Names names_of(const Shape &s, const char *arch) {
     const char *cell = s.wide ? "uint16_t" : "uint8_t";
     snprintf(expr_step, sizeof expr_step, "rw::rware_step_kernel<%d, %s, %s, false, %d>", s.R, cell, static_cfg(s.nt), s.obs);
     snprintf(expr_roll, sizeof expr_roll, "rw::rware_step_kernel<%d, %s, %s, true, %d>", s.R, cell, static_cfg(0), s.obs);
-    const std::string opts_key = std::string(arch) + " -O3 -std=c++17 -mllvm -amdgpu-kernarg-preload-count=16";
+    const std::string opts_key = std::string(arch) + " -O3 -std=c++17 -mllvm -amdgpu-kernarg-preload-count=16" + (s.stats ? " -DRW_STATS_BUILD=1" : "");
     const std::string key = std::string(kJitSourcesSha) + "|" + opts_key + "|" + expr_step + "|" + expr_roll;
     char name[64];
     snprintf(name, sizeof name, "%016llx%016llx.hsaco", (unsigned long long)fnv1a(key, 0xcbf29ce484222325ULL),
@@ -203,8 +203,8 @@ bool compile(const Shape &s, const char *arch, Result *out) {
     }
     bool ok = r->AddNameExpression(prog, expr_step) == 0 && r->AddNameExpression(prog, expr_roll) == 0;
     const std::string arch_opt = std::string("--offload-arch=") + arch;
-    const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-mllvm", "-amdgpu-kernarg-preload-count=16"};
-    ok = ok && r->CompileProgram(prog, 5, opts) == 0;
+    const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-DRW_STATS_BUILD=1"};
+    ok = ok && r->CompileProgram(prog, s.stats ? 6 : 5, opts) == 0;
     size_t ln = 0;
     if (r->GetProgramLogSize(prog, &ln) == 0 && ln > 1) {
         std::string log(ln, '\0');

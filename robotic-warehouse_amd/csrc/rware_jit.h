@@ -23,6 +23,7 @@ struct Shape {
     uint32_t layers;                 // 4 bits per layer id, first layer lowest
     int directional;                 // IMAGE: image_observation_directional (else -1)
     int nt;                          // per-step kernel: 1 = non-temporal observation stores
+    int stats;                       // 1: compiled with RW_STATS_BUILD — the event counters of RW_STATS_ON (rware_kernels.h)
 };
 
 struct Result {

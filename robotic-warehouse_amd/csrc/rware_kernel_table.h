@@ -14,5 +14,9 @@ step_kernel_t generic_r2(bool rollout, bool wide, bool image, bool msg);
 step_kernel_t generic_r3(bool rollout, bool wide, bool image, bool msg);
 step_kernel_t generic_r4(bool rollout, bool wide, bool image, bool msg);
 step_kernel_t generic_r5(bool rollout, bool wide, bool image, bool msg);
+// were the generic / the ahead-of-time specialised kernels compiled with the event-counter code (RW_STATS_BUILD, rware_kernels.h)?
+// The library's own build: generic yes, specialised no (the host-thread emulation build of the tests: both).
+bool generic_has_stats();
+bool static_has_stats();
 
 }  // namespace rw_tab

@@ -72,6 +72,10 @@
 // RW_INLINE: a lambda whose body goes into its caller before any optimisation runs (the pipelined flow's helpers)
 #define RW_INLINE __attribute__((always_inline))
 
+#ifndef RW_STATS_BUILD
+#define RW_STATS_BUILD 0
+#endif
+
 namespace rw {
 
 // (the two type-level helpers the kernel needs, spelled out: the run-time compiler — hipRTC, rware_jit.cpp — has no <type_traits>)
@@ -138,6 +142,10 @@ struct Params {
     // (RW_BUF_FINAL_OBS, [B][N][L] — the image for the IMAGE types); nullptr otherwise
     float *final_obs;
     float *final_features;  // ... and its IMAGE_DICT feature vectors (RW_BUF_FINAL_FEATURES, [B][N][6]), or nullptr
+    // event counters (RW_STATS_ON; launches carry OP_FLAG_STATS): per env, running totals since rw_create — never reset by the engine.
+    // The reference keeps none (`info` is {}, rware/warehouse.py:746-747); read only behind the flag, nullptr otherwise
+    int32_t *stat_deliveries;    // [B] shelf deliveries (:907-927)
+    int32_t *stat_failed_moves;  // [B] FORWARD requests the step turned into NOOP: shelf-block cancel (:843-846) + failed movers (:871-876)
 };
 
 // What changes from launch to launch.  The kernel-argument segment is rewritten by the host for every
@@ -172,7 +180,9 @@ struct LaunchArgs {
 #define RW_LAUNCH_ARGS(la)                                                                                  \
     (la).actions, (la).op, (la).n_steps, (la).obs, (la).rewards, (la).terminated, (la).reset_mask,         \
         (la).timeline, (la).act_stride, (la).obs_stride, (la).rew_stride, (la).term_stride
-enum : int { OP_FLAG_TIMELINE = 0x100 };
+enum : int { OP_FLAG_TIMELINE = 0x100,
+             OP_FLAG_STATS = 0x200,    // count deliveries / failed moves into Params::stat_* (see count_events, rware_phase_goals.h)
+             OP_FLAG_PRIO = 0x400 };   // raise the wavefronts' priority until the agent phases are done (see the kernel's prologue)
 enum : int { TL_START = 0, TL_ZEROED, TL_DMA_ISSUED, TL_ENV_LOADED, TL_LOADED, TL_AGENTS, TL_RESET, TL_OBS_BITS,
              TL_OBS_STORED, TL_END,  // 10, 11: where the wavefronts ran
              TL_AG_RECORD = 12, TL_AG_CELLS, TL_AG_WINNERS, TL_AG_APPLIED, TL_AG_GOALS,  // inside the agent phases (wavefront 0)
@@ -194,6 +204,8 @@ struct LdsLayout {
 };
 enum : int { ENVI_STEPS = 0, ENVI_INACTIVE = 1, ENVI_RESET = 2, ENVI_DONE = 3, ENVI_SKIP = 4,
              ENVI_QDIRTY = 5,  // a request was replaced since the chunk was staged: the queue has to be written back
+             ENVI_NDELIV = 6,  // deliveries of the env's latest step — written by goals_and_termination only, i.e. valid iff that step
+                               // delivered (ENVI_INACTIVE == 0 behind a step); read by count_events
              ENVI_W = 8 };
 
 RW_HD int rw_up4(int x) { return (x + 3) & ~3; }
@@ -447,6 +459,14 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
                         la_act_stride, la_obs_stride, la_rew_stride, la_term_stride};
     const int op = la.op & 0xff;
     const bool tl_on = (la.op & OP_FLAG_TIMELINE) != 0;  // the flag is preloaded; la.timeline itself is fetched only when set
+    // Event counters: compiled in only where RW_STATS_BUILD is set — the generic kernels and the run-time compiled builds rw_create asks for
+    // when the caller wants counters (rware_jit.h).  The ahead-of-time exact-shape builds do not carry the code: even switched off and out
+    // of line it moved 43 of them over a register step (BASELINE config 5's kernel 62 -> 66 VGPRs, 8 -> 7 workgroups per CU; round 6).
+#if RW_STATS_BUILD
+    const bool stats_on = (la.op & OP_FLAG_STATS) != 0;  // (the flag is preloaded: a scalar test where the counters are off)
+#else
+    constexpr bool stats_on = false;
+#endif
     // Start stagger (launches of two or more rounds of workgroups; rw_create decides, bits 16.. of `op`): the workgroups of a launch
     // start together and stay in lock-step — all stage in, all run their agent phases, all store — so the memory system and the
     // SIMDs take turns idling, and the second round inherits the rhythm.  The k-th of the first eight workgroups a CU receives
@@ -463,6 +483,15 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             }
         }
     }
+    // Wavefront priority (round 6; rw_create decides, OP_FLAG_PRIO): everything in front of the first observation store — stage-in, agent
+    // phases — is a chain of dependent steps on one or two wavefronts per workgroup, the stores behind it are bandwidth; a CU holds up to
+    // eight workgroups in different places of that sequence.  The chain runs at priority 3 (s_setprio: the SIMD's issue arbiter picks
+    // ready wavefronts of higher priority first) and drops back to 0 behind the agent-phase barrier, so a wavefront on the chain is
+    // not queued behind the gather / expansion work of its neighbours: small-4ag x 32768 10.75 -> 9.06 us per step, medium-6ag-hard
+    // x 65536 24.4 -> 22.7, x 8192 6.24 -> 5.94, small-12ag 15.1 -> 14.6 (profiles/r06_prio_*.txt; the start-staggered 13 .. 16-agent
+    // launches lose with it and are left alone).  A hint to the scheduler, never a different result.
+    const bool prio_on = !kRollout && !kPipe && (la.op & OP_FLAG_PRIO) != 0;
+    if (prio_on) wave_priority<3>();
     // observation row length: a compile-time constant except with communication bits
     static_assert(kMsg || Cfg::kM == 0, "communication bits need a _MSG observation kind");
     const int M = kMsg ? (Cfg::kM ? Cfg::kM : p.msg_bits) : 0, AM = 1 + M, CW = 7 + M;
@@ -664,6 +693,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     }
     RW_PIPE_MARK_PREV(4, 0, TL_PIPE_FIRST_AG);  // (the agent phases of this chunk ran one stage ago: slot 4 of chunk it - 1)
     lds_barrier();  // (PIPE: barrier A)
+    if (prio_on) wave_priority<0>();
     RW_MARK(TL_AGENTS);
     RW_PIPE_MARK(0, 0);
     // PIPE: the stage-in wavefront 3 issued one stage ago (chunk it + 1, for the agent phases that start behind barrier B) is waited

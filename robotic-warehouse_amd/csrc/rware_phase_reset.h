@@ -4,6 +4,10 @@
 // instructions per kernel, two 13/14-agent builds over a register cliff).  Splitting the text keeps every build's ISA.
     // ---------------------------------------------------------------- RS: reset flagged envs (:757-802)
     if (RW_RARE(s_misc[0] != 0)) {  // workgroup-uniform; rare
+        if (RW_RARE(stats_on) && k_autoreset == AR_SAME_STEP) {  // the terminating step's events, while the arrays still hold that step
+            count_events(true, tid, T);
+            lds_barrier();
+        }
         if constexpr (!kImage) {
             // SAME_STEP autoreset: the observation of the terminating step itself — what Warehouse.step returns together with
             // done = True (rware/warehouse.py:929-946, _make_obs :722-744) — goes to RW_BUF_FINAL_OBS before the env is reset

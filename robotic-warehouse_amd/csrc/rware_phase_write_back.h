@@ -34,6 +34,7 @@
                         for (int k = 0; k < Q; ++k) q_queue[(size_t)ge * Q + k] = s_queue[e * Q + k];
                 }
         } else if (role == 1) {  // agent records and rewards: the chunk is contiguous in both [B][N] arrays
+            if (RW_RARE(stats_on)) count_events(false, lane, 64);
             if (op == OP_STEP)
                 for (int i = lane; i < nea; i += 64) {
                     if (s_envi[rw_div18(i, mN) * ENVI_W + ENVI_RESET]) continue;

@@ -14,6 +14,9 @@ const StaticEntry *RW_CAT(static_group_, RW_STATIC_GROUP)(int *n) {
     *n = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
     return kEntries;
 }
+#if RW_STATIC_GROUP == 0
+bool static_has_stats() { return RW_STATS_BUILD != 0; }  // (the same for every group: one set of compiler flags builds them all)
+#endif
 }  // namespace rw_tab
 #undef RW_CAT
 #undef RW_CAT2

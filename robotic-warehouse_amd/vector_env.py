@@ -147,7 +147,7 @@ class WarehouseVecEnv(_VectorEnvBase):
                  normalised_coordinates: bool = False, render_mode=None, *,
                  autoreset_mode: str = "next_step", devices=None, output: str = "numpy",
                  envs_per_workgroup: int = 0, threads_per_workgroup: int = 0, library: str | None = None,
-                 obs_stores: str | None = None, jit=None, pipe=None):
+                 obs_stores: str | None = None, jit=None, pipe=None, stats: bool = False):
         if not 0 <= int(msg_bits) <= 16:
             raise ValueError("msg_bits must be in 0..16")
         self.msg_bits = int(msg_bits)
@@ -229,7 +229,9 @@ class WarehouseVecEnv(_VectorEnvBase):
                 jit=jit,
                 # None / "auto": the engine's measured rule; False / "off", True / "on": the chunk-pipelined persistent per-step
                 # kernel never / wherever the library has a build for the shape (rw_stream_flags RW_PIPE_*)
-                pipe=pipe))
+                pipe=pipe,
+                # True: the engine keeps per-env event counters (RW_STATS_ON) — see event_counters()
+                stats=stats))
         self._bounds = [b for b in self._bounds if b[1] > b[0]]
         self.shard_bounds = list(self._bounds)  # env range [lo, hi) of every engine / device, in order
         self.devices = devices[: len(self.engines)]
@@ -626,6 +628,21 @@ class WarehouseVecEnv(_VectorEnvBase):
             self._tviews[d] = v
         return v
 
+    def event_counters(self):
+        """{"deliveries": (B,), "failed_moves": (B,)} int32 — running totals per env since construction (`stats=True` only; the
+        engine never resets them: an episode's figure is the difference between two reads).  deliveries: requested shelves brought
+        to a goal (rware/warehouse.py:907-917); failed_moves: FORWARD requests the step turned into NOOP — the shelf-block cancel
+        (:836-846) and the movers that lose the collision resolution (:871-876).  The reference keeps no such figures: its `info`
+        is {} (:746-747), and so is this env's.  output="torch": zero-copy device tensors (a tuple per device when sharded)."""
+        if not self.engines[0].stats:
+            raise RuntimeError("event counters are off: construct the env with stats=True")
+        names = {"deliveries": "stat_deliveries", "failed_moves": "stat_failed_moves"}
+        if self.output == "torch":
+            per_dev = [{k: self._torch.as_tensor(eng.device_array(n), device=f"cuda:{dev}") for k, n in names.items()}
+                       for eng, dev in zip(self.engines, self.devices)]
+            return per_dev[0] if len(per_dev) == 1 else tuple(per_dev)
+        return {k: self._gather(n) for k, n in names.items()}
+
     def device_tensor(self, name):
         """Zero-copy torch view of any engine buffer (single-device envs)."""
         import torch
@@ -642,7 +659,7 @@ class WarehouseVecEnv(_VectorEnvBase):
     def set_state(self, refresh_obs: bool = True, **fields):
         # `grid` first: later coordinate writes then re-mark the derived int32 view stale (layer 0 follows agent_x / agent_y)
         for k, v in sorted(fields.items(), key=lambda kv: kv[0] != "grid"):
-            if k not in STATE_FIELDS and k not in ("need_reset", "agent_msg"):
+            if k not in STATE_FIELDS and k not in ("need_reset", "agent_msg", "stat_deliveries", "stat_failed_moves"):
                 raise KeyError(k)
             v = np.asarray(v)
             for eng, (lo, hi) in zip(self.engines, self._bounds):

@@ -14,6 +14,7 @@ inline void lds_dma_b32(const void *g_lane, void *lds_wave_base) {
 template <typename T> inline T *as_global(T *p) { return p; }
 template <typename T> inline const char *as_bytes(const T *p) { return (const char *)p; }
 inline void nap() {}
+template <int P> inline void wave_priority() {}  // (a scheduling hint: no host meaning)
 inline uint32_t hw_id() { return 0; }
 inline uint32_t xcc_id() { return 0; }
 extern int emu_wave_any_flag[16];

@@ -941,6 +941,40 @@ def test_start_stagger_is_a_create_time_rule_and_does_not_change_results(monkeyp
     env.close()
 
 
+def test_wave_priority_is_a_create_time_rule_and_does_not_change_results(monkeypatch):
+    """rw_info.wave_priority (round 6): per-step launches raise their wavefronts' priority up to the agent-phase barrier — on by rw_create's
+    rule except for 13 .. 16 agents at sensor_range 1 and for steps with 200 MB of observations and more; RWARE_PRIO moves it.  A
+    scheduling hint (nothing on the host threads of this build): the rule, the launch flag's way through every launch form, same results."""
+    def wp(env_id, B, **extra):
+        env = rware_amd.WarehouseVecEnv(B, library=LIB, **dict(rware_amd.env_kwargs(env_id), **extra))
+        v = env.engines[0].info.wave_priority
+        env.close()
+        return v
+    assert wp("rware-small-4ag-v1", 64) == 1 and wp("rware-small-12ag-v1", 8) == 1 and wp("rware-small-17ag-v1", 8) == 1
+    assert wp("rware-medium-13ag-v1", 8) == 0 and wp("rware-large-16ag-v1", 8) == 0
+    assert wp("rware-large-16ag-v1", 8, sensor_range=2) == 1       # BASELINE config 5's shape
+    monkeypatch.setenv("RWARE_PRIO", "0")
+    assert wp("rware-small-4ag-v1", 64) == 0
+    monkeypatch.setenv("RWARE_PRIO", "1")
+    assert wp("rware-medium-13ag-v1", 8) == 1
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    kw["max_steps"] = 9
+    on = rware_amd.WarehouseVecEnv(32, library=LIB, **kw)
+    monkeypatch.setenv("RWARE_PRIO", "0")
+    off = rware_amd.WarehouseVecEnv(32, library=LIB, **kw)
+    assert (on.engines[0].info.wave_priority, off.engines[0].info.wave_priority) == (1, 0)
+    assert np.array_equal(on.reset(seed=2)[0], off.reset(seed=2)[0])
+    acts = np.random.default_rng(8).integers(0, 5, size=(24, 32, 4), dtype=np.int32)
+    for t in range(12):
+        a, b = on.step(acts[t]), off.step(acts[t])
+        assert all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4])), t
+    ra, rb = on.rollout(acts[12:]), off.rollout(acts[12:])       # (fused rollouts never carry the flag)
+    assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+    sa, sb = on.get_state(), off.get_state()
+    assert all(np.array_equal(sa[k], sb[k]) for k in sa)
+    on.close(); off.close()
+
+
 @pytest.mark.parametrize("env_id,extra,B,mode", [
     ("rware-small-4ag-v1", {"max_steps": 25}, 64, "next_step"),                     # 4 chunks on the emulation's 2 persistent workgroups
     ("rware-small-4ag-v1", {"max_steps": 25}, 48, "same_step"),                     # ragged: 2 + 1 chunks; terminal observations

@@ -1263,6 +1263,37 @@ def test_start_stagger_rule_for_13_to_16_agents_matches_oracle():
         env.close()
 
 
+def test_wave_priority_rule_and_results(monkeypatch):
+    """Round 6: rw_info.wave_priority — the per-step launches run their dependent chain (stage-in, agent phases) at wavefront priority 3
+    and drop to 0 behind the agent-phase barrier.  The rule as rw_info shows it; with the priority forced on and off the same
+    observations, rewards, flags and state on the shapes of both families (a scheduling hint, never a different result)."""
+    for env_id, extra, B, want in (("rware-small-4ag-v1", {}, 16384, 1), ("rware-tiny-2ag-v1", {}, 4096, 1), ("rware-medium-6ag-hard-v1", {}, 8192, 1),
+                                   ("rware-large-16ag-v1", {"sensor_range": 2}, 16384, 1), ("rware-small-12ag-v1", {}, 16384, 1),
+                                   ("rware-medium-13ag-v1", {}, 16384, 0), ("rware-large-16ag-v1", {}, 16384, 0), ("rware-small-17ag-v1", {}, 16384, 1),
+                                   ("rware-small-4ag-v1", {}, 131072, 1), ("rware-small-4ag-v1", {}, 262144, 0), ("rware-small-12ag-v1", {}, 65536, 0)):
+        env = rware_amd.WarehouseVecEnv(B, **dict(rware_amd.env_kwargs(env_id), **extra))
+        assert env.engines[0].info.wave_priority == want, (env_id, extra, B)
+        env.close()
+    for env_id, extra, B in (("rware-small-4ag-v1", {}, 32768), ("rware-medium-13ag-v1", {}, 16384), ("rware-large-16ag-v1", {"sensor_range": 2}, 8192)):
+        kw = dict(rware_amd.env_kwargs(env_id), max_steps=17, **extra)
+        monkeypatch.setenv("RWARE_HOOKS", "1")
+        monkeypatch.setenv("RWARE_PRIO", "1")
+        a = rware_amd.WarehouseVecEnv(B, **kw)
+        monkeypatch.setenv("RWARE_PRIO", "0")
+        b = rware_amd.WarehouseVecEnv(B, **kw)
+        monkeypatch.delenv("RWARE_PRIO")
+        assert (a.engines[0].info.wave_priority, b.engines[0].info.wave_priority) == (1, 0)
+        a.reset(seed=4); b.reset(seed=4)
+        rng = np.random.default_rng(5)
+        for t in range(40):
+            act = rng.choice(5, size=(B, kw["n_agents"]), p=[0.1, 0.55, 0.1, 0.1, 0.15]).astype(np.int32)
+            ra, rb = a.step(act), b.step(act)
+            assert all(np.array_equal(x, y) for x, y in zip(ra[:4], rb[:4])), (env_id, t)
+        sa, sb = a.get_state(), b.get_state()
+        assert all(np.array_equal(sa[k], sb[k]) for k in sa), env_id
+        a.close(); b.close()
+
+
 def test_two_pipelines_on_one_device_match_the_single_engine():
     """Double-buffered sampling (bench.py's `two_pipelines`): the batch as two engines on one device, own streams, stepped
     CONCURRENTLY by one launcher thread each, against one engine over the whole batch — same observations and state."""

@@ -27,8 +27,11 @@ def test_live_rollout(env_id, extra):
     pol = np.random.default_rng(7)
     for t in range(250):
         a = rr.scripted_actions(env, pol) if t % 2 else list(pol.choice(5, size=env.n_agents, p=[.1, .6, .1, .1, .1]))
-        obs, r, d, _, _ = rr.ref_step(env, a)
+        (obs, r, d, _, _), n_deliv, n_failed = rr.ref_step_events(env, a)
+        c0 = int(orc.stat_deliveries[0]), int(orc.stat_failed_moves[0])
         r2, d2 = orc.step(np.array(a)[None])
+        # the event counters (RW_BUF_STAT_*): this step's deliveries and failed moves as the reference's own objects show them
+        assert (int(orc.stat_deliveries[0]) - c0[0], int(orc.stat_failed_moves[0]) - c0[1]) == (n_deliv, n_failed), t
         snap, st = rr.snapshot(env), orc.get_state()
         for k, v in snap.items():
             assert np.array_equal(np.asarray(v).reshape(-1), st[k][0].reshape(-1)), (k, t)
@@ -295,8 +298,10 @@ def test_oracle_matches_the_live_reference_on_random_shapes(case):
             o2, r2, d2 = orc.step_autoreset(np.array(a)[None], "next_step")
             r, d = [0.0] * env.n_agents, False
         else:
-            obs, r, d, _, _ = rr.ref_step(env, a)
+            (obs, r, d, _, _), n_deliv, n_failed = rr.ref_step_events(env, a)
+            c0 = int(orc.stat_deliveries[0]), int(orc.stat_failed_moves[0])
             o2, r2, d2 = orc.step_autoreset(np.array(a)[None], "next_step")
+            assert (int(orc.stat_deliveries[0]) - c0[0], int(orc.stat_failed_moves[0]) - c0[1]) == (n_deliv, n_failed), (t, kw)
         snap, st = rr.snapshot(env), orc.get_state()
         for k, v in snap.items():
             assert np.array_equal(np.asarray(v).reshape(-1), st[k][0].reshape(-1)), (k, t, kw)
