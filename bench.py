@@ -294,6 +294,7 @@ def hbm_regime_leg(torch, rware_amd, local_rank, env_id, sha):
             "store_only_kernel_ms_per_launch": floor_ms, "frac_of_store_only_kernel": floor_fraction(floor_ms, k_ms),
             "envs_per_workgroup": int(info.envs_per_workgroup), "kernel_specialised": bool(info.specialised),
             "start_stagger_ns_per_slot": 10 * int(info.stagger_ticks),   # launches of two or more rounds of workgroups (rw_info.stagger_ticks)
+            "wave_priority": int(info.wave_priority),   # 1: the chain in front of the first store runs at raised wavefront priority (rw_info.wave_priority)
             "observation_stores": "non-temporal" if int(info.obs_stores_stream) else "cached",
         }
         if note:
@@ -697,6 +698,7 @@ def main():
                                   if args.submit == "graph" else "one Python/ctypes call per step"),
                 "envs_per_workgroup": int(info.envs_per_workgroup), "threads_per_workgroup": int(info.threads_per_workgroup),
                 "start_stagger_ns_per_slot": 10 * int(info.stagger_ticks),   # 0: the launch is resident at once (no stagger)
+                "wave_priority": int(info.wave_priority),
                 "kernel_specialised": bool(info.specialised), "kernel_build_kind": int(info.build_kind),
                 "observation_stores": "non-temporal (the engine's default rule for this shape; rw_stream_flags / obs_stores= overrides)"
                                       if int(info.obs_stores_stream) else "cached",

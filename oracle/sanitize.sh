@@ -7,7 +7,7 @@
 #     16 agents in crowded warehouses, a chunk-pipelined (PIPE=1) build walking several chunks per workgroup, and rw_multi's launcher
 #     threads: 8 engines, >= 1000 rounds, create / destroy cycles (the sleep / wake handshake);
 #  2b. the WHOLE emulation library under AddressSanitizer + UBSan (heap redzones around every device buffer, the LDS behind a launch's dynamic
-#     shared memory poisoned): the emulated engine tests and the reference's KATs;
+#     shared memory poisoned): the emulated engine tests, the event counters and the reference's KATs;
 #  3. rware_jit.cpp under AddressSanitizer + UBSan: no hipRTC library, a library without the entry points, corrupt / truncated / foreign
 #     cache files, a cache directory that is not private.
 set -u
@@ -17,10 +17,10 @@ CSRC=robotic-warehouse_amd/csrc
 echo "== 1. oracle/rware_oracle.c under -fsanitize=address,undefined: golden traces + RNG vs numpy + live reference check"
 gcc -O1 -g -std=c11 -shared -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -o $OUT/librware_oracle_asan.so oracle/rware_oracle.c || exit 1
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \
-  RWARE_ORACLE_SO=$OUT/librware_oracle_asan.so timeout 2400 python -m pytest tests/test_oracle_golden.py tests/test_oracle_rng_numpy.py tests/test_oracle_vs_reference.py -q -x -p no:cacheprovider 2>&1 | tail -5
+  RWARE_ORACLE_SO=$OUT/librware_oracle_asan.so timeout 2400 python -m pytest tests/test_oracle_golden.py tests/test_oracle_rng_numpy.py tests/test_oracle_vs_reference.py tests/test_event_counters.py -k "not emulated" -m "not gpu" -q -x -p no:cacheprovider 2>&1 | tail -5
 
 echo "== 2. tests/emu (the engine's kernels + C-ABI host code on host threads) under -fsanitize=thread"
-FLAGS="-DRW_NO_JIT -DRW_WITH_PIPE=1 -O1 -g -std=c++17 -fPIC -pthread -Itests/emu -Wno-unknown-pragmas -fsanitize=thread"
+FLAGS="-DRW_NO_JIT -DRW_WITH_PIPE=1 -DRW_STATS_BUILD=1 -O1 -g -std=c++17 -fPIC -pthread -Itests/emu -Wno-unknown-pragmas -fsanitize=thread"
 BUILT_GROUPS="0 10 16 17 18"   # BASELINE shapes | small 9..14 agents (kCell) | large 9..14, 15..19 agents (kCell) | the pipelined builds
 for r in 1 2; do g++ $FLAGS -DRW_GENERIC_R=$r -c -x c++ $CSRC/rware_generic.hip -o $OUT/g$r.o 2>/dev/null & done
 g++ $FLAGS -c -x c++ $CSRC/rware_capi.hip -o $OUT/capi.o 2>/dev/null &
@@ -52,7 +52,8 @@ from rware_oracle import OracleVecEnv
 LIB = "/tmp/rware_san/librware_emu_tsan.so"
 
 def against_oracle(label, B, steps, ctor, kw, seed=3, p=(.1, .55, .1, .1, .15), want=None):
-    env = rware_amd.WarehouseVecEnv(B, library=LIB, **ctor, **kw)
+    # (stats=True: the event counters — global atomics from the service wavefront's lanes — run in every case and are checked at the end)
+    env = rware_amd.WarehouseVecEnv(B, library=LIB, stats=True, **ctor, **kw)
     info = env.engines[0].info
     if want:
         want(info)
@@ -66,6 +67,8 @@ def against_oracle(label, B, steps, ctor, kw, seed=3, p=(.1, .55, .1, .1, .15), 
         assert np.array_equal(o, o2) and np.array_equal(r, r2) and np.array_equal(d, d2.astype(bool)), (label, t)
     st, so = env.get_state(), orc.get_state()
     assert all(np.array_equal(st[k], so[k]) for k in so), label
+    c = env.event_counters()
+    assert np.array_equal(c["deliveries"], orc.stat_deliveries) and np.array_equal(c["failed_moves"], orc.stat_failed_moves), label
     env.close()
     print(f"tsan-run {label}: {steps} steps bit-exact (build kind {int(info.build_kind)}, E {int(info.envs_per_workgroup)}, pipe workgroups {int(info.pipe_workgroups)})", flush=True)
 
@@ -123,7 +126,7 @@ echo "(a ThreadSanitizer WARNING line above = a reported race; none = clean)"
 
 echo "== 2b. the whole emulation library (every table group, all generic kernels, the C-ABI host code) under -fsanitize=address,undefined: the emulated engine tests + the reference's KATs"
 echo "   (device buffers are heap blocks with redzones; the LDS behind each launch's dynamic shared memory is poisoned: an out-of-bounds index in a kernel or in the host code faults)"
-AFLAGS="-DRW_NO_JIT -DRW_WITH_PIPE=1 -O1 -g -std=c++17 -fPIC -pthread -Itests/emu -Wno-unknown-pragmas -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer"
+AFLAGS="-DRW_NO_JIT -DRW_WITH_PIPE=1 -DRW_STATS_BUILD=1 -O1 -g -std=c++17 -fPIC -pthread -Itests/emu -Wno-unknown-pragmas -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer"
 A=$OUT/asan; mkdir -p $A
 ( for g in $(seq 0 18); do echo "g++ $AFLAGS -DRW_STATIC_GROUP=$g -c -x c++ $CSRC/rware_static.hip -o $A/s$g.o"; done
   for r in 1 2 3 4 5; do echo "g++ $AFLAGS -DRW_GENERIC_R=$r -c -x c++ $CSRC/rware_generic.hip -o $A/g$r.o"; done
@@ -131,7 +134,7 @@ A=$OUT/asan; mkdir -p $A
   echo "g++ $AFLAGS -c tests/emu/emu_globals.cpp -o $A/glob.o" ) | xargs -P 8 -I{} sh -c "{} 2>/dev/null"
 g++ -shared -pthread -fsanitize=address,undefined -o $A/librware_emu_asan.so $A/*.o || exit 1
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:allow_user_poisoning=1 UBSAN_OPTIONS=print_stacktrace=1 RWARE_ALLOW_STALE_PMC=1 \
-  RWARE_EMU_LIB=$A/librware_emu_asan.so timeout 5400 python -m pytest tests/test_engine_emulated.py tests/test_reference_kats.py tests/test_gymnasium_boundary.py -q -x -p no:cacheprovider -n 6 \
+  RWARE_EMU_LIB=$A/librware_emu_asan.so timeout 5400 python -m pytest tests/test_engine_emulated.py tests/test_reference_kats.py tests/test_gymnasium_boundary.py tests/test_event_counters.py -m "not gpu" -q -x -p no:cacheprovider -n 6 \
   --deselect tests/test_engine_emulated.py::test_rw_multi_launcher_threads_overlap_the_enqueues 2>&1 | tail -6
 echo "   (deselected: the one wall-clock comparison of the suite — launcher threads against the in-call loop — which a sanitizer build distorts)"
 

@@ -71,6 +71,6 @@ for spec in sys.argv[1:]:
     i = eng.info
     eb = int(i.engine_bytes_per_env_step) * B
     geom = f"pipe E {int(i.pipe_envs_per_workgroup):2d} x {int(i.pipe_workgroups):4d} wgs" if int(i.pipe_workgroups) else f"E {int(i.envs_per_workgroup):2d}" + (f" T {int(i.threads_per_workgroup)}" if int(i.threads_per_workgroup) != 256 else "")
-    print(f"{spec:44s} {KIND[int(i.build_kind)] + (' (jit)' if int(i.jit) > 0 else ''):18s} {geom} {'nt' if int(i.obs_stores_stream) else 'cached':6s} "
+    print(f"{spec:44s} {KIND[int(i.build_kind)] + (' (jit)' if int(i.jit) > 0 else ''):18s} {geom} {'nt' if int(i.obs_stores_stream) else 'cached':6s} {'prio' if int(i.wave_priority) else '    '} "
           f"{best:8.3f} us/step {B * N / best / 1e3:7.2f} G a-s/s  engine {eb / 1e6:7.1f} MB -> {eb / best / 1e6:5.2f} TB/s = {eb / best / 8e6:4.2f} of peak", flush=True)
     env.close()
