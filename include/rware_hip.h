@@ -314,11 +314,13 @@ typedef struct rw_info {
     int32_t envs_per_workgroup, threads_per_workgroup, n_workgroups, lds_bytes;
     int32_t device_id, compute_units;
     int32_t specialised;  /* 1: a kernel build with this task's shapes folded in at compile time is in use */
-    int32_t wave_priority; /* 1: the per-step launches raise their wavefronts' priority (s_setprio 3) from the start of the kernel to
+    int32_t wave_priority; /* bit 0: the per-step launches raise their wavefronts' priority (s_setprio 3) from the start of the kernel to
                              the barrier behind the agent phases, so that the dependent chain in front of the first observation store is
-                             not queued behind the neighbours' store phase on the same CU.  rw_create's measured rule: on, except 13 .. 16
-                             agents at sensor_range 1 and batches far past the Infinity Cache (A/B runs: RWARE_PRIO=0|1 with RWARE_HOOKS=1).
-                             A scheduling hint, never a different result.  (The slot was `state_layout`, 0 since round 3.) */
+                             not queued behind the neighbours' store phase on the same CU; bit 1: the fused rollouts do (every step of the
+                             launch).  rw_create's measured rule: on while a step's observations stay under 200 MB (past that nothing moves),
+                             the per-step launches of 13 .. 16 agents at sensor_range 1 excepted (A/B runs: RWARE_PRIO=0|1,
+                             RWARE_PRIO_ROLLOUT=0|1 with RWARE_HOOKS=1).  A scheduling hint, never a different result.  (The slot was
+                             `state_layout`, 0 since round 3.) */
     int32_t build_kind;   /* which build of the step kernel runs: 0 generic (every shape at run time), 1 exact-shape, 2 agent-count-
                              static (shapes + agent count folded in, request-queue length at run time), 3 size-static (grid folded in,
                              agent count and queue length at run time).  (Occupies what was alignment padding: same struct size.) */

@@ -47,6 +47,7 @@ struct rw_engine {
     int S = 0, L = 0, OW = 0;
     int E = 0, T = 0, n_wg = 0;
     int stagger_ticks = 0, stagger_shift = 0;  // start stagger of a CU's first eight workgroups (multi-round launches: see the kernel's prologue)
+    bool prio_rollout = false; // ... the fused rollouts (every step of the launch raises it again)
     bool prio = false;         // per-step launches carry OP_FLAG_PRIO: raised wavefront priority up to the agent-phase barrier (rw_info::wave_priority)
     size_t lds_bytes = 0;
     hipStream_t stream = nullptr;
@@ -150,7 +151,7 @@ int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false, hipE
     const bool pipe = eng->pipe_kernel && op == rw::OP_STEP && !rollout;  // (persistent workgroups: no start stagger)
     if (!pipe) la.op |= (eng->stagger_ticks & 0xff) << 16 | (eng->stagger_shift & 0xf) << 24;
     if (eng->stats) la.op |= rw::OP_FLAG_STATS;
-    if (eng->prio && !rollout) la.op |= rw::OP_FLAG_PRIO;
+    if (rollout ? eng->prio_rollout : eng->prio) la.op |= rw::OP_FLAG_PRIO;
     if (op != rw::OP_OBS) eng->grid_stale = eng->agents_stale = eng->counters_stale = true;  // the kernels keep the shadow and the packed agent records current, not the int32 views
     if (!eng->own_stream && !eng->captured) {  // (a stream of the caller's may be capturing; the engine's own stream never is)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -660,9 +661,16 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // 16384 16.3 -> 17.7 us, small-15ag 19.3 -> 20.0, small-14ag x 65536 48.5 -> 52.2) — and except steps whose observations approach
         // the Infinity Cache size (200 MB of them and more: small-12ag x 65536 42.3 -> 42.9, small-19ag x 65536 81.2 -> 83.0, small-4ag x
         // 262144 58.9 -> 59.6), which do not move or lose a per cent or two.
-        eng->prio = !(R == 1 && N >= 13 && N <= 16) && (double)B * N * eng->L * 4 <= 200e6;
-        const char *pr = rw_hook("RWARE_PRIO");  // (A/B and test hook: 0 = off, 1 = on whatever the shape)
+        // The fused rollouts (every step of the launch raises the priority again): they gain at every agent count — small-4ag 3.95 ->
+        // 3.72 us per step, medium-6ag-hard x 8192 4.20 -> 3.94, small-8ag 8.89 -> 8.33, medium-13ag 14.5 -> 13.85, large-16ag 21.75 -> 21.25
+        // (profiles/r06_prio_rollout.txt) — so only the size limit applies to them.
+        const bool fits = (double)B * N * eng->L * 4 <= 200e6;
+        eng->prio = fits && !(R == 1 && N >= 13 && N <= 16);
+        eng->prio_rollout = fits;
+        const char *pr = rw_hook("RWARE_PRIO");  // (A/B and test hooks: 0 = off, 1 = on whatever the shape)
         if (pr && (pr[0] == '0' || pr[0] == '1')) eng->prio = pr[0] == '1';
+        const char *prr = rw_hook("RWARE_PRIO_ROLLOUT");
+        if (prr && (prr[0] == '0' || prr[0] == '1')) eng->prio_rollout = prr[0] == '1';
     }
 
     {
@@ -1324,7 +1332,7 @@ int rw_get_info(const rw_engine *eng, rw_info *out) {
     out->pipe_envs_per_workgroup = eng->pipe_kernel ? eng->pipe_E : 0;
     out->pipe_workgroups = eng->pipe_kernel ? eng->pipe_grid : 0;
     out->stats = eng->stats ? 1 : 0;
-    out->wave_priority = eng->prio ? 1 : 0;
+    out->wave_priority = (eng->prio ? 1 : 0) | (eng->prio_rollout ? 2 : 0);
     out->specialised = eng->specialised ? 1 : 0;
     out->build_kind = eng->build_kind;
     out->obs_stores_stream = p.nt_obs;

@@ -489,8 +489,9 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
     // ready wavefronts of higher priority first) and drops back to 0 behind the agent-phase barrier, so a wavefront on the chain is
     // not queued behind the gather / expansion work of its neighbours: small-4ag x 32768 10.75 -> 9.06 us per step, medium-6ag-hard
     // x 65536 24.4 -> 22.7, x 8192 6.24 -> 5.94, small-12ag 15.1 -> 14.6 (profiles/r06_prio_*.txt; the start-staggered 13 .. 16-agent
-    // launches lose with it and are left alone).  A hint to the scheduler, never a different result.
-    const bool prio_on = !kRollout && !kPipe && (la.op & OP_FLAG_PRIO) != 0;
+    // launches lose with it and are left alone; the fused rollouts raise it again at the top of every step: small-4ag 3.95 -> 3.72 us per
+    // step).  A hint to the scheduler, never a different result.
+    const bool prio_on = !kPipe && (la.op & OP_FLAG_PRIO) != 0;
     if (prio_on) wave_priority<3>();
     // observation row length: a compile-time constant except with communication bits
     static_assert(kMsg || Cfg::kM == 0, "communication bits need a _MSG observation kind");
@@ -674,6 +675,7 @@ rware_step_kernel(const Params *__restrict__ cp, RW_LAUNCH_PARAMS) {
             if (rs) atomicOr(&s_misc[0], 1);
         }
         lds_barrier();
+        if (kRollout && prio_on) wave_priority<3>();  // (fused rollout: the next step's chain)
     }
 #include "rware_phase_goals.h"
     // ---------------------------------------------------------------- AG: per-agent phases, wave-local

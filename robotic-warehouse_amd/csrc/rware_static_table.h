@@ -86,7 +86,11 @@ namespace {
 //   small-6ag   B = 8192 7.42 vs 8.42 | 16384  9.37 vs  9.85 | 32768 16.2 vs 14.5      medium-6ag-hard 7.25 vs 8.27 | 10.83 vs 9.84 | 17.2 vs 14.7
 //   tiny-6ag-hard        7.53 vs 8.48 |       11.25 vs  9.92 |       17.1 vs 14.4
 // -> 8 agents: up to 16384 envs; 6 agents: up to 8192 envs.
-#define RW_E8_MAXB(N) ((N) >= 8 ? 16384 : 8192)
+// Round 6, on today's kernel (non-temporal stores, the register budget of 8 wavefronts, wavefront priority; profiles/r06_geom3.txt, E = 8 vs 16):
+//   small-8ag   B = 32768 15.8 vs 17.5 | 65536 26.8 vs 30.1 | 131072 55.4 vs 56.5    tiny-8ag 16.0 vs 17.7 | 26.8 vs 30.6 | 54.8 vs 57.0
+//   medium-8ag  15.8 vs 17.5 | 28.3 vs 29.4 | 56.6 vs 57.0        6 agents stay: medium-6ag-hard 13.7 vs 13.6 | 23.0 vs 22.7 | 43.5 vs 45.1
+// -> 8 agents: 8 envs per workgroup at EVERY batch (the 16-env build stays for explicit geometries).
+#define RW_E8_MAXB(N) ((N) >= 8 ? 0 : 8192)
 #define RW_TINY_E8(N, Q) RW_STATIC(11, 10, N, Q, 32, 1, 8, 256, RW_E8_MAXB(N)), RW_TINY(N, Q)
 #define RW_SMALL_E8(N, Q) RW_STATIC(20, 10, N, Q, 80, 1, 8, 256, RW_E8_MAXB(N)), RW_SMALL(N, Q)
 #define RW_MEDIUM_E8(N, Q) RW_STATIC(20, 16, N, Q, 144, 1, 8, 256, RW_E8_MAXB(N)), RW_MEDIUM(N, Q)

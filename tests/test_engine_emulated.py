@@ -947,28 +947,31 @@ def test_wave_priority_is_a_create_time_rule_and_does_not_change_results(monkeyp
     scheduling hint (nothing on the host threads of this build): the rule, the launch flag's way through every launch form, same results."""
     def wp(env_id, B, **extra):
         env = rware_amd.WarehouseVecEnv(B, library=LIB, **dict(rware_amd.env_kwargs(env_id), **extra))
-        v = env.engines[0].info.wave_priority
+        v = env.engines[0].info.wave_priority   # bit 0: per-step launches, bit 1: fused rollouts
         env.close()
         return v
-    assert wp("rware-small-4ag-v1", 64) == 1 and wp("rware-small-12ag-v1", 8) == 1 and wp("rware-small-17ag-v1", 8) == 1
-    assert wp("rware-medium-13ag-v1", 8) == 0 and wp("rware-large-16ag-v1", 8) == 0
-    assert wp("rware-large-16ag-v1", 8, sensor_range=2) == 1       # BASELINE config 5's shape
+    assert wp("rware-small-4ag-v1", 64) == 3 and wp("rware-small-12ag-v1", 8) == 3 and wp("rware-small-17ag-v1", 8) == 3
+    assert wp("rware-medium-13ag-v1", 8) == 2 and wp("rware-large-16ag-v1", 8) == 2   # (their rollouts gain, their per-step launches lose)
+    assert wp("rware-large-16ag-v1", 8, sensor_range=2) == 3       # BASELINE config 5's shape
     monkeypatch.setenv("RWARE_PRIO", "0")
+    assert wp("rware-small-4ag-v1", 64) == 2
+    monkeypatch.setenv("RWARE_PRIO_ROLLOUT", "0")
     assert wp("rware-small-4ag-v1", 64) == 0
+    monkeypatch.delenv("RWARE_PRIO_ROLLOUT")
     monkeypatch.setenv("RWARE_PRIO", "1")
-    assert wp("rware-medium-13ag-v1", 8) == 1
+    assert wp("rware-medium-13ag-v1", 8) == 3
     kw = rware_amd.env_kwargs("rware-small-4ag-v1")
     kw["max_steps"] = 9
     on = rware_amd.WarehouseVecEnv(32, library=LIB, **kw)
     monkeypatch.setenv("RWARE_PRIO", "0")
     off = rware_amd.WarehouseVecEnv(32, library=LIB, **kw)
-    assert (on.engines[0].info.wave_priority, off.engines[0].info.wave_priority) == (1, 0)
+    assert (on.engines[0].info.wave_priority & 1, off.engines[0].info.wave_priority & 1) == (1, 0)
     assert np.array_equal(on.reset(seed=2)[0], off.reset(seed=2)[0])
     acts = np.random.default_rng(8).integers(0, 5, size=(24, 32, 4), dtype=np.int32)
     for t in range(12):
         a, b = on.step(acts[t]), off.step(acts[t])
         assert all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4])), t
-    ra, rb = on.rollout(acts[12:]), off.rollout(acts[12:])       # (fused rollouts never carry the flag)
+    ra, rb = on.rollout(acts[12:]), off.rollout(acts[12:])       # (fused rollouts carry the flag by a rule of their own: both do here)
     assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
     sa, sb = on.get_state(), off.get_state()
     assert all(np.array_equal(sa[k], sb[k]) for k in sa)

@@ -1272,23 +1272,27 @@ def test_wave_priority_rule_and_results(monkeypatch):
                                    ("rware-medium-13ag-v1", {}, 16384, 0), ("rware-large-16ag-v1", {}, 16384, 0), ("rware-small-17ag-v1", {}, 16384, 1),
                                    ("rware-small-4ag-v1", {}, 131072, 1), ("rware-small-4ag-v1", {}, 262144, 0), ("rware-small-12ag-v1", {}, 65536, 0)):
         env = rware_amd.WarehouseVecEnv(B, **dict(rware_amd.env_kwargs(env_id), **extra))
-        assert env.engines[0].info.wave_priority == want, (env_id, extra, B)
+        assert env.engines[0].info.wave_priority & 1 == want, (env_id, extra, B)          # bit 0: the per-step launches
+        assert (env.engines[0].info.wave_priority >> 1) == (0 if B * rware_amd.env_kwargs(env_id)["n_agents"] * env.obs_length * 4 > 200e6 else 1)   # bit 1: the fused rollouts
         env.close()
     for env_id, extra, B in (("rware-small-4ag-v1", {}, 32768), ("rware-medium-13ag-v1", {}, 16384), ("rware-large-16ag-v1", {"sensor_range": 2}, 8192)):
         kw = dict(rware_amd.env_kwargs(env_id), max_steps=17, **extra)
         monkeypatch.setenv("RWARE_HOOKS", "1")
-        monkeypatch.setenv("RWARE_PRIO", "1")
+        monkeypatch.setenv("RWARE_PRIO", "1"); monkeypatch.setenv("RWARE_PRIO_ROLLOUT", "1")
         a = rware_amd.WarehouseVecEnv(B, **kw)
-        monkeypatch.setenv("RWARE_PRIO", "0")
+        monkeypatch.setenv("RWARE_PRIO", "0"); monkeypatch.setenv("RWARE_PRIO_ROLLOUT", "0")
         b = rware_amd.WarehouseVecEnv(B, **kw)
-        monkeypatch.delenv("RWARE_PRIO")
-        assert (a.engines[0].info.wave_priority, b.engines[0].info.wave_priority) == (1, 0)
+        monkeypatch.delenv("RWARE_PRIO"); monkeypatch.delenv("RWARE_PRIO_ROLLOUT")
+        assert (a.engines[0].info.wave_priority, b.engines[0].info.wave_priority) == (3, 0)
         a.reset(seed=4); b.reset(seed=4)
         rng = np.random.default_rng(5)
         for t in range(40):
             act = rng.choice(5, size=(B, kw["n_agents"]), p=[0.1, 0.55, 0.1, 0.1, 0.15]).astype(np.int32)
             ra, rb = a.step(act), b.step(act)
             assert all(np.array_equal(x, y) for x, y in zip(ra[:4], rb[:4])), (env_id, t)
+        tape = rng.choice(5, size=(12, B, kw["n_agents"]), p=[0.1, 0.55, 0.1, 0.1, 0.15]).astype(np.int32)
+        fa, fb = a.rollout(tape, want_obs=False), b.rollout(tape, want_obs=False)        # the fused rollouts, with and without
+        assert all(np.array_equal(x, y) for x, y in zip(fa[1:], fb[1:])), env_id
         sa, sb = a.get_state(), b.get_state()
         assert all(np.array_equal(sa[k], sb[k]) for k in sa), env_id
         a.close(); b.close()
