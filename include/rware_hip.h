@@ -337,9 +337,11 @@ typedef struct rw_info {
                                   it; bench.py prices `frac_engine` on it (<= 1 by construction)                               */
     int32_t stagger_ticks;     /* > 0: the k-th of the first eight workgroups a CU receives starts k * stagger_ticks * 10 ns late, so that
                                   the workgroups of a CU do not run their load / agent / store phases in lock-step.  rw_create's measured rule:
-                                  <= 12 agents — 250 ns from two rounds of workgroups on; 13 .. 16 agents — 550 ns at one round and from four
-                                  rounds on (400 ns up to two rounds with sensor_range 2); else 0 (A/B runs: RWARE_STAGGER_TICKS=n with
-                                  RWARE_HOOKS=1; 0 = off).  A delay, never a different result */
+                                  13 .. 16 agents at sensor_range 1 — 550 ns at one round and from four rounds on; launches that do NOT run at
+                                  raised wavefront priority (wave_priority bit 0 clear: steps of >= 200 MB of observations) — <= 12 agents 250 ns
+                                  from two rounds of workgroups on, 13 .. 16 agents at sensor_range 2 400 ns up to two rounds; else 0: with the
+                                  priority the delay is only a delay (A/B runs: RWARE_STAGGER_TICKS=n with RWARE_HOOKS=1; 0 = off).  A delay,
+                                  never a different result */
     int32_t pipe_envs_per_workgroup; /* != 0: rw_step* launches run the chunk-pipelined persistent build with chunks of this many envs ... */
     int32_t pipe_workgroups;         /* ... on this many persistent workgroups (rw_stream_flags RW_PIPE_ON / RW_PIPE_OFF)              */
     int32_t stats;                   /* 1: RW_STATS_ON — RW_BUF_STAT_* are kept (was `reserved[1]`: same struct size)                 */

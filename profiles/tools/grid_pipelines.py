@@ -1,6 +1,6 @@
 """One line per task: the batch as ONE engine against rware_amd.make_pipelines(B, 2) (two sub-batches on streams of their own), us per
 step of the WHOLE batch, per-step launches from device action tapes, a launcher thread per engine (un-profiled, wall clock).
-    python profiles/tools/grid_pipelines.py [B]"""
+    python profiles/tools/grid_pipelines.py [B [task[:sensor_range] ...]]   (no tasks: the papers' grid + the 9 .. 19-agent ids)"""
 import sys
 import threading
 import time
@@ -12,6 +12,7 @@ sys.path.insert(0, ".")
 import rware_amd  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+TASKS = sys.argv[2:]
 grid = [f"rware-{s}-{n}ag{d}-v1" for s in ("tiny", "small", "medium") for n in (2, 4, 6, 8) for d in ("-easy", "", "-hard")]
 extra = ["rware-large-2ag-v1", "rware-large-4ag-v1", "rware-large-6ag-v1", "rware-large-8ag-v1", "rware-small-9ag-v1", "rware-small-10ag-v1",
          "rware-tiny-11ag-v1", "rware-small-12ag-v1", "rware-medium-13ag-v1", "rware-small-14ag-v1", "rware-medium-15ag-hard-v1", "rware-small-16ag-v1",
@@ -19,8 +20,13 @@ extra = ["rware-large-2ag-v1", "rware-large-4ag-v1", "rware-large-6ag-v1", "rwar
 K, TS = 1500, 64
 print(f"B = {B} envs on one GPU; us per step of the whole batch; one engine -> two pipelines of {B // 2}")
 print(f"{'task':30s} {'one engine':>11s} {'two pipelines':>14s} {'change':>8s} {'G agent-steps/s':>16s}")
-for env_id in grid + extra:
+for env_id in (TASKS or grid + extra):
+    sr = 0
+    if ":" in env_id:
+        env_id, sr = env_id.split(":")[0], int(env_id.split(":")[1])
     kw = rware_amd.env_kwargs(env_id)
+    if sr:
+        kw["sensor_range"] = sr
     N = kw["n_agents"]
     acts = torch.from_numpy(np.random.default_rng(1).integers(0, 5, size=(TS, B, N), dtype=np.int32)).cuda()
     res = []

@@ -638,23 +638,6 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         const long long per_cu = std::min<long long>(8, (160 * 1024) / (long long)std::max<size_t>(eng->lds_bytes, 1));
         const bool pow2 = n_cu > 0 && (n_cu & (n_cu - 1)) == 0;
         while (pow2 && (1 << eng->stagger_shift) < n_cu) ++eng->stagger_shift;
-        // (up to 12 agents: beyond, the workgroups are bound by their agent phases' instruction issue, there is little idle phase to
-        //  fill and the sweep is a wash — large-16ag -3 % at 4 rounds, +4 % at 2)
-        eng->stagger_ticks = (pow2 && N <= 12 && (long long)eng->n_wg >= 2 * per_cu * n_cu) ? 25 : 0;  // x 10 ns per slot (profiles/r04_stagger_sweep.txt)
-        // 13 .. 16 agents (round 6, profiles/r06_stagger_single_round.txt, r06_t128_stagger.txt): these launches gain from WIDER slots, and
-        // already when the launch is resident at once — eight workgroups per CU with two agent wavefronts each contend for the same
-        // SIMDs in their agent phases, and 0.55 us between their starts takes the phases apart (16384 envs: medium-13ag 17.7 -> 16.4 us,
-        // small-13ag 18.1 -> 17.0, small-15ag 20.4 -> 19.3, small-14ag 17.3 -> 17.0, large-16ag 18.0 -> 17.3; four rounds and more: small-14ag x
-        // 65536 55.1 -> 49.5, large-16ag x 65536 61.1 -> 59.3).  Exactly two rounds lose (large-16ag x 32768 30.8 -> 32.0, medium-16ag x 32768
-        // 31.2 -> 32.5): left alone.  9 .. 12 and 17 .. 19 agents lose or do not move at one round (small-10ag 13.1 -> 13.5, 19ag 21.2 -> 21.6).
-        // sensor_range 2 (BASELINE config 5, 4-env workgroups, two rounds at 16384 envs): 40 ticks, 35.1 -> 34.5; four rounds +-0.
-        if (pow2 && N >= 13 && N <= 16 && per_cu > 0) {
-            const long long resident = per_cu * n_cu, wg = (long long)eng->n_wg;
-            if (R == 1) eng->stagger_ticks = (wg <= resident || wg >= 4 * resident) ? 55 : 0;
-            else if (R == 2) eng->stagger_ticks = (wg <= 2 * resident) ? 40 : 0;
-        }
-        const char *st = rw_hook("RWARE_STAGGER_TICKS");  // (A/B and test hook: 0 = off, n = ticks whatever the launch size)
-        if (st && *st && pow2) eng->stagger_ticks = std::min(255, std::max(0, atoi(st)));
         // Wavefront priority up to the agent-phase barrier (round 6, rware_kernels.h; same-box A/B of library variants and of this
         // switch: profiles/r06_prio_ab.txt, r06_prio_ab2.txt, r06_prio_wide.txt, r06_prio_sweep.txt).  On for every launch except the
         // 13 .. 16-agent ones at sensor_range 1 — the family that runs start-staggered: with the priority on top they lose (medium-13ag x
@@ -669,6 +652,28 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         eng->prio_rollout = fits;
         const char *pr = rw_hook("RWARE_PRIO");  // (A/B and test hooks: 0 = off, 1 = on whatever the shape)
         if (pr && (pr[0] == '0' || pr[0] == '1')) eng->prio = pr[0] == '1';
+        // Start stagger.  Up to 12 agents (beyond, the workgroups are bound by their agent phases' instruction issue, there is little idle
+        // phase to fill and the sweep is a wash — large-16ag -3 % at 4 rounds, +4 % at 2): 250 ns per slot from two rounds of workgroups
+        // on (profiles/r04_stagger_sweep.txt) — WHERE THE PRIORITY IS OFF: with the chain at raised priority the rounds no longer run in
+        // lock-step, and the delay is only a delay (profiles/r06_stagger_under_prio.txt, priority on, stagger 0 against 25: small-3ag x
+        // 65536 13.9 against 15.05 us, small-5ag 21.5 / 22.6, small-7ag 26.9 / 28.7, small-6ag 21.85 / 22.7, medium-6ag-hard 22.3 / 22.85,
+        // small-4ag 14.6 / 14.7; 8 .. 10 agents from four rounds on would keep a per cent or two of it: small-8ag x 65536 27.2 / 26.8).
+        eng->stagger_ticks = (pow2 && N <= 12 && !eng->prio && (long long)eng->n_wg >= 2 * per_cu * n_cu) ? 25 : 0;  // x 10 ns per slot
+        // 13 .. 16 agents (round 6, profiles/r06_stagger_single_round.txt, r06_t128_stagger.txt): these launches gain from WIDER slots, and
+        // already when the launch is resident at once — eight workgroups per CU with two agent wavefronts each contend for the same
+        // SIMDs in their agent phases, and 0.55 us between their starts takes the phases apart (16384 envs: medium-13ag 17.7 -> 16.4 us,
+        // small-13ag 18.1 -> 17.0, small-15ag 20.4 -> 19.3, small-14ag 17.3 -> 17.0, large-16ag 18.0 -> 17.3; four rounds and more: small-14ag x
+        // 65536 55.1 -> 49.5, large-16ag x 65536 61.1 -> 59.3).  Exactly two rounds lose (large-16ag x 32768 30.8 -> 32.0, medium-16ag x 32768
+        // 31.2 -> 32.5): left alone.  9 .. 12 and 17 .. 19 agents lose or do not move at one round (small-10ag 13.1 -> 13.5, 19ag 21.2 -> 21.6).
+        // sensor_range 2 (BASELINE config 5, 4-env workgroups, two rounds at 16384 envs): 40 ticks, 35.1 -> 34.5 — without the priority; with
+        // it none (profiles/r06_cfg5_stagger_prio.txt: config 5's shard 33.9 against 34.3 with the 40 ticks, x 8192 19.56 / 19.66).
+        if (pow2 && N >= 13 && N <= 16 && per_cu > 0) {
+            const long long resident = per_cu * n_cu, wg = (long long)eng->n_wg;
+            if (R == 1) eng->stagger_ticks = (wg <= resident || wg >= 4 * resident) ? 55 : 0;
+            else if (R == 2) eng->stagger_ticks = (!eng->prio && wg <= 2 * resident) ? 40 : 0;
+        }
+        const char *st = rw_hook("RWARE_STAGGER_TICKS");  // (A/B and test hook: 0 = off, n = ticks whatever the launch size)
+        if (st && *st && pow2) eng->stagger_ticks = std::min(255, std::max(0, atoi(st)));
         const char *prr = rw_hook("RWARE_PRIO_ROLLOUT");
         if (prr && (prr[0] == '0' || prr[0] == '1')) eng->prio_rollout = prr[0] == '1';
     }

@@ -911,11 +911,15 @@ def test_rw_multi_enqueues_every_engine_from_one_call(threads, monkeypatch):
 
 def test_start_stagger_is_a_create_time_rule_and_does_not_change_results(monkeypatch):
     """Launches of two or more rounds of workgroups (>= 2 x 8 per CU; the emulated device has one CU) stagger the start of the first
-    eight workgroups per CU (rw_info.stagger_ticks x 10 ns per slot; RWARE_STAGGER_TICKS moves the default): a delay, never a
-    different result."""
+    eight workgroups per CU (rw_info.stagger_ticks x 10 ns per slot; RWARE_STAGGER_TICKS moves the default) — where they do not run at
+    raised wavefront priority (round 6: with the priority the delay is only a delay): a delay, never a different result."""
     kw = rware_amd.env_kwargs("rware-small-4ag-v1")
     kw["max_steps"] = 11
     kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    prio = rware_amd.WarehouseVecEnv(256, library=LIB, **kw)             # 16 workgroups, two rounds — at raised priority: no stagger
+    assert (prio.engines[0].info.wave_priority & 1, prio.engines[0].info.stagger_ticks) == (1, 0)
+    prio.close()
+    monkeypatch.setenv("RWARE_PRIO", "0")                                # the rest of this test: the rule without the priority
     small = rware_amd.WarehouseVecEnv(64, library=LIB, **kw)             # 4 workgroups of 16 envs
     assert small.engines[0].info.stagger_ticks == 0
     small.close()

@@ -1149,8 +1149,9 @@ def test_runtime_specialisation_policy(tmp_path, monkeypatch):
     B = 65536
     jenv, aenv = rware_amd.WarehouseVecEnv(B, jit=True, **kw4), rware_amd.WarehouseVecEnv(B, **kw4)
     assert jenv.engines[0].info.jit in (1, 2) and aenv.engines[0].info.jit == 0
-    # 4096 workgroups = two rounds of 8 per CU: both launches stagger the start of the first round (a delay, never a different result)
-    assert aenv.engines[0].info.stagger_ticks == 25 and jenv.engines[0].info.stagger_ticks == 25
+    # 4096 workgroups = two rounds of 8 per CU: both launches run at raised wavefront priority instead of a start stagger (round 6)
+    assert (aenv.engines[0].info.stagger_ticks, jenv.engines[0].info.stagger_ticks) == (0, 0)
+    assert (aenv.engines[0].info.wave_priority, jenv.engines[0].info.wave_priority) == (3, 3)
     orc = OracleVecEnv(B, **dict(kw4, reward_type=rware_amd.enums.enum_value(kw4["reward_type"])))
     o0 = orc.reset(seed=3)
     assert np.array_equal(jenv.reset(seed=3)[0], o0) and np.array_equal(aenv.reset(seed=3)[0], o0)
@@ -1210,13 +1211,17 @@ def test_rw_multi_one_call_steps_eight_engines(threads, monkeypatch):
 
 
 def test_start_stagger_only_for_launches_of_two_or_more_rounds(monkeypatch):
-    """rw_info.stagger_ticks: 0 at the headline batch (1024 workgroups, 4 per CU) and at a full single round (2048), 25 from two
-    rounds on; RWARE_STAGGER_TICKS moves it.  With and without the stagger the same observations, rewards and state."""
+    """rw_info.stagger_ticks: 0 at the headline batch (1024 workgroups, 4 per CU) and at a full single round (2048); from two rounds on
+    25 where the launch does not run at raised wavefront priority (round 6: with the priority — every step under 200 MB of observations —
+    the delay is only a delay), 0 where it does; RWARE_STAGGER_TICKS moves it.  With and without the stagger the same observations,
+    rewards and state."""
     kw = rware_amd.env_kwargs("rware-small-4ag-v1")
-    for B, want in ((16384, 0), (32768, 0), (65536, 25)):
+    for B, want in ((16384, 0), (32768, 0), (65536, 0), (262144, 25)):
         env = rware_amd.WarehouseVecEnv(B, **kw)
         assert env.engines[0].info.stagger_ticks == want, B
+        assert env.engines[0].info.wave_priority & 1 == (0 if want else 1), B
         env.close()
+    monkeypatch.setenv("RWARE_PRIO", "0")     # (the rule without the priority: round 4's)
     a = rware_amd.WarehouseVecEnv(65536, **kw)
     monkeypatch.setenv("RWARE_STAGGER_TICKS", "0")
     b = rware_amd.WarehouseVecEnv(65536, **kw)
@@ -1236,10 +1241,11 @@ def test_start_stagger_only_for_launches_of_two_or_more_rounds(monkeypatch):
 
 def test_start_stagger_rule_for_13_to_16_agents_matches_oracle():
     """Round 6: launches of 13 .. 16 agents stagger their workgroups' starts by wider slots, already when the launch is resident at once
-    (one round) and from four rounds on, not at exactly two; sensor_range 2 (BASELINE config 5) up to two rounds.  The rule as
-    rw_info shows it, and — a delay, never a different result — the staggered launches against the oracle."""
+    (one round) and from four rounds on, not at exactly two; sensor_range 2 (BASELINE config 5) runs at raised wavefront priority
+    instead (second session: 33.9 against 34.3 us with the 40 ticks it had without the priority).  The rule as rw_info shows it, and —
+    a delay, never a different result — the staggered launches against the oracle."""
     for env_id, extra, B, want in (("rware-large-16ag-v1", {}, 16384, 55), ("rware-large-16ag-v1", {}, 32768, 0), ("rware-small-14ag-v1", {}, 65536, 55),
-                                   ("rware-large-16ag-v1", {"sensor_range": 2}, 16384, 40), ("rware-large-16ag-v1", {"sensor_range": 2}, 32768, 0),
+                                   ("rware-large-16ag-v1", {"sensor_range": 2}, 16384, 0), ("rware-large-16ag-v1", {"sensor_range": 2}, 32768, 0),
                                    ("rware-small-12ag-v1", {}, 16384, 0), ("rware-small-17ag-v1", {}, 16384, 0)):
         env = rware_amd.WarehouseVecEnv(B, **dict(rware_amd.env_kwargs(env_id), **extra))
         assert env.engines[0].info.stagger_ticks == want, (env_id, extra, B)
