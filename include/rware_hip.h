@@ -113,7 +113,16 @@ enum rw_stream_flags {
      * RW_BUF_STAT_FAILED_MOVES (below) — off by default, and the reference's `info` stays {} either way (rware/warehouse.py:746-747).
      * Counted by the service wavefront beside the observation stores (re-derived from what the state write-back holds; nothing is added
      * to the agent phases), in every launch form: rw_step*, fused rollouts, tapes, HIP graphs, rw_multi. */
-    RW_STATS_ON = 128
+    RW_STATS_ON = 128,
+    /* Wavefront priority (rw_info.wave_priority): the launches run the dependent chain in front of their first observation store at raised
+     * priority by rw_create's measured rule (on, except the per-step launches of 13 .. 16 agents at sensor_range 1 and steps of 200 MB of
+     * observations and more).  RW_PRIO_OFF: never — what rware_amd.make_pipelines asks for when a sub-batch has 8192 envs or fewer: with TWO
+     * launches in flight the raised chain of one takes the issue slots of the other's store phase, which is what fills the gap (two
+     * pipelines of 8192 envs, per step of the whole batch: small-8ag 7.9 us without against 9.1 with, small-10ag 10.7 / 11.9, medium-13ag
+     * 13.4 / 15.4; profiles/r06_pipelines_prio.txt).  RW_PRIO_ON: always (per-step launches and fused rollouts alike).  A scheduling
+     * hint either way: same results.  (A/B runs: RWARE_PRIO=0|1, RWARE_PRIO_ROLLOUT=0|1 with RWARE_HOOKS=1 move the default only.) */
+    RW_PRIO_OFF = 256,
+    RW_PRIO_ON = 512
 };
 
 /* Device buffers (all env-major, C-contiguous).  Replaces the attributes callers read off the

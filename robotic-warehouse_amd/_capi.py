@@ -31,6 +31,7 @@ RW_STREAM_USE_GIVEN = 1  # rw_stream_flags: `stream` is taken literally, NULL ==
 RW_OBS_STORES_CACHED, RW_OBS_STORES_STREAM = 2, 4  # rw_stream_flags: keep the observation lines cached / force the non-temporal hint
 RW_JIT_OFF, RW_JIT_FORCE = 8, 16  # rw_stream_flags: run-time specialisation (hipRTC) never / always; default: shapes without an exact build, B >= 4096
 RW_PIPE_OFF, RW_PIPE_ON = 32, 64  # rw_stream_flags: the chunk-pipelined persistent per-step kernel never / wherever a build exists; default: the engine's measured rule
+RW_PRIO_OFF, RW_PRIO_ON = 256, 512  # rw_stream_flags: raised wavefront priority on the chain in front of the first store never / always; default: the engine's measured rule
 RW_STATS_ON = 128  # rw_stream_flags: keep the per-env event counters RW_BUF_STAT_DELIVERIES / _FAILED_MOVES (off by default)
 
 AUTORESET = {"disabled": 0, None: 0, "next_step": 1, "same_step": 2}
@@ -187,7 +188,7 @@ class Engine:
                  max_inactivity_steps, max_steps, reward_type, normalised_coordinates=False,
                  autoreset_mode="next_step", device_id=0, envs_per_workgroup=0,
                  threads_per_workgroup=0, stream=None, library=None, observation_type=1,
-                 image_layers=(), image_directional=True, msg_bits=0, use_given_stream=False, obs_stores=None, jit=None, pipe=None, stats=False):
+                 image_layers=(), image_directional=True, msg_bits=0, use_given_stream=False, obs_stores=None, jit=None, pipe=None, stats=False, wave_priority=None):
         self.lib = load(library)
         self._h = C.c_void_p()
         self._arena, self.arena_allocations = {}, 0  # rollout_host's device tapes (grow-only; freed in close())
@@ -203,7 +204,8 @@ class Engine:
             (RW_STREAM_USE_GIVEN if use_given_stream else 0) | {None: 0, "auto": 0, "cached": RW_OBS_STORES_CACHED, "stream": RW_OBS_STORES_STREAM}[obs_stores]
             | {None: 0, "auto": 0, False: RW_JIT_OFF, "off": RW_JIT_OFF, True: RW_JIT_FORCE, "force": RW_JIT_FORCE}[jit]
             | {None: 0, "auto": 0, False: RW_PIPE_OFF, "off": RW_PIPE_OFF, True: RW_PIPE_ON, "on": RW_PIPE_ON}[pipe]
-            | (RW_STATS_ON if stats else 0),
+            | (RW_STATS_ON if stats else 0)
+            | {None: 0, "auto": 0, False: RW_PRIO_OFF, "off": RW_PRIO_OFF, True: RW_PRIO_ON, "on": RW_PRIO_ON}[wave_priority],
             hw.ctypes.data, goals.ctypes.data, C.c_void_p(stream or 0))
         rc = self.lib.rw_create(C.byref(cfg), C.byref(self._h))
         if rc != RW_OK:

@@ -650,8 +650,12 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         const bool fits = (double)B * N * eng->L * 4 <= 200e6;
         eng->prio = fits && !(R == 1 && N >= 13 && N <= 16);
         eng->prio_rollout = fits;
-        const char *pr = rw_hook("RWARE_PRIO");  // (A/B and test hooks: 0 = off, 1 = on whatever the shape)
+        const char *pr = rw_hook("RWARE_PRIO");  // (A/B and test hooks: 0 = off, 1 = on whatever the shape; an explicit flag of the caller wins)
         if (pr && (pr[0] == '0' || pr[0] == '1')) eng->prio = pr[0] == '1';
+        const char *prr = rw_hook("RWARE_PRIO_ROLLOUT");
+        if (prr && (prr[0] == '0' || prr[0] == '1')) eng->prio_rollout = prr[0] == '1';
+        if (cfg->stream_flags & RW_PRIO_OFF) eng->prio = eng->prio_rollout = false;  // (rware_amd.make_pipelines: two launches in flight)
+        if (cfg->stream_flags & RW_PRIO_ON) eng->prio = eng->prio_rollout = true;
         // Start stagger.  Up to 12 agents (beyond, the workgroups are bound by their agent phases' instruction issue, there is little idle
         // phase to fill and the sweep is a wash — large-16ag -3 % at 4 rounds, +4 % at 2): 250 ns per slot from two rounds of workgroups
         // on (profiles/r04_stagger_sweep.txt) — WHERE THE PRIORITY IS OFF: with the chain at raised priority the rounds no longer run in
@@ -674,8 +678,6 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         }
         const char *st = rw_hook("RWARE_STAGGER_TICKS");  // (A/B and test hook: 0 = off, n = ticks whatever the launch size)
         if (st && *st && pow2) eng->stagger_ticks = std::min(255, std::max(0, atoi(st)));
-        const char *prr = rw_hook("RWARE_PRIO_ROLLOUT");
-        if (prr && (prr[0] == '0' || prr[0] == '1')) eng->prio_rollout = prr[0] == '1';
     }
 
     {

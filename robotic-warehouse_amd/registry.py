@@ -155,6 +155,13 @@ def make_pipelines(num_envs: int, n: int = 2, device: int = 0, env_id: str = Non
     if "devices" in kw:
         raise ValueError("make_pipelines puts every sub-batch on ONE GPU: pass device=<ordinal>, not devices=")
     per = num_envs // n
+    # Two launches in flight on one device: the raised wavefront priority each engine would give its own chain (rw_info.wave_priority)
+    # takes issue slots from the OTHER pipeline's store phase — which is what fills the gap.  Measured (profiles/r06_pipelines_prio.txt, two
+    # pipelines of 8192 envs, us per step of the whole batch, without / with): small-8ag 7.9 / 9.1, small-10ag 10.7 / 11.9, small-12ag
+    # 11.9 / 12.9, medium-13ag 13.4 / 15.4, medium-6ag-hard 6.85 / 7.05; from 16384 envs per pipeline on the engine's own rule is as good
+    # or better (small-8ag x 32768 13.3 / 12.0, small-4ag 7.2 / 7.1).  The caller's wave_priority= wins.
+    if n > 1 and per <= 8192:
+        kw.setdefault("wave_priority", False)
     pipes, rejected = [], []
     for k in range(n):
         # HIP maps streams onto a handful of hardware queues, and two streams that land on the same queue run one after the other

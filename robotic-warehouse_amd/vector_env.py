@@ -147,7 +147,7 @@ class WarehouseVecEnv(_VectorEnvBase):
                  normalised_coordinates: bool = False, render_mode=None, *,
                  autoreset_mode: str = "next_step", devices=None, output: str = "numpy",
                  envs_per_workgroup: int = 0, threads_per_workgroup: int = 0, library: str | None = None,
-                 obs_stores: str | None = None, jit=None, pipe=None, stats: bool = False):
+                 obs_stores: str | None = None, jit=None, pipe=None, stats: bool = False, wave_priority=None):
         if not 0 <= int(msg_bits) <= 16:
             raise ValueError("msg_bits must be in 0..16")
         self.msg_bits = int(msg_bits)
@@ -231,7 +231,10 @@ class WarehouseVecEnv(_VectorEnvBase):
                 # kernel never / wherever the library has a build for the shape (rw_stream_flags RW_PIPE_*)
                 pipe=pipe,
                 # True: the engine keeps per-env event counters (RW_STATS_ON) — see event_counters()
-                stats=stats))
+                stats=stats,
+                # None / "auto": the engine's measured rule (rw_info.wave_priority); False / True: the launches never / always run the chain
+                # in front of their first observation store at raised wavefront priority (RW_PRIO_OFF / RW_PRIO_ON) — a scheduling hint
+                wave_priority=wave_priority))
         self._bounds = [b for b in self._bounds if b[1] > b[0]]
         self.shard_bounds = list(self._bounds)  # env range [lo, hi) of every engine / device, in order
         self.devices = devices[: len(self.engines)]

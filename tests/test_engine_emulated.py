@@ -964,6 +964,11 @@ def test_wave_priority_is_a_create_time_rule_and_does_not_change_results(monkeyp
     monkeypatch.delenv("RWARE_PRIO_ROLLOUT")
     monkeypatch.setenv("RWARE_PRIO", "1")
     assert wp("rware-medium-13ag-v1", 8) == 3
+    monkeypatch.delenv("RWARE_PRIO")
+    # the caller's flag (RW_PRIO_OFF / RW_PRIO_ON; what make_pipelines passes for small sub-batches) wins over rule and hooks
+    assert wp("rware-small-4ag-v1", 64, wave_priority=False) == 0 and wp("rware-medium-13ag-v1", 8, wave_priority=True) == 3
+    monkeypatch.setenv("RWARE_PRIO", "1")
+    assert wp("rware-small-4ag-v1", 64, wave_priority=False) == 0
     kw = rware_amd.env_kwargs("rware-small-4ag-v1")
     kw["max_steps"] = 9
     on = rware_amd.WarehouseVecEnv(32, library=LIB, **kw)

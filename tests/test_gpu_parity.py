@@ -1304,6 +1304,24 @@ def test_wave_priority_rule_and_results(monkeypatch):
         a.close(); b.close()
 
 
+def test_pipelines_of_small_sub_batches_run_without_the_wavefront_priority():
+    """make_pipelines: with two launches in flight the raised chain of one takes issue slots from the other's store phase, so sub-batches of
+    8192 envs or fewer are built with RW_PRIO_OFF (profiles/r06_pipelines_prio.txt); bigger ones keep the engine's rule; the caller's
+    wave_priority= wins."""
+    def priorities(B, **kw):
+        pipes = rware_amd.make_pipelines(B, 2, env_id="rware-small-10ag-v1", **kw)
+        out = [p.env.engines[0].info.wave_priority for p in pipes]
+        for p in pipes:
+            p.env.close()
+        return out
+    assert priorities(16384) == [0, 0]
+    assert priorities(32768) == [3, 3]
+    assert priorities(16384, wave_priority=True) == [3, 3]
+    one = rware_amd.WarehouseVecEnv(8192, **rware_amd.env_kwargs("rware-small-10ag-v1"))
+    assert one.engines[0].info.wave_priority == 3
+    one.close()
+
+
 def test_two_pipelines_on_one_device_match_the_single_engine():
     """Double-buffered sampling (bench.py's `two_pipelines`): the batch as two engines on one device, own streams, stepped
     CONCURRENTLY by one launcher thread each, against one engine over the whole batch — same observations and state."""
