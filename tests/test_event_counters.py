@@ -217,6 +217,31 @@ def test_emulated_fused_rollout_counts_like_single_steps(env_id, extra, B, geom,
 
 
 @pytest.mark.timeout(1500)
+def test_emulated_pipelined_build_counts_too(monkeypatch):
+    """the chunk-pipelined persistent flow (a `make PIPE=1` library; the emulation build carries it) with counters: the service wavefront
+    counts per chunk, several chunks per workgroup"""
+    monkeypatch.setenv("RWARE_PIPE_GRID", "2")
+    kw = rware_amd.env_kwargs("rware-small-4ag-v1")
+    kw["max_steps"] = 14
+    kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+    B = 96   # 6 chunks of 16 envs on 2 persistent workgroups
+    env = rware_amd.WarehouseVecEnv(B, library=_emu(), stats=True, pipe=True, **kw)
+    assert env.engines[0].info.pipe_workgroups == 2 and env.engines[0].info.stats == 1
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=12)[0], orc.reset(seed=12))
+    rng = np.random.default_rng(12)
+    for t in range(35):
+        a = rng.choice(5, size=(B, 4), p=[.05, .7, .1, .1, .05]).astype(np.int32)
+        _, rew, _, _, _ = env.step(a)
+        _, r2, _ = orc.step_autoreset(a, "next_step")
+        assert np.array_equal(rew, r2), t
+        c = env.event_counters()
+        assert np.array_equal(c["deliveries"], orc.stat_deliveries) and np.array_equal(c["failed_moves"], orc.stat_failed_moves), t
+    assert orc.stat_failed_moves.sum() > 0
+    env.close()
+
+
+@pytest.mark.timeout(1500)
 def test_emulated_counters_switch_snapshot_and_writes():
     check_switch_snapshot_and_writes(_emu())
 
