@@ -242,6 +242,27 @@ def test_emulated_pipelined_build_counts_too(monkeypatch):
 
 
 @pytest.mark.timeout(1500)
+def test_emulated_sharded_env_gathers_its_counters():
+    """an env sharded over several engines (devices=[...]): event_counters() is the concatenation in env order, equal to the unsharded oracle"""
+    kw = rware_amd.env_kwargs("rware-tiny-2ag-v1")
+    kw["max_steps"] = 12
+    B = 24
+    env = rware_amd.WarehouseVecEnv(B, library=_emu(), devices=[0, 0, 0], stats=True, **kw)
+    assert len(env.engines) == 3
+    orc = OracleVecEnv(B, **kw)
+    assert np.array_equal(env.reset(seed=3)[0], orc.reset(seed=3))
+    rng = np.random.default_rng(9)
+    for t in range(30):
+        a = rng.choice(5, size=(B, 2), p=[.05, .7, .1, .1, .05]).astype(np.int32)
+        env.step(a)
+        orc.step_autoreset(a, "next_step")
+    c = env.event_counters()
+    assert c["deliveries"].shape == (B,) and np.array_equal(c["deliveries"], orc.stat_deliveries)
+    assert np.array_equal(c["failed_moves"], orc.stat_failed_moves) and orc.stat_failed_moves.sum() > 0
+    env.close()
+
+
+@pytest.mark.timeout(1500)
 def test_emulated_counters_switch_snapshot_and_writes():
     check_switch_snapshot_and_writes(_emu())
 
