@@ -46,6 +46,10 @@ struct rw_engine {
     rw::Params prm{};
     int S = 0, L = 0, OW = 0;
     int E = 0, T = 0, n_wg = 0;
+    // the fused rollout's own launch geometry: the same as the per-step kernel's except where rw_create gives the per-step launches
+    // smaller workgroups than the rollouts want (13 .. 16 agents, see there)
+    int roll_n_wg = 0;
+    size_t roll_lds_bytes = 0;
     int stagger_ticks = 0, stagger_shift = 0;  // start stagger of a CU's first eight workgroups (multi-round launches: see the kernel's prologue)
     bool prio_rollout = false; // ... the fused rollouts (every step of the launch raises it again)
     bool prio = false;         // per-step launches carry OP_FLAG_PRIO: raised wavefront priority up to the agent-phase barrier (rw_info::wave_priority)
@@ -168,23 +172,25 @@ int launch(rw_engine *eng, rw::LaunchArgs la, int op, bool rollout = false, hipE
         RW_HIP(eng, hipGetLastError());
         return RW_OK;
     }
+    const int n_wg = rollout ? eng->roll_n_wg : eng->n_wg;
+    const size_t lds = rollout ? eng->roll_lds_bytes : eng->lds_bytes;
     if (eng->jit_step) {  // a run-time specialised build: the same launch through the module API
         const rw::Params *cp = eng->d_prm;
         void *args[13] = {&cp, &la.actions, &la.op, &la.n_steps, &la.obs, &la.rewards, &la.terminated, &la.reset_mask, &la.timeline,
                           &la.act_stride, &la.obs_stride, &la.rew_stride, &la.term_stride};
         hipFunction_t f = rollout ? eng->jit_rollout : eng->jit_step;
         if (start || stop)
-            RW_HIP(eng, hipExtModuleLaunchKernel(f, (uint32_t)eng->n_wg * (uint32_t)eng->T, 1, 1, (uint32_t)eng->T, 1, 1, eng->lds_bytes, eng->stream,
+            RW_HIP(eng, hipExtModuleLaunchKernel(f, (uint32_t)n_wg * (uint32_t)eng->T, 1, 1, (uint32_t)eng->T, 1, 1, lds, eng->stream,
                                                  args, nullptr, start, stop, 0));
         else
-            RW_HIP(eng, hipModuleLaunchKernel(f, (uint32_t)eng->n_wg, 1, 1, (uint32_t)eng->T, 1, 1, (uint32_t)eng->lds_bytes, eng->stream, args, nullptr));
+            RW_HIP(eng, hipModuleLaunchKernel(f, (uint32_t)n_wg, 1, 1, (uint32_t)eng->T, 1, 1, (uint32_t)lds, eng->stream, args, nullptr));
         return RW_OK;
     }
     if (start || stop)  // the events ride on this dispatch (its own start / end timestamps): no marker packets in the stream
-        hipExtLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
+        hipExtLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(n_wg), dim3(eng->T), lds,
                               eng->stream, start, stop, 0, (const rw::Params *)eng->d_prm, RW_LAUNCH_ARGS(la));
     else
-        hipLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(eng->n_wg), dim3(eng->T), eng->lds_bytes,
+        hipLaunchKernelGGL(rollout ? eng->kernel_rollout : eng->kernel, dim3(n_wg), dim3(eng->T), lds,
                            eng->stream, (const rw::Params *)eng->d_prm, RW_LAUNCH_ARGS(la));
     RW_HIP(eng, hipGetLastError());
     return RW_OK;
@@ -432,6 +438,8 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
 
     // workgroup geometry: E envs per workgroup (multiple of 4 keeps every chunk 16-byte aligned)
     int E = cfg->envs_per_workgroup, T = cfg->threads_per_workgroup;
+    int roll_E = 0;  // != 0: the fused rollout runs on workgroups of this many envs (its own table entry), not on E
+    bool wide4 = false;  // 13 .. 16 agents on the 4-env per-step build (see the table search below): priority instead of the start stagger
     if (T == 0) T = 256;
     if (T % 64 || T < 64 || T > 256) {
         fail(eng, RW_ERR_INVALID_ARG, "threads_per_workgroup %d must be 64..256, multiple of 64", T);
@@ -470,9 +478,11 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     if (!(eng->image && eng->msg_bits > 0)) {  // (image + messages together: generic builds only)
         // Pick a specialised build: exact-shape entries before size-static ones, first match wins.
         const bool geom_default = cfg->envs_per_workgroup == 0 && cfg->threads_per_workgroup == 0;
-        const StaticEntry *best = nullptr;
         const char *pq = rw_hook("RWARE_PREFER_QRT");  // (test / A-B hook: skip the exact (N, Q) builds)
         const bool prefer_qrt = pq && pq[0] == '1';
+        // find(want_e): the table's own choice for this batch (want_e == 0), or its entry with want_e envs per 256-thread workgroup
+        auto find = [&](int want_e) -> const StaticEntry * {
+        const StaticEntry *best = nullptr;
         for (int exact = 1; exact >= 0 && !best; --exact)
             for (int grp = 0; grp < rw_tab::kStaticGroups && !best; ++grp) {
             int n_se = 0;
@@ -491,13 +501,35 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
                 if (prefer_qrt && se.N != 0 && se.Q >= 0 && !se.image && se.M == 0) continue;  // (test / A-B hook: skip the exact (N, Q) builds)
                 const bool shape = se.H == H && se.W == W && se.S == S && se.R == R && (se.N == 0 || (se.N == N && q_ok));
                 if (!shape || B % se.E != 0) continue;
-                if (geom_default ? (se.max_B == 0 || B <= se.max_B) : (E == se.E && T == se.T)) { best = &se; break; }
+                if (want_e ? (se.E == want_e && se.T == 256)
+                           : geom_default ? (se.max_B == 0 || B <= se.max_B) : (E == se.E && T == se.T)) { best = &se; break; }
             }
             }
+        return best;
+        };
+        // 13 .. 16 agents at sensor_range 1 (round 6, second session; profiles/r06_1316_matrix.txt — 8 tasks x 10 batches x geometry x stagger x
+        // priority): their 8-env workgroups hold TWO full agent wavefronts, which is why these launches wanted a start stagger and lose with
+        // the wavefront priority; on 4-env workgroups (one agent wavefront each) they behave like the smaller tasks, and with the priority
+        // on and no stagger beat the 8-env rule below one full round of 8-env workgroups (2048 envs: large-16ag 8.17 -> 6.61 us, 4096: 9.52
+        // -> 7.35, medium-13ag 9.71 -> 7.61; 8192: 11.7 -> 11.1; 12288: 14.6 -> 13.2) and between one and four rounds (24576: large-16ag 25.1 ->
+        // 22.0, 32768: 30.8 -> 27.8, medium-13ag 30.8 -> 27.2, small-15ag 34.4 -> 31.5; 49152: small-16ag 45.5 -> 39.7; 14 agents -2 .. -4 %).
+        // At exactly one round (16384 envs) and from four rounds on the staggered 8-env launch stays (16384: medium-13ag 16.2 against 16.6,
+        // large-14ag 15.9 / 16.7; 65536: small-16ag 56.7 / 60.9, large-16ag 58.9 / 63.6).  The FUSED ROLLOUTS keep the 8-env build at every
+        // batch (4-env: +10 .. +47 %, profiles/r06_1316_rollout_geom.txt): the engine then launches its two kernels with different geometries.
+        int want_e = 0;
+        if (geom_default && R == 1 && N >= 13 && N <= 16 && !eng->image && eng->msg_bits == 0 && B % 4 == 0) {
+            const long long wg8 = ((long long)B + 7) / 8, resident = 8LL * std::max(1, eng->prop.multiProcessorCount);
+            const char *e4 = rw_hook("RWARE_WIDE_E4");  // (A/B and test hook: 0 = never, 1 = at every batch)
+            if (e4 ? e4[0] == '1' : (wg8 < resident || (wg8 > resident && wg8 < 4 * resident))) want_e = 4;
+        }
+        const StaticEntry *best = want_e ? find(want_e) : nullptr;
+        const StaticEntry *best_roll = nullptr;
+        if (best) best_roll = find(0);            // (the rollouts' build: the table's own choice)
+        if (!best || !best_roll || best_roll->Q != best->Q) { best = find(0); best_roll = nullptr; want_e = 0; }  // (no 4-env build of this shape: the tiny warehouse)
         // event counters (RW_STATS_ON): only kernels compiled with the counting code (RW_STATS_BUILD) will do — the generic ones, a run-time
         // compiled exact-shape build (below), and — in a library whose specialised builds were made with the switch — those
         if (best && want_stats && !rw_tab::static_has_stats()) {
-            best = nullptr;
+            best = best_roll = nullptr;
             eng->jit_log = "event counters: the ahead-of-time exact-shape builds do not carry the counting code";
         }
         if (best) {
@@ -505,7 +537,9 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
             T = best->T;
             eng->kernel = best->fn;
             eng->kernel_nt = best->fn_nt;
-            eng->kernel_rollout = best->fn_rollout;
+            eng->kernel_rollout = best_roll ? best_roll->fn_rollout : best->fn_rollout;
+            roll_E = best_roll ? best_roll->E : 0;
+            wide4 = want_e == 4;
             eng->specialised = true;
             eng->q_runtime = best->Q < 0;
             eng->build_kind = best->N == 0 ? 3 : best->Q < 0 ? 2 : 1;
@@ -586,6 +620,8 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
                     if (me == hipSuccess) {
                         E = je_;
                         T = 256;
+                        roll_E = 0;
+                        wide4 = false;
                         eng->specialised = true;
                         eng->q_runtime = false;
                         eng->build_kind = 1;
@@ -614,18 +650,21 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
     eng->E = E;
     eng->T = T;
     eng->n_wg = (B + E - 1) / E;
+    eng->roll_n_wg = roll_E ? (B + roll_E - 1) / roll_E : eng->n_wg;
     // (an agent-count-static build reserves 2 N queue slots per env in LDS whatever Q is)
     eng->lds_bytes = sizeof(int32_t) * (size_t)rw::make_lds_layout(E, N, eng->q_runtime ? 2 * N : Q, HW, SW, eng->OW, cell_bytes, AM).total;
-    if (eng->lds_bytes > 160 * 1024) {
+    eng->roll_lds_bytes = roll_E ? sizeof(int32_t) * (size_t)rw::make_lds_layout(roll_E, N, eng->q_runtime ? 2 * N : Q, HW, SW, eng->OW, cell_bytes, AM).total
+                                 : eng->lds_bytes;
+    if (std::max(eng->lds_bytes, eng->roll_lds_bytes) > 160 * 1024) {
         fail(eng, RW_ERR_INVALID_ARG, "LDS footprint %zu B exceeds 160 KiB; lower envs_per_workgroup", eng->lds_bytes);
         return bail(RW_ERR_INVALID_ARG);
     }
-    if (eng->lds_bytes > 64 * 1024) {
+    if (std::max(eng->lds_bytes, eng->roll_lds_bytes) > 64 * 1024) {
         hipError_t lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(eng->kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->lds_bytes);
         if (lds_err == hipSuccess)
             lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(eng->kernel_rollout),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->lds_bytes);
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->roll_lds_bytes);
         if (lds_err == hipSuccess && eng->kernel_nt)
             lds_err = hipFuncSetAttribute(reinterpret_cast<const void *>(eng->kernel_nt),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)eng->lds_bytes);
@@ -648,7 +687,11 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // 3.72 us per step, medium-6ag-hard x 8192 4.20 -> 3.94, small-8ag 8.89 -> 8.33, medium-13ag 14.5 -> 13.85, large-16ag 21.75 -> 21.25
         // (profiles/r06_prio_rollout.txt) — so only the size limit applies to them.
         const bool fits = (double)B * N * eng->L * 4 <= 200e6;
-        eng->prio = fits && !(R == 1 && N >= 13 && N <= 16);
+        // (13 .. 16 agents: on their 4-env workgroups with the priority; on 8-env workgroups — the tiny warehouse has no 4-env build — with it
+        //  only up to half a round of workgroups, where the stagger is a loss: 4096 envs large-16ag 9.52 us with the stagger, 9.00 without,
+        //  8.80 with the priority instead; 8192: small-14ag 12.65 / 11.26 / 10.84; profiles/r06_1316_matrix.txt)
+        const bool wide8_small = 2 * (long long)eng->n_wg <= per_cu * n_cu;
+        eng->prio = fits && !(R == 1 && N >= 13 && N <= 16 && !wide4 && !wide8_small);
         eng->prio_rollout = fits;
         const char *pr = rw_hook("RWARE_PRIO");  // (A/B and test hooks: 0 = off, 1 = on whatever the shape; an explicit flag of the caller wins)
         if (pr && (pr[0] == '0' || pr[0] == '1')) eng->prio = pr[0] == '1';
@@ -673,7 +716,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // it none (profiles/r06_cfg5_stagger_prio.txt: config 5's shard 33.9 against 34.3 with the 40 ticks, x 8192 19.56 / 19.66).
         if (pow2 && N >= 13 && N <= 16 && per_cu > 0) {
             const long long resident = per_cu * n_cu, wg = (long long)eng->n_wg;
-            if (R == 1) eng->stagger_ticks = (wg <= resident || wg >= 4 * resident) ? 55 : 0;
+            if (R == 1) eng->stagger_ticks = (!wide4 && ((2 * wg > resident && wg <= resident) || wg >= 4 * resident)) ? 55 : 0;
             else if (R == 2) eng->stagger_ticks = (!eng->prio && wg <= 2 * resident) ? 40 : 0;
         }
         const char *st = rw_hook("RWARE_STAGGER_TICKS");  // (A/B and test hook: 0 = off, n = ticks whatever the launch size)

@@ -6,7 +6,7 @@
 // honoured ONLY when RWARE_HOOKS=1 is set as well — a production process that happens to inherit one of them runs the rules.
 //   RWARE_OBS_STORES=cached|stream   RWARE_STAGGER_TICKS=n   RWARE_PREFER_QRT=1   RWARE_JIT=off|force   RWARE_JIT_LIBRARY=path
 //   RWARE_JIT_NO_CACHE=1   RWARE_PIPE=0|1   RWARE_PIPE_E=n   RWARE_PIPE_WGS_PER_CU=n   RWARE_PIPE_GRID=n   RWARE_MULTI_THREADS=0|1
-//   RWARE_SELFTEST_BREAK=1   RWARE_PRIO=0|1   RWARE_PRIO_ROLLOUT=0|1
+//   RWARE_SELFTEST_BREAK=1   RWARE_PRIO=0|1   RWARE_PRIO_ROLLOUT=0|1   RWARE_WIDE_E4=0|1
 // (RWARE_JIT_CACHE — where compiled code objects are kept — is configuration, not a hook, and is read unconditionally.)
 // A hook variable that is set while RWARE_HOOKS is not is IGNORED — and says so once per variable on stderr, so that a script written
 // against an older library (which read e.g. RWARE_JIT=off unconditionally) does not change behaviour silently.

@@ -955,7 +955,9 @@ def test_wave_priority_is_a_create_time_rule_and_does_not_change_results(monkeyp
         env.close()
         return v
     assert wp("rware-small-4ag-v1", 64) == 3 and wp("rware-small-12ag-v1", 8) == 3 and wp("rware-small-17ag-v1", 8) == 3
-    assert wp("rware-medium-13ag-v1", 8) == 2 and wp("rware-large-16ag-v1", 8) == 2   # (their rollouts gain, their per-step launches lose)
+    # 13 .. 16 agents at one full round of 8-env workgroups (the emulated device has one CU: 8 workgroups, 64 envs): their rollouts gain,
+    # their start-staggered per-step launches lose (below and above that batch they run on 4-env workgroups WITH the priority: next test)
+    assert wp("rware-medium-13ag-v1", 64) == 2 and wp("rware-large-16ag-v1", 64) == 2
     assert wp("rware-large-16ag-v1", 8, sensor_range=2) == 3       # BASELINE config 5's shape
     monkeypatch.setenv("RWARE_PRIO", "0")
     assert wp("rware-small-4ag-v1", 64) == 2
@@ -963,10 +965,10 @@ def test_wave_priority_is_a_create_time_rule_and_does_not_change_results(monkeyp
     assert wp("rware-small-4ag-v1", 64) == 0
     monkeypatch.delenv("RWARE_PRIO_ROLLOUT")
     monkeypatch.setenv("RWARE_PRIO", "1")
-    assert wp("rware-medium-13ag-v1", 8) == 3
+    assert wp("rware-medium-13ag-v1", 64) == 3
     monkeypatch.delenv("RWARE_PRIO")
     # the caller's flag (RW_PRIO_OFF / RW_PRIO_ON; what make_pipelines passes for small sub-batches) wins over rule and hooks
-    assert wp("rware-small-4ag-v1", 64, wave_priority=False) == 0 and wp("rware-medium-13ag-v1", 8, wave_priority=True) == 3
+    assert wp("rware-small-4ag-v1", 64, wave_priority=False) == 0 and wp("rware-medium-13ag-v1", 64, wave_priority=True) == 3
     monkeypatch.setenv("RWARE_PRIO", "1")
     assert wp("rware-small-4ag-v1", 64, wave_priority=False) == 0
     kw = rware_amd.env_kwargs("rware-small-4ag-v1")
@@ -985,6 +987,56 @@ def test_wave_priority_is_a_create_time_rule_and_does_not_change_results(monkeyp
     sa, sb = on.get_state(), off.get_state()
     assert all(np.array_equal(sa[k], sb[k]) for k in sa)
     on.close(); off.close()
+
+
+def test_13_to_16_agents_step_on_4_env_workgroups_and_roll_out_on_8(monkeypatch):
+    """Round 6: 13 .. 16 agents at sensor_range 1 — the per-step launches run on 4-env workgroups (one agent wavefront each) at raised
+    wavefront priority below one full round of 8-env workgroups and between one and four rounds, on the start-staggered 8-env build at
+    exactly one round and from four rounds on; the fused rollouts keep the 8-env build at every batch, so ONE engine launches its two
+    kernels with different geometries.  The rule (the emulated device has one CU: a round is 8 workgroups), the hook, and per-step
+    launches interleaved with fused rollouts against the oracle."""
+    def geom(env_id, B):
+        env = rware_amd.WarehouseVecEnv(B, library=LIB, **rware_amd.env_kwargs(env_id))
+        i = env.engines[0].info
+        out = (i.envs_per_workgroup, i.n_workgroups, i.wave_priority, i.stagger_ticks)
+        env.close()
+        return out
+    assert geom("rware-large-16ag-v1", 32) == (4, 8, 3, 0)          # half a round of 8-env workgroups: 4-env, priority, no stagger
+    assert geom("rware-large-16ag-v1", 64) == (8, 8, 2, 55)         # exactly one round: the staggered 8-env launch
+    assert geom("rware-large-16ag-v1", 128) == (4, 32, 3, 0)        # two rounds
+    assert geom("rware-large-16ag-v1", 256) == (8, 32, 2, 55)       # four rounds
+    assert geom("rware-medium-13ag-v1", 32)[0] == 4 and geom("rware-small-14ag-v1", 128)[0] == 4
+    assert geom("rware-tiny-14ag-v1", 32) == (8, 4, 3, 0)           # (the tiny warehouse has no 4-env build: 8-env, priority up to half a round)
+    assert geom("rware-tiny-14ag-v1", 64) == (8, 8, 2, 55) and geom("rware-small-12ag-v1", 32)[0] == 8 and geom("rware-small-17ag-v1", 32)[0] == 8
+    monkeypatch.setenv("RWARE_WIDE_E4", "0")
+    assert geom("rware-large-16ag-v1", 32)[0] == 8
+    monkeypatch.setenv("RWARE_WIDE_E4", "1")
+    assert geom("rware-large-16ag-v1", 64) == (4, 16, 3, 0)
+    monkeypatch.delenv("RWARE_WIDE_E4")
+    for env_id, B in (("rware-large-16ag-v1", 32), ("rware-medium-13ag-v1", 128)):
+        kw = rware_amd.env_kwargs(env_id)
+        kw["max_steps"] = 9
+        kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+        N = kw["n_agents"]
+        env = rware_amd.WarehouseVecEnv(B, library=LIB, **kw)
+        assert env.engines[0].info.envs_per_workgroup == 4
+        orc = OracleVecEnv(B, **kw)
+        assert np.array_equal(env.reset(seed=4)[0], orc.reset(seed=4))
+        rng = np.random.default_rng(0)
+        for rnd in range(2):
+            for t in range(5):
+                a = rng.choice(5, size=(B, N), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+                o, r, d, _, _ = env.step(a)
+                o2, r2, d2 = orc.step_autoreset(a, "next_step")
+                assert np.array_equal(o, o2) and np.array_equal(r, r2) and np.array_equal(d, d2.astype(bool)), (env_id, rnd, t)
+            acts = rng.choice(5, size=(6, B, N), p=[.1, .55, .1, .1, .15]).astype(np.int32)
+            obs, rew, term = env.rollout(acts)        # the 8-env rollout build on the state the 4-env step kernel left, and back
+            for t in range(6):
+                o2, r2, d2 = orc.step_autoreset(acts[t], "next_step")
+                assert np.array_equal(obs[t], o2) and np.array_equal(rew[t], r2) and np.array_equal(term[t], d2.astype(bool)), (env_id, rnd, t)
+        st, so = env.get_state(), orc.get_state()
+        assert all(np.array_equal(st[k], so[k]) for k in so), env_id
+        env.close()
 
 
 @pytest.mark.parametrize("env_id,extra,B,mode", [

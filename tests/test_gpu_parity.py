@@ -1322,6 +1322,50 @@ def test_pipelines_of_small_sub_batches_run_without_the_wavefront_priority():
     one.close()
 
 
+def test_13_to_16_agents_step_on_4_env_workgroups_and_roll_out_on_8(monkeypatch):
+    """Round 6: the per-step launches of 13 .. 16 agents (sensor_range 1) run on 4-env workgroups at raised wavefront priority below one
+    full round of 8-env workgroups (16384 envs) and between one and four rounds, the fused rollouts on the 8-env build at every batch
+    (profiles/r06_1316_matrix.txt, r06_1316_rollout_geom.txt).  The rule as rw_info shows it, and the two kernels of one engine — different
+    launch geometries — against the oracle, per-step launches and fused rollouts interleaved."""
+    for env_id, B, want in (("rware-large-16ag-v1", 4096, (4, 3, 0)), ("rware-large-16ag-v1", 8192, (4, 3, 0)), ("rware-large-16ag-v1", 16384, (8, 2, 55)),
+                            ("rware-large-16ag-v1", 32768, (4, 3, 0)), ("rware-large-16ag-v1", 65536, (8, 0, 55)), ("rware-medium-13ag-v1", 49152, (4, 3, 0)),   # (65536 x 16 agents: 297 MB of observations per step, past the priority's size limit)
+                            ("rware-small-14ag-v1", 24576, (4, 3, 0)), ("rware-tiny-14ag-v1", 4096, (8, 3, 0)), ("rware-tiny-14ag-v1", 16384, (8, 2, 55)),
+                            ("rware-small-12ag-v1", 4096, (8, 3, 0)), ("rware-small-17ag-v1", 32768, (8, 3, 0))):
+        env = rware_amd.WarehouseVecEnv(B, **rware_amd.env_kwargs(env_id))
+        i = env.engines[0].info
+        assert (i.envs_per_workgroup, i.wave_priority, i.stagger_ticks) == want, (env_id, B)
+        env.close()
+    monkeypatch.setenv("RWARE_WIDE_E4", "0")
+    env = rware_amd.WarehouseVecEnv(4096, **rware_amd.env_kwargs("rware-large-16ag-v1"))
+    assert env.engines[0].info.envs_per_workgroup == 8
+    env.close()
+    monkeypatch.delenv("RWARE_WIDE_E4")
+    for env_id, B in (("rware-large-16ag-v1", 4096), ("rware-medium-13ag-v1", 32768), ("rware-small-15ag-v1", 8192)):
+        kw = rware_amd.env_kwargs(env_id)
+        kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
+        kw["max_steps"] = 17
+        N = kw["n_agents"]
+        env = rware_amd.WarehouseVecEnv(B, **kw)
+        assert env.engines[0].info.envs_per_workgroup == 4
+        orc = OracleVecEnv(B, **kw)
+        assert np.array_equal(env.reset(seed=9)[0], orc.reset(seed=9))
+        rng = np.random.default_rng(2)
+        for rnd in range(2):
+            for t in range(12):
+                a = rng.choice(5, size=(B, N), p=[0.1, 0.55, 0.1, 0.1, 0.15]).astype(np.int32)
+                obs, rew, term, _, _ = env.step(a)
+                o2, r2, d2 = orc.step_autoreset(a, "next_step")
+                assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, d2.astype(bool)), (env_id, rnd, t)
+            tape = rng.choice(5, size=(8, B, N), p=[0.1, 0.55, 0.1, 0.1, 0.15]).astype(np.int32)
+            _, rew, term = env.rollout(tape, want_obs=False)
+            for t in range(8):
+                _, r2, d2 = orc.step_autoreset(tape[t], "next_step")
+                assert np.array_equal(rew[t], r2) and np.array_equal(term[t], d2.astype(bool)), (env_id, rnd, t)
+        st, so = env.get_state(), orc.get_state()
+        assert all(np.array_equal(st[k], so[k]) for k in so), env_id
+        env.close()
+
+
 def test_two_pipelines_on_one_device_match_the_single_engine():
     """Double-buffered sampling (bench.py's `two_pipelines`): the batch as two engines on one device, own streams, stepped
     CONCURRENTLY by one launcher thread each, against one engine over the whole batch — same observations and state."""
