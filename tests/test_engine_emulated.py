@@ -747,8 +747,11 @@ def test_agent_count_static_builds_read_the_queue_length_at_run_time(env_id, ext
     B, N = 32, kw["n_agents"]
     env = rware_amd.WarehouseVecEnv(B, library=LIB, **kw)
     assert env.engines[0].info.specialised == 1
-    # (geometry by the measured rules of rware_static_table.h: 16 envs up to 4 agents, 8 from 5 on)
-    assert env.engines[0].info.build_kind == 2 and env.engines[0].info.envs_per_workgroup == (16 if N <= 4 else 8)
+    # (geometry by the measured rules of rware_static_table.h / rw_create: 16 envs up to 4 agents, 8 from 5 on — except the per-step
+    #  launches of 13 .. 16 agents below one round of 8-env workgroups, which run on the 4-env build where the warehouse size has one;
+    #  the fused rollout further down then runs on the 8-env build of the same engine)
+    wide4 = 13 <= N <= 16 and "tiny" not in env_id
+    assert env.engines[0].info.build_kind == 2 and env.engines[0].info.envs_per_workgroup == (16 if N <= 4 else 4 if wide4 else 8)
     orc = OracleVecEnv(B, **kw)
     assert np.array_equal(env.reset(seed=14)[0], orc.reset(seed=14))
     rng = np.random.default_rng(16)
