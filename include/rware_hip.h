@@ -322,7 +322,7 @@ typedef struct rw_info {
     int32_t num_envs, grid_h, grid_w, n_agents, request_queue_size, n_shelves, obs_length;
     int32_t envs_per_workgroup, threads_per_workgroup, n_workgroups, lds_bytes;   /* of the per-step launches; the fused rollout may run on another
                              build of the same shape (13 .. 16 agents: per-step launches on 4-env workgroups below one round of workgroups and
-                             between one and four, rollouts on 8-env ones; rw_create's measured rule) */
+                             between one and four, rollouts on 8-env ones; 17 .. 19 agents below 8192 envs likewise; rw_create's measured rule) */
     int32_t device_id, compute_units;
     int32_t specialised;  /* 1: a kernel build with this task's shapes folded in at compile time is in use */
     int32_t wave_priority; /* bit 0: the per-step launches raise their wavefronts' priority (s_setprio 3) from the start of the kernel to

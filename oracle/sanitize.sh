@@ -79,10 +79,17 @@ be.env.close()
 kw = rware_amd.env_kwargs("rware-medium-6ag-hard-v1"); kw["reward_type"] = 1; kw["max_steps"] = 12
 against_oracle("generic kernel (medium-6ag-hard, 5 envs, 128 threads)", 5, 30, dict(envs_per_workgroup=4, threads_per_workgroup=128), kw)
 # per-cell agent phases (kCell): the LDS atomicMax chain walks, the four-neighbour winner test, four-ballot goal flags — crowded on purpose
+os.environ["RWARE_WIDE_E4"] = "0"   # (the 8-env builds of these shapes; rw_create's rule would give so small a batch the 4-env ones: next two cases)
 kw = rware_amd.env_kwargs("rware-small-10ag-v1"); kw["reward_type"] = 1; kw["max_steps"] = 15
 against_oracle("kCell small-10ag (agent-count-static, E 8)", 16, 40, {}, kw, want=lambda i: (int(i.build_kind) == 2 and int(i.envs_per_workgroup) == 8) or sys.exit("not the kCell build"))
 kw = rware_amd.env_kwargs("rware-large-16ag-v1"); kw["reward_type"] = 2; kw["max_steps"] = 15
-against_oracle("kCell large-16ag (agent-count-static, E 8, TWO_STAGE)", 16, 30, {}, kw, want=lambda i: int(i.build_kind) == 2 or sys.exit("not the kCell build"))
+against_oracle("kCell large-16ag (agent-count-static, E 8, TWO_STAGE)", 16, 30, {}, kw, want=lambda i: (int(i.build_kind) == 2 and int(i.envs_per_workgroup) == 8) or sys.exit("not the 8-env kCell build"))
+del os.environ["RWARE_WIDE_E4"]
+# round 6: the same shapes as rw_create launches them at this batch — per-step kernel on 4-env workgroups (and, 16 agents, the fused rollout on 8-env ones)
+kw = rware_amd.env_kwargs("rware-small-10ag-v1"); kw["reward_type"] = 1; kw["max_steps"] = 15
+against_oracle("kCell small-10ag on the 4-env build (rw_create's rule)", 16, 25, {}, kw, want=lambda i: int(i.envs_per_workgroup) == 4 or sys.exit("not the 4-env build"))
+kw = rware_amd.env_kwargs("rware-large-16ag-v1"); kw["reward_type"] = 1; kw["max_steps"] = 15
+against_oracle("kCell large-16ag on the 4-env build (rw_create's rule)", 16, 20, {}, kw, want=lambda i: int(i.envs_per_workgroup) == 4 or sys.exit("not the 4-env build"))
 kw = rware_amd.env_kwargs("rware-large-16ag-v1"); kw["sensor_range"] = 2; kw["reward_type"] = 1; kw["max_steps"] = 12
 against_oracle("BASELINE config 5's kernel (large-16ag, sensor_range 2, exact, E 4)", 8, 25, {}, kw, want=lambda i: int(i.build_kind) == 1 or sys.exit("not the exact build"))
 # the chunk-pipelined persistent builds (make PIPE=1): 2 persistent workgroups walk 4 chunks each, two LDS chunk buffers

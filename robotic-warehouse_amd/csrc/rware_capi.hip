@@ -516,16 +516,25 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // At exactly one round (16384 envs) and from four rounds on the staggered 8-env launch stays (16384: medium-13ag 16.2 against 16.6,
         // large-14ag 15.9 / 16.7; 65536: small-16ag 56.7 / 60.9, large-16ag 58.9 / 63.6).  The FUSED ROLLOUTS keep the 8-env build at every
         // batch (4-env: +10 .. +47 %, profiles/r06_1316_rollout_geom.txt): the engine then launches its two kernels with different geometries.
+        // 9 .. 12 and 17 .. 19 agents (profiles/r06_e4_small_batches.txt, r06_e4_others.txt): the 4-env build wins while its workgroups stay
+        // under ONE round (fewer than 8 per CU: below 8192 envs) — small-10ag x 4096 8.47 -> 7.17 us, x 6144 8.87 -> 7.69, small-12ag x 4096
+        // 9.27 -> 7.77, small-19ag x 4096 13.33 -> 11.31, x 6144 14.15 -> 12.06 — and loses from there on (small-10ag x 8192 9.24 -> 10.46).
+        // Their fused rollouts: 9 .. 12 agents gain likewise (small-10ag x 4096 6.12 -> 5.02 us per step) and follow; 17 .. 19 agents do not
+        // (small-17ag x 4096 9.0 -> 12.9) and keep the 8-env build.
         int want_e = 0;
-        if (geom_default && R == 1 && N >= 13 && N <= 16 && !eng->image && eng->msg_bits == 0 && B % 4 == 0) {
-            const long long wg8 = ((long long)B + 7) / 8, resident = 8LL * std::max(1, eng->prop.multiProcessorCount);
+        bool roll_follows = false;  // the fused rollout runs on the per-step launch's build (else on the table's own choice)
+        if (geom_default && R == 1 && N >= 9 && N <= 19 && !eng->image && eng->msg_bits == 0 && B % 4 == 0) {
+            const long long resident = 8LL * std::max(1, eng->prop.multiProcessorCount);
+            const long long wg8 = ((long long)B + 7) / 8, wg4 = ((long long)B + 3) / 4;
+            const bool two_waves = N >= 13 && N <= 16;  // (an 8-env workgroup of theirs holds two FULL agent wavefronts)
             const char *e4 = rw_hook("RWARE_WIDE_E4");  // (A/B and test hook: 0 = never, 1 = at every batch)
-            if (e4 ? e4[0] == '1' : (wg8 < resident || (wg8 > resident && wg8 < 4 * resident))) want_e = 4;
+            if (e4 ? e4[0] == '1' : two_waves ? (wg8 < resident || (wg8 > resident && wg8 < 4 * resident)) : wg4 < resident) want_e = 4;
+            roll_follows = N <= 12;
         }
         const StaticEntry *best = want_e ? find(want_e) : nullptr;
         const StaticEntry *best_roll = nullptr;
-        if (best) best_roll = find(0);            // (the rollouts' build: the table's own choice)
-        if (!best || !best_roll || best_roll->Q != best->Q) { best = find(0); best_roll = nullptr; want_e = 0; }  // (no 4-env build of this shape: the tiny warehouse)
+        if (best && !roll_follows) best_roll = find(0);            // (the rollouts' build: the table's own choice)
+        if (!best || (!roll_follows && (!best_roll || best_roll->Q != best->Q))) { best = find(0); best_roll = nullptr; want_e = 0; }  // (no 4-env build of this shape: the tiny warehouse)
         // event counters (RW_STATS_ON): only kernels compiled with the counting code (RW_STATS_BUILD) will do — the generic ones, a run-time
         // compiled exact-shape build (below), and — in a library whose specialised builds were made with the switch — those
         if (best && want_stats && !rw_tab::static_has_stats()) {
@@ -687,7 +696,7 @@ int rw_create(const rw_config *cfg, rw_engine **out) {
         // 3.72 us per step, medium-6ag-hard x 8192 4.20 -> 3.94, small-8ag 8.89 -> 8.33, medium-13ag 14.5 -> 13.85, large-16ag 21.75 -> 21.25
         // (profiles/r06_prio_rollout.txt) — so only the size limit applies to them.
         const bool fits = (double)B * N * eng->L * 4 <= 200e6;
-        // (13 .. 16 agents: on their 4-env workgroups with the priority; on 8-env workgroups — the tiny warehouse has no 4-env build — with it
+        // (13 .. 16 agents — `wide4` below is only ever read for them: on their 4-env workgroups with the priority; on 8-env workgroups — the tiny warehouse has no 4-env build — with it
         //  only up to half a round of workgroups, where the stagger is a loss: 4096 envs large-16ag 9.52 us with the stagger, 9.00 without,
         //  8.80 with the priority instead; 8192: small-14ag 12.65 / 11.26 / 10.84; profiles/r06_1316_matrix.txt)
         const bool wide8_small = 2 * (long long)eng->n_wg <= per_cu * n_cu;

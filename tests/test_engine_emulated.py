@@ -1010,13 +1010,17 @@ def test_13_to_16_agents_step_on_4_env_workgroups_and_roll_out_on_8(monkeypatch)
     assert geom("rware-large-16ag-v1", 256) == (8, 32, 2, 55)       # four rounds
     assert geom("rware-medium-13ag-v1", 32)[0] == 4 and geom("rware-small-14ag-v1", 128)[0] == 4
     assert geom("rware-tiny-14ag-v1", 32) == (8, 4, 3, 0)           # (the tiny warehouse has no 4-env build: 8-env, priority up to half a round)
-    assert geom("rware-tiny-14ag-v1", 64) == (8, 8, 2, 55) and geom("rware-small-12ag-v1", 32)[0] == 8 and geom("rware-small-17ag-v1", 32)[0] == 8
+    assert geom("rware-tiny-14ag-v1", 64) == (8, 8, 2, 55)
+    # 9 .. 12 and 17 .. 19 agents: the 4-env build while its workgroups stay under one round (here: fewer than 8), the 8-env one from there on
+    assert geom("rware-small-10ag-v1", 16) == (4, 4, 3, 0) and geom("rware-small-19ag-v1", 28)[0] == 4 and geom("rware-tiny-10ag-v1", 16)[0] == 8
+    assert geom("rware-small-12ag-v1", 32)[0] == 8 and geom("rware-small-17ag-v1", 32)[0] == 8 and geom("rware-small-8ag-v1", 16)[0] == 8
     monkeypatch.setenv("RWARE_WIDE_E4", "0")
     assert geom("rware-large-16ag-v1", 32)[0] == 8
     monkeypatch.setenv("RWARE_WIDE_E4", "1")
     assert geom("rware-large-16ag-v1", 64) == (4, 16, 3, 0)
     monkeypatch.delenv("RWARE_WIDE_E4")
-    for env_id, B in (("rware-large-16ag-v1", 32), ("rware-medium-13ag-v1", 128)):
+    # (9 .. 12 agents: the fused rollout follows onto the 4-env build; 13 .. 19: it stays on the 8-env one)
+    for env_id, B in (("rware-large-16ag-v1", 32), ("rware-medium-13ag-v1", 128), ("rware-small-10ag-v1", 16), ("rware-small-19ag-v1", 16)):
         kw = rware_amd.env_kwargs(env_id)
         kw["max_steps"] = 9
         kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])

@@ -1330,7 +1330,10 @@ def test_13_to_16_agents_step_on_4_env_workgroups_and_roll_out_on_8(monkeypatch)
     for env_id, B, want in (("rware-large-16ag-v1", 4096, (4, 3, 0)), ("rware-large-16ag-v1", 8192, (4, 3, 0)), ("rware-large-16ag-v1", 16384, (8, 2, 55)),
                             ("rware-large-16ag-v1", 32768, (4, 3, 0)), ("rware-large-16ag-v1", 65536, (8, 0, 55)), ("rware-medium-13ag-v1", 49152, (4, 3, 0)),   # (65536 x 16 agents: 297 MB of observations per step, past the priority's size limit)
                             ("rware-small-14ag-v1", 24576, (4, 3, 0)), ("rware-tiny-14ag-v1", 4096, (8, 3, 0)), ("rware-tiny-14ag-v1", 16384, (8, 2, 55)),
-                            ("rware-small-12ag-v1", 4096, (8, 3, 0)), ("rware-small-17ag-v1", 32768, (8, 3, 0))):
+                            # 9 .. 12 and 17 .. 19 agents: the 4-env build below 8192 envs (its workgroups stay under one round), the 8-env one from there on
+                            ("rware-small-12ag-v1", 4096, (4, 3, 0)), ("rware-small-10ag-v1", 6144, (4, 3, 0)), ("rware-small-10ag-v1", 8192, (8, 3, 0)),
+                            ("rware-small-19ag-v1", 4096, (4, 3, 0)), ("rware-small-17ag-v1", 32768, (8, 3, 0)), ("rware-tiny-10ag-v1", 4096, (8, 3, 0)),
+                            ("rware-small-8ag-v1", 4096, (8, 3, 0))):
         env = rware_amd.WarehouseVecEnv(B, **rware_amd.env_kwargs(env_id))
         i = env.engines[0].info
         assert (i.envs_per_workgroup, i.wave_priority, i.stagger_ticks) == want, (env_id, B)
@@ -1340,7 +1343,9 @@ def test_13_to_16_agents_step_on_4_env_workgroups_and_roll_out_on_8(monkeypatch)
     assert env.engines[0].info.envs_per_workgroup == 8
     env.close()
     monkeypatch.delenv("RWARE_WIDE_E4")
-    for env_id, B in (("rware-large-16ag-v1", 4096), ("rware-medium-13ag-v1", 32768), ("rware-small-15ag-v1", 8192)):
+    # (9 .. 12 agents: the fused rollout follows onto the 4-env build; 13 .. 19: it stays on the 8-env one)
+    for env_id, B in (("rware-large-16ag-v1", 4096), ("rware-medium-13ag-v1", 32768), ("rware-small-15ag-v1", 8192), ("rware-small-10ag-v1", 4096),
+                      ("rware-small-19ag-v1", 6144)):
         kw = rware_amd.env_kwargs(env_id)
         kw["reward_type"] = rware_amd.enums.enum_value(kw["reward_type"])
         kw["max_steps"] = 17
